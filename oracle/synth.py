@@ -1,0 +1,126 @@
+"""Seeded synthetic weights / inputs for parity tests and the bench (TEST INFRASTRUCTURE).
+
+There are no checkpoints offline, so every test/bench model uses random-init
+weights.  The reference's own init (``init_weights`` gan_utils.py:25-28, sigma
+0.01 on weight_v, g=||v||) gives |out| <= 0.06 and bias-dominated signals,
+which makes parity checks insensitive.  We use the
+variance-preserving scheme of SURVEY.md §8(d) instead:
+
+  weight_v ~ N(0,1), weight_g ~ gain*U(0.7,1.3), bias ~ N(0,0.05),
+  Snake alpha/beta ~ N(0,0.3) (log-scale), un-normed ``weight`` ~ N(0,1)/sqrt(fan_in).
+
+Each tensor is drawn from its own generator seeded by crc32(key) ^ seed, so the
+values do not depend on key order or on which other tensors exist; they are
+reproducible wherever the same torch CPU RNG runs (same image on the GPU box).
+
+``*_param_shapes`` restate the reference constructors' parameter lists
+(hifigan.py:151-199, :376-422; bigvgan.py:232-306) -- pinned against the real
+reference ``state_dict`` key/shape lists committed in tests/golden/keys_*.json.
+"""
+
+from __future__ import annotations
+
+import zlib
+from collections import OrderedDict
+
+import torch
+
+from .vocoder_oracle import kaiser_sinc_filter1d
+
+
+def _wn_conv(shapes, prefix, cout, cin, k, transposed=False, wn=True, bias=True):
+    d0 = cin if transposed else cout
+    d1 = cout if transposed else cin
+    if wn:  # weight_norm re-registers g/v AFTER bias
+        if bias:
+            shapes[prefix + ".bias"] = (cout,)
+        shapes[prefix + ".weight_g"] = (d0, 1, 1)
+        shapes[prefix + ".weight_v"] = (d0, d1, k)
+    else:
+        shapes[prefix + ".weight"] = (d0, d1, k)
+        if bias:
+            shapes[prefix + ".bias"] = (cout,)
+
+
+def _generator_param_shapes(n_in, hp, vits=False, gin_channels=0, ups_fmt="ups.{i}", act=None):
+    s = OrderedDict()
+    c0 = hp["upsample_initial_channel"]
+    _wn_conv(s, "conv_pre", c0, n_in, 7, wn=not vits)
+    for i, (u, k) in enumerate(zip(hp["upsample_rates"], hp["upsample_kernel_sizes"])):
+        _wn_conv(s, ups_fmt.format(i=i), c0 // 2 ** (i + 1), c0 // 2**i, k, transposed=True)
+    nk = len(hp["resblock_kernel_sizes"])
+    ch = c0
+    for i in range(len(hp["upsample_rates"])):
+        ch = c0 // 2 ** (i + 1)
+        for j, (k, d) in enumerate(zip(hp["resblock_kernel_sizes"], hp["resblock_dilation_sizes"])):
+            pre = f"resblocks.{i * nk + j}"
+            if str(hp["resblock"]) == "1":
+                for p in range(len(d)):
+                    _wn_conv(s, f"{pre}.convs1.{p}", ch, ch, k)
+                for p in range(len(d)):
+                    _wn_conv(s, f"{pre}.convs2.{p}", ch, ch, k)
+                n_act = 2 * len(d)
+            else:
+                for p in range(len(d)):
+                    _wn_conv(s, f"{pre}.convs.{p}", ch, ch, k)
+                n_act = len(d)
+            if act is not None:
+                for m in range(n_act):
+                    act(s, f"{pre}.activations.{m}", ch)
+    if act is not None:
+        act(s, "activation_post", ch)
+    _wn_conv(s, "conv_post", 1, ch, 7, wn=not vits, bias=not vits)
+    if vits and gin_channels:
+        _wn_conv(s, "cond", c0, gin_channels, 1, wn=False)
+    return s
+
+
+def hifigan_param_shapes(n_in, hp, vits=False, gin_channels=0):
+    """Ordered {key: shape} of HiFiGAN (hifigan.py:151-199) or HiFiGAN_vits (:376-422)."""
+    return _generator_param_shapes(n_in, hp, vits=vits, gin_channels=gin_channels)
+
+
+def bigvgan_param_shapes(n_in, hp):
+    """Ordered {key: shape} of BigVGAN (bigvgan.py:232-306) incl. Snake params and the
+    persistent anti-aliasing filter buffers (resample.py:31-34, filter.py:89-90)."""
+    beta = hp["activation"] == "snakebeta"
+
+    def act(s, prefix, c):
+        s[prefix + ".act.alpha"] = (c,)
+        if beta:
+            s[prefix + ".act.beta"] = (c,)
+        s[prefix + ".upsample.filter"] = (1, 1, 12)
+        s[prefix + ".downsample.lowpass.filter"] = (1, 1, 12)
+
+    return _generator_param_shapes(n_in, hp, ups_fmt="ups.{i}.0", act=act)
+
+
+def synth_tensor(key, shape, seed=1234, g_gain=1.0):
+    gen = torch.Generator().manual_seed((zlib.crc32(key.encode()) ^ seed) & 0x7FFFFFFF)
+    leaf = key.rsplit(".", 1)[-1]
+    if leaf == "filter":
+        return kaiser_sinc_filter1d(0.25, 0.3, 12).reshape(shape)
+    if leaf == "weight_v":
+        return torch.randn(shape, generator=gen)
+    if leaf == "weight_g":
+        return g_gain * (0.7 + 0.6 * torch.rand(shape, generator=gen))
+    if leaf == "bias":
+        return 0.05 * torch.randn(shape, generator=gen)
+    if leaf in ("alpha", "beta"):
+        return 0.3 * torch.randn(shape, generator=gen)
+    if leaf == "weight":
+        fan_in = 1
+        for d in shape[1:]:
+            fan_in *= d
+        return torch.randn(shape, generator=gen) / fan_in**0.5
+    raise KeyError(key)
+
+
+def synth_state_dict(shapes, seed=1234, g_gain=1.0):
+    return OrderedDict((k, synth_tensor(k, tuple(v), seed, g_gain)) for k, v in shapes.items())
+
+
+def synth_mel(B, n_mel, T, seed=0):
+    """Log-mel-like input: randn*2-5."""
+    gen = torch.Generator().manual_seed(seed)
+    return torch.randn(B, n_mel, T, generator=gen) * 2 - 5

@@ -1,0 +1,432 @@
+"""CPU oracle for the Amphion vocoder-inference hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``amphion_amd/`` may import this file;
+only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg use it, and only as the checker / the timed CPU baseline.
+
+This is a *restatement* of the reference algorithm as plain functions over a
+``state_dict`` (reference key names, Appendix A of SURVEY.md).  The reference
+itself has no arithmetic of its own on this path: every op is a call into
+torch (``env.sh:15`` pins torch==2.0.1; this image has 2.10) or librosa 0.9.1
+(``env.sh:13``, absent here).  The restatement therefore calls the same
+``torch.nn.functional`` primitives on CPU for the convolutions and writes the
+rest (weight-norm fold, Snake, Kaiser-sinc filter, Slaney mel filterbank,
+framing + DFT) out explicitly.
+
+Parity pin: the reference has no tests / golden vectors, so the
+oracle is pinned against outputs of the reference classes themselves, imported
+in the build container by ``tests/golden/make_golden.py`` and committed under
+``tests/golden/*.npz`` (``tests/test_oracle_golden.py`` checks them).
+
+Every function cites the reference file:line it follows (paths relative to
+/root/reference).
+"""
+
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+LRELU_SLOPE = 0.1  # models/vocoders/gan/generator/hifigan.py:14, bigvgan.py:17
+
+
+# ----------------------------------------------------------------------------
+# small helpers
+# ----------------------------------------------------------------------------
+def get_padding(kernel_size: int, dilation: int = 1) -> int:
+    """modules/vocoder_blocks/gan_utils.py:12-13"""
+    return int((kernel_size * dilation - dilation) / 2)
+
+
+def fold_weight_norm(g: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """torch.nn.utils.weight_norm (dim=0): w = g * v / ||v||_2 over all dims but 0.
+
+    Used on every conv of the generators (hifigan.py:23,157,176,199).  For
+    ConvTranspose1d dim 0 is C_in.  No epsilon.
+    """
+    norm = v.reshape(v.shape[0], -1).norm(dim=1).reshape(-1, *([1] * (v.dim() - 1)))
+    return g * (v / norm)
+
+
+def conv_params(sd, prefix, dtype):
+    """Return (weight, bias) for ``prefix`` accepting weight-normed or folded keys
+    (vocoder_inference.py:270-332 loads either form; remove_weight_norm collapses
+    weight_g/weight_v to weight)."""
+    if prefix + ".weight" in sd:
+        w = torch.as_tensor(sd[prefix + ".weight"]).to(dtype)
+    else:
+        g = torch.as_tensor(sd[prefix + ".weight_g"]).to(dtype)
+        v = torch.as_tensor(sd[prefix + ".weight_v"]).to(dtype)
+        w = fold_weight_norm(g, v)
+    b = sd.get(prefix + ".bias", None)
+    if b is not None:
+        b = torch.as_tensor(b).to(dtype)
+    return w, b
+
+
+def _cfg_get(cfg, name):
+    return cfg[name] if isinstance(cfg, dict) else getattr(cfg, name)
+
+
+# ----------------------------------------------------------------------------
+# HiFi-GAN
+# ----------------------------------------------------------------------------
+def resblock1(sd, prefix, x, k, dils, dtype, act=None):
+    """ResBlock1.forward hifigan.py:93-100 (ResBlock1_vits :305-320 with x_mask=None).
+
+    ``act`` = None -> leaky_relu(0.1); otherwise a callable(idx, x) for AMPBlock1
+    (bigvgan.py:137-146: activations[2p] before convs1[p], [2p+1] before convs2[p]).
+    """
+    for p, d in enumerate(dils):
+        w1, b1 = conv_params(sd, f"{prefix}.convs1.{p}", dtype)
+        w2, b2 = conv_params(sd, f"{prefix}.convs2.{p}", dtype)
+        xt = F.leaky_relu(x, LRELU_SLOPE) if act is None else act(2 * p, x)
+        xt = F.conv1d(xt, w1, b1, dilation=d, padding=get_padding(k, d))
+        xt = F.leaky_relu(xt, LRELU_SLOPE) if act is None else act(2 * p + 1, xt)
+        xt = F.conv1d(xt, w2, b2, dilation=1, padding=get_padding(k, 1))
+        x = xt + x
+    return x
+
+
+def resblock2(sd, prefix, x, k, dils, dtype, act=None):
+    """ResBlock2.forward hifigan.py:140-145 / AMPBlock2.forward bigvgan.py:218-224."""
+    for p, d in enumerate(dils):
+        w, b = conv_params(sd, f"{prefix}.convs.{p}", dtype)
+        xt = F.leaky_relu(x, LRELU_SLOPE) if act is None else act(p, x)
+        xt = F.conv1d(xt, w, b, dilation=d, padding=get_padding(k, d))
+        x = xt + x
+    return x
+
+
+def hifigan_forward(sd, hp, mel, dtype=torch.float32, g=None, ups_key="ups.{i}"):
+    """HiFiGAN.forward hifigan.py:203-219 and HiFiGAN_vits.forward hifigan.py:424-443.
+
+    ``hp`` carries resblock, upsample_rates, upsample_kernel_sizes,
+    resblock_kernel_sizes, resblock_dilation_sizes (cfg.model.hifigan.*,
+    hifigan.py:155-199).  ``g`` is the optional VITS speaker condition.
+    """
+    x = torch.as_tensor(mel).to(dtype)
+    rates = list(_cfg_get(hp, "upsample_rates"))
+    uks = list(_cfg_get(hp, "upsample_kernel_sizes"))
+    rks = list(_cfg_get(hp, "resblock_kernel_sizes"))
+    rds = [list(d) for d in _cfg_get(hp, "resblock_dilation_sizes")]
+    rb = resblock1 if str(_cfg_get(hp, "resblock")) == "1" else resblock2
+    nk = len(rks)
+
+    w, b = conv_params(sd, "conv_pre", dtype)
+    x = F.conv1d(x, w, b, padding=3)  # :204
+    if g is not None:  # :426-427
+        wc, bc = conv_params(sd, "cond", dtype)
+        x = x + F.conv1d(torch.as_tensor(g).to(dtype), wc, bc)
+    for i, (u, k) in enumerate(zip(rates, uks)):
+        x = F.leaky_relu(x, LRELU_SLOPE)  # :206
+        w, b = conv_params(sd, ups_key.format(i=i), dtype)
+        x = F.conv_transpose1d(x, w, b, stride=u, padding=(k - u) // 2)  # :207
+        xs = None
+        for j in range(nk):  # :208-213
+            r = rb(sd, f"resblocks.{i * nk + j}", x, rks[j], rds[j], dtype)
+            xs = r if xs is None else xs + r
+        x = xs / nk  # :214
+    x = F.leaky_relu(x)  # default slope 0.01, :215
+    w, b = conv_params(sd, "conv_post", dtype)
+    x = F.conv1d(x, w, b, padding=3)  # :216
+    return torch.tanh(x)  # :217
+
+
+# ----------------------------------------------------------------------------
+# BigVGAN: Snake + anti-aliased activation
+# ----------------------------------------------------------------------------
+def kaiser_sinc_filter1d(cutoff, half_width, kernel_size, dtype=torch.float32):
+    """modules/anti_aliasing/filter.py:30-61 (returns [kernel_size])."""
+    even = kernel_size % 2 == 0
+    half_size = kernel_size // 2
+    delta_f = 4 * half_width
+    A = 2.285 * (half_size - 1) * math.pi * delta_f + 7.95
+    if A > 50.0:
+        beta = 0.1102 * (A - 8.7)
+    elif A >= 21.0:
+        beta = 0.5842 * (A - 21) ** 0.4 + 0.07886 * (A - 21.0)
+    else:
+        beta = 0.0
+    window = torch.kaiser_window(kernel_size, beta=beta, periodic=False)
+    if even:
+        time = torch.arange(-half_size, half_size) + 0.5
+    else:
+        time = torch.arange(kernel_size) - half_size
+    filt = 2 * cutoff * window * torch.sinc(2 * cutoff * time)
+    filt = filt / filt.sum()
+    return filt.to(dtype)
+
+
+def snake(x, alpha, beta=None, logscale=False):
+    """Snake.forward snake.py:51-61 / SnakeBeta.forward snake.py:110-122."""
+    a = alpha.reshape(1, -1, 1).to(x.dtype)
+    b = a if beta is None else beta.reshape(1, -1, 1).to(x.dtype)
+    if logscale:
+        a = torch.exp(a)
+        b = torch.exp(b) if beta is not None else a
+    return x + (1.0 / (b + 0.000000001)) * torch.pow(torch.sin(x * a), 2)
+
+
+def activation1d(x, alpha, beta=None, logscale=False, filt_up=None, filt_down=None):
+    """Activation1d.forward act.py:31-36 with UpSample1d (resample.py:36-45) and
+    DownSample1d/LowPassFilter1d (resample.py:62-65, filter.py:92-99); ratio 2,
+    kernel 12."""
+    ratio, ks = 2, 12
+    C = x.shape[1]
+    if filt_up is None:
+        filt_up = kaiser_sinc_filter1d(0.5 / ratio, 0.6 / ratio, ks, x.dtype)
+    if filt_down is None:
+        filt_down = kaiser_sinc_filter1d(0.5 / ratio, 0.6 / ratio, ks, x.dtype)
+    fu = filt_up.to(x.dtype).reshape(1, 1, ks).expand(C, -1, -1)
+    fd = filt_down.to(x.dtype).reshape(1, 1, ks).expand(C, -1, -1)
+    pad = ks // ratio - 1  # 5
+    pad_left = pad * ratio + (ks - ratio) // 2  # 15
+    pad_right = pad * ratio + (ks - ratio + 1) // 2  # 15
+    y = F.pad(x, (pad, pad), mode="replicate")
+    y = ratio * F.conv_transpose1d(y, fu, stride=ratio, groups=C)
+    y = y[..., pad_left:-pad_right]
+    y = snake(y, alpha, beta, logscale)
+    y = F.pad(y, (ks // 2 - 1, ks // 2), mode="replicate")  # (5, 6)
+    return F.conv1d(y, fd, stride=ratio, groups=C)
+
+
+def bigvgan_forward(sd, hp, mel, dtype=torch.float32):
+    """BigVGAN.forward bigvgan.py:313-331."""
+    x = torch.as_tensor(mel).to(dtype)
+    rates = list(_cfg_get(hp, "upsample_rates"))
+    uks = list(_cfg_get(hp, "upsample_kernel_sizes"))
+    rks = list(_cfg_get(hp, "resblock_kernel_sizes"))
+    rds = [list(d) for d in _cfg_get(hp, "resblock_dilation_sizes")]
+    snakebeta = _cfg_get(hp, "activation") == "snakebeta"
+    if _cfg_get(hp, "activation") not in ("snake", "snakebeta"):
+        raise NotImplementedError(  # bigvgan.py:132-135
+            "activation incorrectly specified. check the config file and look for 'activation'."
+        )
+    logscale = bool(_cfg_get(hp, "snake_logscale"))
+    is1 = str(_cfg_get(hp, "resblock")) == "1"
+    nk = len(rks)
+
+    def make_act(prefix):
+        def act(idx, t):
+            p = f"{prefix}.activations.{idx}"
+            al = torch.as_tensor(sd[p + ".act.alpha"])
+            be = torch.as_tensor(sd[p + ".act.beta"]) if snakebeta else None
+            fu = torch.as_tensor(sd[p + ".upsample.filter"]).reshape(-1)
+            fd = torch.as_tensor(sd[p + ".downsample.lowpass.filter"]).reshape(-1)
+            return activation1d(t, al, be, logscale, fu, fd)
+
+        return act
+
+    w, b = conv_params(sd, "conv_pre", dtype)
+    x = F.conv1d(x, w, b, padding=3)
+    for i, (u, k) in enumerate(zip(rates, uks)):
+        w, b = conv_params(sd, f"ups.{i}.0", dtype)  # nested ModuleList bigvgan.py:261-276
+        x = F.conv_transpose1d(x, w, b, stride=u, padding=(k - u) // 2)  # no lrelu :316-318
+        xs = None
+        for j in range(nk):
+            pre = f"resblocks.{i * nk + j}"
+            fn = resblock1 if is1 else resblock2
+            r = fn(sd, pre, x, rks[j], rds[j], dtype, act=make_act(pre))
+            xs = r if xs is None else xs + r
+        x = xs / nk
+    al = torch.as_tensor(sd["activation_post.act.alpha"])
+    be = torch.as_tensor(sd["activation_post.act.beta"]) if snakebeta else None
+    fu = torch.as_tensor(sd["activation_post.upsample.filter"]).reshape(-1)
+    fd = torch.as_tensor(sd["activation_post.downsample.lowpass.filter"]).reshape(-1)
+    x = activation1d(x, al, be, logscale, fu, fd)  # :327
+    w, b = conv_params(sd, "conv_post", dtype)
+    x = F.conv1d(x, w, b, padding=3)
+    return torch.tanh(x)
+
+
+# ----------------------------------------------------------------------------
+# Mel / STFT front end
+# ----------------------------------------------------------------------------
+def _hz_to_mel_slaney(f):
+    f = np.asarray(f, dtype=np.float64)
+    f_sp = 200.0 / 3
+    mels = f / f_sp
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = np.log(6.4) / 27.0
+    return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-300) / min_log_hz) / logstep, mels)
+
+
+def _mel_to_hz_slaney(m):
+    m = np.asarray(m, dtype=np.float64)
+    f_sp = 200.0 / 3
+    freqs = f_sp * m
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = np.log(6.4) / 27.0
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), freqs)
+
+
+def mel_filterbank(sr, n_fft, n_mels, fmin=0.0, fmax=None):
+    """librosa 0.9.1 ``filters.mel(sr, n_fft, n_mels, fmin, fmax)`` (htk=False,
+    norm="slaney", dtype float32) -- called at utils/mel.py:66-72,133-139,199-205 and
+    utils/stft.py:245-247.  librosa is not in the reference tree; this restates its
+    published algorithm.  Returns float32 [n_mels, n_fft//2+1].
+    """
+    if fmax is None:
+        fmax = float(sr) / 2
+    n_bins = 1 + n_fft // 2
+    fftfreqs = np.linspace(0, float(sr) / 2, n_bins, endpoint=True)
+    mel_pts = np.linspace(_hz_to_mel_slaney(fmin), _hz_to_mel_slaney(fmax), n_mels + 2)
+    mel_f = _mel_to_hz_slaney(mel_pts)
+    fdiff = np.diff(mel_f)
+    ramps = np.subtract.outer(mel_f, fftfreqs)
+    weights = np.zeros((n_mels, n_bins), dtype=np.float64)
+    for i in range(n_mels):
+        lower = -ramps[i] / fdiff[i]
+        upper = ramps[i + 2] / fdiff[i + 1]
+        weights[i] = np.maximum(0, np.minimum(lower, upper))
+    enorm = 2.0 / (mel_f[2 : n_mels + 2] - mel_f[:n_mels])
+    weights *= enorm[:, np.newaxis]
+    return weights.astype(np.float32)
+
+
+def hann_periodic(n, dtype=torch.float32):
+    """torch.hann_window(n) default periodic=True (utils/mel.py:28,76,143)."""
+    k = torch.arange(n, dtype=torch.float64)
+    return (0.5 - 0.5 * torch.cos(2 * math.pi * k / n)).to(dtype)
+
+
+def _stft_center_false(y, n_fft, hop, win, dtype):
+    """torch.stft(center=False, onesided, normalized=False) written as explicit
+    framing * window -> rfft (utils/mel.py:153-164). y: [B, L'] -> [B, bins, F, 2]."""
+    y = y.to(dtype)
+    frames = y.unfold(-1, n_fft, hop)  # [B, F, n_fft]
+    w = hann_periodic(win, dtype)
+    if win < n_fft:  # torch.stft centre-pads the window to n_fft
+        lp = (n_fft - win) // 2
+        w = F.pad(w, (lp, n_fft - win - lp))
+    spec = torch.fft.rfft(frames * w, n=n_fft, dim=-1)  # [B, F, bins]
+    spec = spec.transpose(1, 2)
+    return torch.view_as_real(spec)
+
+
+def _reflect_pad(y, cfg):
+    p = int((cfg.n_fft - cfg.hop_size) / 2)
+    return F.pad(y.unsqueeze(1), (p, p), mode="reflect").squeeze(1)
+
+
+def extract_linear_features(y, cfg, dtype=torch.float32):
+    """utils/mel.py:20-52. y [B, L] -> [B, bins, F] squeezed on dim 0."""
+    y = _reflect_pad(torch.as_tensor(y).to(dtype), cfg)
+    spec = _stft_center_false(y, cfg.n_fft, cfg.hop_size, cfg.win_size, dtype)
+    spec = torch.sqrt(spec.pow(2).sum(-1) + 1e-9)
+    return torch.squeeze(spec, 0)
+
+
+def _mel_common(y, cfg, eps, dtype):
+    y = _reflect_pad(torch.as_tensor(y).to(dtype), cfg)
+    spec = _stft_center_false(y, cfg.n_fft, cfg.hop_size, cfg.win_size, dtype)
+    spec = torch.sqrt(spec.pow(2).sum(-1) + eps)
+    basis = torch.from_numpy(
+        mel_filterbank(cfg.sample_rate, cfg.n_fft, cfg.n_mel, cfg.fmin, cfg.fmax)
+    ).to(dtype)
+    spec = torch.matmul(basis, spec)
+    return torch.log(torch.clamp(spec, min=1e-5))  # utils/mel.py:10-12
+
+
+def extract_mel_features(y, cfg, dtype=torch.float32):
+    """utils/mel.py:111-170 (eps 1e-9, squeeze(0))."""
+    return _mel_common(y, cfg, 1e-9, dtype).squeeze(0)
+
+
+def mel_spectrogram_torch(y, cfg, dtype=torch.float32):
+    """utils/mel.py:55-104 (eps 1e-6, no squeeze)."""
+    return _mel_common(y, cfg, 1e-6, dtype)
+
+
+def amplitude_phase_spectrum(y, cfg, dtype=torch.float32):
+    """utils/mel.py:244-280."""
+    y = _reflect_pad(torch.as_tensor(y).to(dtype), cfg)
+    st = _stft_center_false(y, cfg.n_fft, cfg.hop_size, cfg.win_size, dtype)
+    if st.size(0) == 1:
+        st = st.squeeze(0)
+    rea, imag = st[..., 0], st[..., 1]
+    log_amp = torch.log(torch.abs(torch.sqrt(rea.pow(2) + imag.pow(2))) + 1e-5)
+    phase = torch.atan2(imag, rea)
+    return log_amp, phase, rea, imag
+
+
+def taco_stft_transform(y, filter_length, hop_length, win_length, dtype=torch.float32):
+    """STFT.transform utils/stft.py:152-181: reflect-pad n_fft/2, conv1d with the
+    windowed Fourier basis [2*cutoff, 1, n_fft], stride hop -> (magnitude, phase)."""
+    y = torch.as_tensor(y).to(dtype)
+    B, L = y.shape
+    cutoff = filter_length // 2 + 1
+    fb = np.fft.fft(np.eye(filter_length))
+    fb = np.vstack([np.real(fb[:cutoff, :]), np.imag(fb[:cutoff, :])])  # stft.py:57-61
+    n = np.arange(win_length, dtype=np.float64)
+    w = 0.5 - 0.5 * np.cos(2 * np.pi * n / win_length)  # scipy get_window("hann", fftbins=True) :67
+    lp = (filter_length - win_length) // 2  # librosa.util.pad_center :68
+    w = np.pad(w, (lp, filter_length - win_length - lp))
+    basis = torch.from_numpy((fb * w[None, :]).astype(np.float32)).to(dtype).unsqueeze(1)
+    x = F.pad(y.view(B, 1, 1, L), (filter_length // 2, filter_length // 2, 0, 0), mode="reflect").squeeze(1)
+    ft = F.conv1d(x, basis, stride=hop_length, padding=0)
+    re, im = ft[:, :cutoff, :], ft[:, cutoff:, :]
+    mag = torch.sqrt(re**2 + im**2)
+    phase = torch.atan2(im, re)
+    return mag, phase
+
+
+def taco_mel_spectrogram(y, filter_length, hop_length, win_length, n_mel, sr, fmin, fmax, dtype=torch.float32):
+    """TacotronSTFT.mel_spectrogram utils/stft.py:259-278 -> (mel, energy)."""
+    mag, _ = taco_stft_transform(y, filter_length, hop_length, win_length, dtype)
+    energy = torch.norm(mag, dim=1)
+    basis = torch.from_numpy(mel_filterbank(sr, filter_length, n_mel, fmin, fmax)).to(dtype)
+    mel = torch.matmul(basis, mag)
+    mel = torch.log(torch.clamp(mel, min=1e-5))  # spectral_normalize, stft.py:249-251
+    return mel, energy
+
+
+# ----------------------------------------------------------------------------
+# configs used by BASELINE.json
+# ----------------------------------------------------------------------------
+def hifigan_v1_hp():
+    """config/vits.json:36-71 (HiFi-GAN V1 hyper-parameters)."""
+    return dict(
+        resblock="1",
+        upsample_rates=[8, 8, 2, 2],
+        upsample_kernel_sizes=[16, 16, 4, 4],
+        upsample_initial_channel=512,
+        resblock_kernel_sizes=[3, 7, 11],
+        resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]],
+    )
+
+
+def hifigan_recipe_hp():
+    """egs/vocoder/gan/hifigan/exp_config.json:14-45 (resblock "2" recipe net)."""
+    return dict(
+        resblock="2",
+        upsample_rates=[8, 8, 4],
+        upsample_kernel_sizes=[16, 16, 8],
+        upsample_initial_channel=256,
+        resblock_kernel_sizes=[3, 5, 7],
+        resblock_dilation_sizes=[[1, 2], [2, 6], [3, 12]],
+    )
+
+
+def bigvgan_base_hp():
+    """egs/vocoder/gan/bigvgan/exp_config.json:14-53."""
+    hp = hifigan_v1_hp()
+    hp.update(activation="snakebeta", snake_logscale=True)
+    return hp
+
+
+def preprocess_22k():
+    """config/fs2.json:25-31."""
+    return SimpleNamespace(sample_rate=22050, n_fft=1024, win_size=1024, hop_size=256, n_mel=80, fmin=0, fmax=8000)
+
+
+def preprocess_24k():
+    """config/vocoder.json:34-40."""
+    return SimpleNamespace(sample_rate=24000, n_fft=1024, win_size=1024, hop_size=256, n_mel=100, fmin=0, fmax=12000)
