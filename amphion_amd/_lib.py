@@ -1,0 +1,131 @@
+"""ctypes binding of libamphion_hip.so (C ABI in include/amphion_hip.h).
+
+There is no CPU fallback anywhere in this package: if the library is missing, or
+a tensor is not on a ROCm device, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libamphion_hip.so")
+
+AMP_MAX_STAGES = 8
+AMP_MAX_KERNELS = 8
+AMP_MAX_DILATIONS = 8
+
+AMP_ARCH_HIFIGAN, AMP_ARCH_BIGVGAN, AMP_ARCH_HIFIGAN_VITS = 0, 1, 2
+AMP_ACT_LRELU, AMP_ACT_SNAKE, AMP_ACT_SNAKEBETA = 0, 1, 2
+
+
+class AmpError(RuntimeError):
+    """A libamphion_hip call returned a negative amp_status."""
+
+    def __init__(self, status, message):
+        super().__init__(f"libamphion_hip error {status}: {message}")
+        self.status = status
+
+
+class amp_gen_desc(ctypes.Structure):
+    _fields_ = [
+        ("arch", c_int32),
+        ("n_in", c_int32),
+        ("upsample_initial_channel", c_int32),
+        ("n_stages", c_int32),
+        ("upsample_rates", c_int32 * AMP_MAX_STAGES),
+        ("upsample_kernel_sizes", c_int32 * AMP_MAX_STAGES),
+        ("n_kernels", c_int32),
+        ("resblock_kernel_sizes", c_int32 * AMP_MAX_KERNELS),
+        ("n_dilations", c_int32 * AMP_MAX_KERNELS),
+        ("resblock_dilation_sizes", (c_int32 * AMP_MAX_DILATIONS) * AMP_MAX_KERNELS),
+        ("resblock_type", c_int32),
+        ("activation", c_int32),
+        ("snake_logscale", c_int32),
+        ("gin_channels", c_int32),
+    ]
+
+
+class amp_mel_desc(ctypes.Structure):
+    _fields_ = [
+        ("n_fft", c_int32),
+        ("win_size", c_int32),
+        ("hop_size", c_int32),
+        ("n_mel", c_int32),
+        ("pad_mode", c_int32),
+        ("mag_eps", c_float),
+        ("log_clip", c_float),
+    ]
+
+
+_SIGNATURES = {
+    "amp_version": (c_int, []),
+    "amp_last_error": (c_char_p, []),
+    "amp_device_count": (c_int, []),
+    "amp_gen_create": (c_int, [POINTER(amp_gen_desc), POINTER(c_void_p)]),
+    "amp_gen_set_weight": (c_int, [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int]),
+    "amp_gen_finalize": (c_int, [c_void_p]),
+    "amp_gen_hop": (c_int, [c_void_p]),
+    "amp_gen_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "amp_gen_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "amp_gen_set_profiling": (c_int, [c_void_p, c_int]),
+    "amp_gen_last_timing_ms": (c_int, [c_void_p, c_int, POINTER(c_float)]),
+    "amp_gen_destroy": (None, [c_void_p]),
+    "amp_conv_create": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, POINTER(c_void_p)]),
+    "amp_conv_out_len": (c_int, [c_void_p, c_int]),
+    "amp_conv_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_float, c_void_p, c_void_p]),
+    "amp_conv_destroy": (None, [c_void_p]),
+    "amp_antialias_snake": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "amp_mel_num_frames": (c_int, [POINTER(amp_mel_desc), c_int]),
+    "amp_mel_forward": (c_int, [POINTER(amp_mel_desc), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the bound library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -m amphion_amd.build` "
+                "(the HIP path has no CPU fallback)"
+            )
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status < 0:
+        raise AmpError(status, lib().amp_last_error().decode("utf-8", "replace"))
+    return status
+
+
+def require_device_tensor(t, name="tensor"):
+    import torch
+
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name} is on {t.device}: the amphion_amd kernels run on a ROCm (MI355X) device only; "
+            "there is no CPU fallback (move the model and its input to 'cuda')"
+        )
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def current_stream_ptr(device):
+    import torch
+
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,73 @@
+"""Builds libamphion_hip.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+    python -m amphion_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  Objects go to amphion_amd/csrc/_build/, the library to
+amphion_amd/lib/libamphion_hip.so (git-ignored, shipped to the GPU box with the snapshot).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_build")
+LIB = os.path.join(HERE, "lib", "libamphion_hip.so")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+CONV_TAPS = (1, 2, 3, 5, 7, 11)
+
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC, "-Wall",
+         "-Wno-unused-function"]
+
+
+def _units():
+    units = [("generator.hip", "generator.o", []), ("small_kernels.hip", "small_kernels.o", []),
+             ("mel.hip", "mel.o", [])]
+    for kt in CONV_TAPS:
+        units.append(("conv_mfma.hip", f"conv_mfma_kt{kt}.o", [f"-DAMP_KT={kt}"]))
+    return units
+
+
+def _deps_mtime():
+    m = 0.0
+    for root in (CSRC, INCLUDE):
+        for fn in os.listdir(root):
+            if fn.endswith((".h", ".hip", ".cpp")):
+                m = max(m, os.path.getmtime(os.path.join(root, fn)))
+    return max(m, os.path.getmtime(__file__))
+
+
+def _compile(unit):
+    src, obj, extra = unit
+    cmd = [HIPCC] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", os.path.join(OBJ, obj)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+    return obj
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    newest = _deps_mtime()
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= newest:
+        return LIB
+    units = _units()
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(_compile, units))
+    cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + [os.path.join(OBJ, o) for o in objs]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+    if verbose:
+        print("built", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

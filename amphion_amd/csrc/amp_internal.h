@@ -1,0 +1,73 @@
+// Internal declarations shared by the translation units of libamphion_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "amphion_hip.h"
+
+namespace amp {
+
+constexpr int KC = 8;  // input channels staged per K-chunk (2 per MFMA k-step, 4 k-steps per tap)
+
+// Arguments of the implicit-GEMM conv kernel (conv_mfma.hip).
+//   Y'[m, q] = sum_i sum_j  W'[m, i, j] * act_in(X[i, q + off0 + j*dstep])          (zero outside [0, Tin))
+// For a Conv1d:          m = output channel, off_j = (j - (k-1)/2) * dilation, up = 1.
+// For a ConvTranspose1d: m = o*up + r  (polyphase row), taps s: X[i, q - s], W' = W[i, o, r + s*up];
+//                        the result is scattered to n = q*up + r - up_pad.
+struct ConvArgs {
+    const float* x;      // [B, Cin, Tin]
+    const float* wp;     // packed A fragments, see pack_weights()
+    const float* bias;   // [Cout] or nullptr
+    const float* res;    // [B, Cout, Tout] or nullptr (may alias y)
+    float* y;            // [B, Cout, Tout]
+    int B, Cin, Tin;
+    int nchunks;         // ceil(Cin / KC)
+    int M;               // GEMM rows = Cout * up
+    int Tq;              // GEMM columns per batch item
+    int tiles_per_item;  // ceil(Tq / NT)
+    int off0, dstep;     // tap offsets
+    int halo_left;       // max(0, -min_j off_j)
+    int wd;              // staged columns actually needed: NT + halo_left + halo_right
+    int Cout, Tout;
+    int up, up_pad;
+    float slope_in, slope_out;  // 1.0f = identity
+    int mode;                   // 0: y = v   1: y = y + v   2: y = (y + v) / div
+    float div;
+};
+
+struct ConvPlan {
+    int KT;      // taps compiled into the kernel (1,2,3,5,7,11)
+    int WM, WN;  // waves along M / N (WM*WN == 4)
+    int NI;      // 32-column MFMA tiles per wave
+    int HALO;    // staged halo capacity (64 or 128)
+    int NT() const { return 32 * NI * WN; }
+    int Mgroup() const { return 32 * WM; }
+};
+
+// Chooses the kernel variant for a conv with `ntaps` taps, GEMM rows M, halo_total columns and Tq
+// columns per item.  Returns false if unsupported.
+bool choose_plan(int ntaps, int M, int halo_total, int Tq, ConvPlan* plan);
+hipError_t launch_conv(const ConvPlan& plan, const ConvArgs& a, hipStream_t stream);
+
+// conv_post: y[b,0,t] = tanh( bias + sum_i sum_j w[i][j] * act_in(x[b,i,t+j-pad]) )   (Cout == 1)
+hipError_t launch_conv_post(const float* x, const float* w_dev /*[Cin*K]*/, const float* bias_dev /*[1] or null*/,
+                            float* y, int B, int Cin, int T, int K, float slope_in, int apply_tanh,
+                            hipStream_t stream);
+
+// Activation1d (anti-aliased Snake); a_dev = alpha (already exp'ed if logscale), invb_dev = 1/(beta+1e-9)
+hipError_t launch_act1d(const float* x, float* y, int B, int C, int T, const float* a_dev, const float* invb_dev,
+                        const float* filt_up12, const float* filt_dn12, hipStream_t stream);
+
+// y[b,c,t] += cond[b,c]   (HiFiGAN_vits `x + self.cond(g)` with g of length 1)
+hipError_t launch_add_channel_bias(float* y, const float* cb, int B, int C, int T, hipStream_t stream);
+
+// mel front end (mel.hip)
+hipError_t launch_mel(const amp_mel_desc& d, const float* wav, int B, int L, int F, const float* window,
+                      const float* melbasis, float* mel, float* mag, float* re, float* im, hipStream_t stream);
+
+void set_error(const char* fmt, ...);
+
+}  // namespace amp

@@ -1,0 +1,172 @@
+// Implicit-GEMM 1-D convolution on the gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Replaces, for the whole generator, the reference's F.conv1d / nn.ConvTranspose1d calls
+// (hifigan.py:93-100,204,207,216; bigvgan.py:137-146,314-329) together with the element-wise ops
+// around them (leaky_relu before/after, bias, residual add, MRF accumulate and 1/num_kernels).
+//
+//   GEMM view (per batch item):  Y'[M, Tq] = W'[M, K] * Xcol[K, Tq],   K = Cin * taps
+//   - A operand (weights) is pre-packed on the host in MFMA fragment order and streamed from L2
+//     straight into VGPRs (one float4 = the four k-steps of one tap of one 8-channel chunk).
+//   - B operand (activations) is staged once per 8-channel chunk into LDS as [8][NT + HALO] rows
+//     (time fastest, coalesced global reads, activation + zero padding applied while staging); every
+//     tap is the same rows read at a shifted column, 32 consecutive lanes -> 32 consecutive banks.
+//   - fp32 MFMA is bit-for-bit an fmaf chain, so parity with the fp32 reference is at rounding level.
+//
+// This file is compiled once per tap count:  -DAMP_KT=<1|2|3|5|7|11>.
+#include "amp_internal.h"
+
+#ifndef AMP_KT
+#error "compile with -DAMP_KT=<taps>"
+#endif
+
+namespace amp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int KT, int WM, int WN, int NI, int HALO>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
+    constexpr int NT = 32 * NI * WN;            // output columns per workgroup
+    constexpr int S = NT + HALO;                // LDS row stride (floats)
+    constexpr int NST = (KC * S + 255) / 256;   // staging elements per thread per chunk
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][KC][S]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int item = blockIdx.x / a.tiles_per_item;
+    const int tile = blockIdx.x - item * a.tiles_per_item;
+    const int q0 = tile * NT;
+    const int mb = blockIdx.y * WM + wm;        // 32-row block of W'
+
+    f32x16 acc[NI];
+#pragma unroll
+    for (int t = 0; t < NI; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const float* xb = a.x + (size_t)item * a.Cin * a.Tin;
+    const int tbase = q0 - a.halo_left;
+    const float slope_in = a.slope_in;
+
+    float xs[NST];
+    auto stage_load = [&](int chunk) {
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int idx = tid + 256 * it;
+            const int row = idx / S;
+            const int col = idx - row * S;
+            const int ch = chunk * KC + row;
+            const int t = tbase + col;
+            const bool ok = (idx < KC * S) && (col < a.wd) && (ch < a.Cin) && (t >= 0) && (t < a.Tin);
+            float v = 0.f;
+            if (ok) v = xb[(size_t)ch * a.Tin + t];
+            xs[it] = v;
+        }
+    };
+    auto stage_store = [&](int buf) {
+        float* dst = smem + buf * (KC * S);
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int idx = tid + 256 * it;
+            float v = xs[it];
+            v = v > 0.f ? v : v * slope_in;
+            if (idx < KC * S) dst[idx] = v;
+        }
+    };
+
+    const float4* wa = reinterpret_cast<const float4*>(a.wp) + (size_t)mb * a.nchunks * (KT * 64) + lane;
+    // One register set for the A fragments: a tap's float4 is re-loaded for the NEXT chunk right
+    // after its last use, so the L2 latency hides under the remaining KT-1 taps of MFMAs.
+    float4 a_cur[KT];
+
+    const int rd0 = hi * S + wn * (32 * NI) + l31 + a.halo_left + a.off0;
+    const int dstep = a.dstep;
+
+    stage_load(0);
+#pragma unroll
+    for (int g = 0; g < KT; ++g) a_cur[g] = wa[(size_t)g * 64];
+    stage_store(0);
+    __syncthreads();
+
+    const int nchunks = a.nchunks;
+    for (int c = 0; c < nchunks; ++c) {
+        const bool more = (c + 1) < nchunks;
+        if (more) stage_load(c + 1);
+        const float4* wan = wa + (size_t)(c + 1) * (KT * 64);
+        const float* base = smem + (c & 1) * (KC * S) + rd0;
+#pragma unroll
+        for (int g = 0; g < KT; ++g) {
+            const float* bg = base + g * dstep;
+            const float av[4] = {a_cur[g].x, a_cur[g].y, a_cur[g].z, a_cur[g].w};
+            if (more) a_cur[g] = wan[(size_t)g * 64];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+#pragma unroll
+                for (int t = 0; t < NI; ++t) {
+                    const float bv = bg[p * 2 * S + 32 * t];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], bv, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        if (more) stage_store((c + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, residual, MRF accumulate, activation-on-store, (polyphase) scatter ----
+    const int up = a.up;
+    const int qw = q0 + wn * (32 * NI) + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const int m = mb * 32 + row;
+        if (m < a.M) {
+            const int o = (up == 1) ? m : m / up;
+            const int rr = m - o * up;
+            const float bv = a.bias ? a.bias[o] : 0.f;
+            const size_t rowoff = ((size_t)item * a.Cout + o) * a.Tout;
+#pragma unroll
+            for (int t = 0; t < NI; ++t) {
+                const int q = qw + 32 * t;
+                const int n = q * up + rr - a.up_pad;
+                if (q < a.Tq && n >= 0 && n < a.Tout) {
+                    float v = acc[t][r] + bv;
+                    if (a.res) v += a.res[rowoff + n];
+                    if (a.mode == 1) v = a.y[rowoff + n] + v;
+                    else if (a.mode == 2) v = (a.y[rowoff + n] + v) / a.div;
+                    v = v > 0.f ? v : v * a.slope_out;
+                    a.y[rowoff + n] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int KT, int WM, int WN, int NI, int HALO>
+static hipError_t launch_one(const ConvArgs& a, hipStream_t stream) {
+    constexpr int NT = 32 * NI * WN;
+    constexpr int S = NT + HALO;
+    const size_t lds = (size_t)2 * KC * S * sizeof(float);
+    dim3 grid((unsigned)(a.B * a.tiles_per_item), (unsigned)((a.M + 32 * WM - 1) / (32 * WM)));
+    hipLaunchKernelGGL((conv_mfma_kernel<KT, WM, WN, NI, HALO>), grid, dim3(256), lds, stream, a);
+    return hipGetLastError();
+}
+
+#define AMP_CAT2(a, b) a##b
+#define AMP_CAT(a, b) AMP_CAT2(a, b)
+
+hipError_t AMP_CAT(launch_conv_kt, AMP_KT)(const ConvPlan& p, const ConvArgs& a, hipStream_t stream) {
+    constexpr int KT = AMP_KT;
+    if (p.HALO == 64) {
+        if (p.WM == 4) return launch_one<KT, 4, 1, 8, 64>(a, stream);
+        if (p.WM == 2) return launch_one<KT, 2, 2, 8, 64>(a, stream);
+        return launch_one<KT, 1, 4, 4, 64>(a, stream);
+    } else {
+        if (p.WM == 4) return launch_one<KT, 4, 1, 8, 128>(a, stream);
+        if (p.WM == 2) return launch_one<KT, 2, 2, 8, 128>(a, stream);
+        return launch_one<KT, 1, 4, 4, 128>(a, stream);
+    }
+}
+
+}  // namespace amp

@@ -1,0 +1,135 @@
+// Mel / STFT front end on gfx950: framing (reflect padding) * window -> radix-2 Stockham FFT in LDS ->
+// |X| -> mel filterbank -> log, one workgroup per frame, nothing but the final features leaves the CU.
+//
+// Replaces utils/mel.py:20-170 (torch.stft + sqrt + matmul + log as 5 separate tensor ops) and the
+// conv1d-with-Fourier-basis STFT of utils/stft.py:152-181,259-278 (TacotronSTFT).
+#include "amp_internal.h"
+
+namespace amp {
+
+__device__ __forceinline__ int reflect_index(int s, int L) {
+    // torch reflect padding (no edge repeat); pad < L is checked on the host
+    if (s < 0) s = -s;
+    if (s >= L) s = 2 * (L - 1) - s;
+    return s;
+}
+
+__global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ wav, int L, int F, int n_fft, int log2n,
+                                                  int hop, int pad, int n_mel, float mag_eps, float log_clip,
+                                                  const float* __restrict__ window, const float* __restrict__ melbasis,
+                                                  float* __restrict__ mel, float* __restrict__ mag,
+                                                  float* __restrict__ re_out, float* __restrict__ im_out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float2* buf0 = reinterpret_cast<float2*>(smem);   // [n_fft]
+    float2* buf1 = buf0 + n_fft;                      // [n_fft]
+    float2* tw = buf1 + n_fft;                        // [n_fft/2]  exp(-2*pi*i*m/n_fft)
+    float* magl = reinterpret_cast<float*>(tw + n_fft / 2);  // [n_fft/2+1]
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / F;
+    const int f = blockIdx.x - b * F;
+    const int half = n_fft >> 1;
+    const int bins = half + 1;
+    const float* wb = wav + (size_t)b * L;
+
+    for (int n = tid; n < n_fft; n += 256) {
+        const int s = reflect_index(f * hop + n - pad, L);
+        buf0[n] = make_float2(wb[s] * window[n], 0.f);
+    }
+    for (int m = tid; m < half; m += 256) {
+        float sn, cs;
+        sincospif(-2.0f * (float)m / (float)n_fft, &sn, &cs);
+        tw[m] = make_float2(cs, sn);
+    }
+    __syncthreads();
+
+    float2* in = buf0;
+    float2* out = buf1;
+    for (int s = 0; s < log2n; ++s) {
+        const int Ns = 1 << s;
+        const int tstride = half >> s;  // twiddle index step: (n_fft/2) / Ns
+        for (int j = tid; j < half; j += 256) {
+            const int k = j & (Ns - 1);
+            const float2 w = tw[k * tstride];
+            const float2 v0 = in[j];
+            const float2 x1 = in[j + half];
+            const float2 v1 = make_float2(x1.x * w.x - x1.y * w.y, x1.x * w.y + x1.y * w.x);
+            const int j0 = ((j - k) << 1) + k;
+            out[j0] = make_float2(v0.x + v1.x, v0.y + v1.y);
+            out[j0 + Ns] = make_float2(v0.x - v1.x, v0.y - v1.y);
+        }
+        __syncthreads();
+        float2* t = in; in = out; out = t;
+    }
+    // `in` now holds the spectrum in natural order
+    for (int k = tid; k < bins; k += 256) {
+        const float2 v = in[k];
+        const float m = sqrtf(v.x * v.x + v.y * v.y + mag_eps);
+        magl[k] = m;
+        const size_t o = ((size_t)b * bins + k) * F + f;
+        if (mag) mag[o] = m;
+        if (re_out) re_out[o] = v.x;
+        if (im_out) im_out[o] = v.y;
+    }
+    if (!mel) return;
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int m = wave; m < n_mel; m += 4) {
+        const float* row = melbasis + (size_t)m * bins;
+        float acc = 0.f;
+        for (int k = lane; k < bins; k += 64) acc = fmaf(row[k], magl[k], acc);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if (lane == 0) {
+            float v = acc;
+            if (log_clip > 0.f) v = logf(fmaxf(v, log_clip));
+            mel[((size_t)b * n_mel + m) * F + f] = v;
+        }
+    }
+}
+
+hipError_t launch_mel(const amp_mel_desc& d, const float* wav, int B, int L, int F, const float* window,
+                      const float* melbasis, float* mel, float* mag, float* re, float* im, hipStream_t stream) {
+    int log2n = 0;
+    while ((1 << log2n) < d.n_fft) ++log2n;
+    const int pad = d.pad_mode == 0 ? (d.n_fft - d.hop_size) / 2 : d.n_fft / 2;
+    const size_t lds = (size_t)(2 * d.n_fft + d.n_fft / 2) * sizeof(float2) + (size_t)(d.n_fft / 2 + 1) * sizeof(float);
+    dim3 grid((unsigned)((size_t)B * F));
+    hipLaunchKernelGGL(mel_kernel, grid, dim3(256), lds, stream, wav, L, F, d.n_fft, log2n, d.hop_size, pad,
+                       mel ? d.n_mel : 0, d.mag_eps, d.log_clip, window, melbasis, mel, mag, re, im);
+    return hipGetLastError();
+}
+
+}  // namespace amp
+
+using namespace amp;
+
+extern "C" {
+
+int amp_mel_num_frames(const amp_mel_desc* d, int L) {
+    if (!d || d->hop_size <= 0 || d->n_fft <= 0) return 0;
+    const int pad = d->pad_mode == 0 ? (d->n_fft - d->hop_size) / 2 : d->n_fft / 2;
+    const int Lp = L + 2 * pad;
+    if (Lp < d->n_fft) return 0;
+    return (Lp - d->n_fft) / d->hop_size + 1;
+}
+
+int amp_mel_forward(const amp_mel_desc* d, const float* wav_dev, int B, int L, const float* window_dev,
+                    const float* melbasis_dev, float* mel_dev, float* mag_dev, float* re_dev, float* im_dev,
+                    void* stream) {
+    if (!d || !wav_dev || !window_dev) { set_error("amp_mel_forward: null argument"); return AMP_ERR_INVALID; }
+    if (d->n_fft < 64 || d->n_fft > 4096 || (d->n_fft & (d->n_fft - 1)) != 0) {
+        set_error("amp_mel_forward: n_fft=%d must be a power of two in [64, 4096]", d->n_fft);
+        return AMP_ERR_UNSUPPORTED;
+    }
+    if (d->hop_size <= 0 || B <= 0 || L <= 0) { set_error("amp_mel_forward: hop=%d B=%d L=%d", d->hop_size, B, L); return AMP_ERR_INVALID; }
+    const int pad = d->pad_mode == 0 ? (d->n_fft - d->hop_size) / 2 : d->n_fft / 2;
+    if (pad >= L) { set_error("amp_mel_forward: reflect padding %d needs more than %d samples", pad, L); return AMP_ERR_INVALID; }
+    if (mel_dev && (d->n_mel <= 0 || !melbasis_dev)) { set_error("amp_mel_forward: mel output needs n_mel > 0 and a mel basis"); return AMP_ERR_INVALID; }
+    const int F = amp_mel_num_frames(d, L);
+    if (F <= 0) { set_error("amp_mel_forward: no frames for L=%d", L); return AMP_ERR_INVALID; }
+    hipError_t e = launch_mel(*d, wav_dev, B, L, F, window_dev, melbasis_dev, mel_dev, mag_dev, re_dev, im_dev, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("amp_mel_forward: %s", hipGetErrorString(e)); return AMP_ERR_HIP; }
+    return AMP_OK;
+}
+
+}  // extern "C"

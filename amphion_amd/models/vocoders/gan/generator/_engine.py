@@ -1,0 +1,220 @@
+"""Shared host logic of the MI355X generators: parameter holders that keep the reference's
+state_dict key names/shapes, and the bridge from an nn.Module to an ``amp_gen`` handle.
+
+The nn.Parameters stay the source of truth (``load_state_dict``, ``.to()``, ``.cuda()``,
+``remove_weight_norm()`` all work as in the reference); the folded + MFMA-packed device copy
+inside the handle is rebuilt lazily whenever a parameter changes.
+"""
+from __future__ import annotations
+
+import ctypes
+import weakref
+
+import torch
+import torch.nn as nn
+
+from amphion_amd import _lib
+
+
+def _norm_except_dim0(v: torch.Tensor) -> torch.Tensor:
+    return v.reshape(v.shape[0], -1).norm(dim=1).reshape(-1, *([1] * (v.dim() - 1)))
+
+
+class ConvParams(nn.Module):
+    """Parameters of ``weight_norm(Conv1d(...))`` / ``weight_norm(ConvTranspose1d(...))`` or of a
+    plain conv, under the reference's key names: ``bias``, ``weight_g``, ``weight_v`` (or
+    ``weight`` once weight-norm is removed / never applied).
+
+    Initialisation reproduces the reference's RNG consumption: torch's default Conv init, then
+    (``init_normal=True``) the ``init_weights`` draw of gan_utils.py:25-28 -- which, applied after
+    ``weight_norm``, only touches the derived ``weight`` attribute and leaves g/v unchanged
+    (hifigan.py:55,90,200-201).
+    """
+
+    def __init__(self, cin, cout, k, *, transposed=False, stride=1, dilation=1, padding=0, weight_norm=True,
+                 bias=True, init_normal=False):
+        super().__init__()
+        self.cin, self.cout, self.k = cin, cout, k
+        self.transposed, self.stride, self.dilation, self.padding = transposed, stride, dilation, padding
+        if transposed:
+            ref = nn.ConvTranspose1d(cin, cout, k, stride, padding=padding, bias=bias)
+        else:
+            ref = nn.Conv1d(cin, cout, k, 1, dilation=dilation, padding=padding, bias=bias)
+        w = ref.weight.data
+        b = ref.bias.data.clone() if bias else None
+        if weight_norm:
+            # weight_norm() deletes `weight` and registers g, v AFTER the existing bias
+            if bias:
+                self.bias = nn.Parameter(b)
+            else:
+                self.register_parameter("bias", None)
+            self.weight_g = nn.Parameter(_norm_except_dim0(w).clone())
+            self.weight_v = nn.Parameter(w.clone())
+            if init_normal:
+                torch.empty_like(w).normal_(0.0, 0.01)  # consumed, no effect on g/v (see docstring)
+        else:
+            if init_normal:
+                w = w.normal_(0.0, 0.01)
+            self.weight = nn.Parameter(w.clone())
+            if bias:
+                self.bias = nn.Parameter(b)
+            else:
+                self.register_parameter("bias", None)
+
+    @property
+    def has_weight_norm(self):
+        return "weight_g" in self._parameters
+
+    def folded_weight(self) -> torch.Tensor:
+        """w = g * v / ||v|| (torch.nn.utils.weight_norm, dim=0)."""
+        if not self.has_weight_norm:
+            return self.weight
+        return self.weight_g * (self.weight_v / _norm_except_dim0(self.weight_v))
+
+    def remove_weight_norm(self):
+        if not self.has_weight_norm:
+            raise ValueError("weight_norm of 'weight' not found")  # as torch.nn.utils.remove_weight_norm
+        w = self.folded_weight().detach()
+        del self._parameters["weight_g"]
+        del self._parameters["weight_v"]
+        self.weight = nn.Parameter(w)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        # accept the other form (folded <-> weight-normed) by converting this holder first
+        has_w = prefix + "weight" in state_dict
+        has_gv = prefix + "weight_g" in state_dict and prefix + "weight_v" in state_dict
+        if self.has_weight_norm and has_w and not has_gv:
+            self.remove_weight_norm()
+        elif not self.has_weight_norm and has_gv and not has_w:
+            w = self._parameters.pop("weight")
+            self.weight_g = nn.Parameter(_norm_except_dim0(w.data).clone())
+            self.weight_v = nn.Parameter(w.data.clone())
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                      error_msgs)
+
+    def extra_repr(self):
+        kind = "ConvTranspose1d" if self.transposed else "Conv1d"
+        return f"{kind}({self.cin}, {self.cout}, k={self.k}, stride={self.stride}, dilation={self.dilation}, " \
+               f"padding={self.padding}, weight_norm={self.has_weight_norm})"
+
+
+def _destroy_handle(ptr):
+    try:
+        _lib.lib().amp_gen_destroy(ctypes.c_void_p(ptr))
+    except Exception:  # interpreter shutdown
+        pass
+
+
+class HipGenerator(nn.Module):
+    """Base of HiFiGAN / HiFiGAN_vits / BigVGAN: owns the ``amp_gen`` handle and the workspace."""
+
+    def __init__(self):
+        super().__init__()
+        self._amp_handle = None
+        self._amp_finalizer = None
+        self._amp_sig = None
+        self._amp_device = None
+        self._amp_ws = None
+        self._amp_profiling = False
+
+    # subclasses provide the architecture descriptor
+    def _amp_desc(self) -> _lib.amp_gen_desc:  # pragma: no cover - abstract
+        raise NotImplementedError
+
+    @staticmethod
+    def _fill_desc(arch, n_in, c0, rates, ksizes, rb_kernels, rb_dils, resblock, activation=_lib.AMP_ACT_LRELU,
+                   logscale=False, gin=0):
+        d = _lib.amp_gen_desc()
+        if len(rates) > _lib.AMP_MAX_STAGES or len(rb_kernels) > _lib.AMP_MAX_KERNELS:
+            raise ValueError("too many upsample stages / resblock kernels")
+        d.arch, d.n_in, d.upsample_initial_channel, d.n_stages = arch, int(n_in), int(c0), len(rates)
+        for i, (u, k) in enumerate(zip(rates, ksizes)):
+            d.upsample_rates[i], d.upsample_kernel_sizes[i] = int(u), int(k)
+        d.n_kernels = len(rb_kernels)
+        for j, (k, dl) in enumerate(zip(rb_kernels, rb_dils)):
+            if len(dl) > _lib.AMP_MAX_DILATIONS:
+                raise ValueError("too many dilations")
+            d.resblock_kernel_sizes[j] = int(k)
+            d.n_dilations[j] = len(dl)
+            for p, v in enumerate(dl):
+                d.resblock_dilation_sizes[j][p] = int(v)
+        d.resblock_type = 1 if str(resblock) == "1" else 2
+        d.activation, d.snake_logscale, d.gin_channels = int(activation), int(bool(logscale)), int(gin)
+        return d
+
+    def _amp_signature(self):
+        return tuple((k, v.data_ptr(), v._version, tuple(v.shape)) for k, v in self.state_dict(keep_vars=True).items())
+
+    def _amp_release(self):
+        if self._amp_finalizer is not None:
+            self._amp_finalizer()  # destroys the handle once
+        self._amp_handle = self._amp_finalizer = self._amp_sig = self._amp_device = None
+
+    def _amp_ensure(self, device):
+        sig = self._amp_signature()
+        if self._amp_handle is not None and sig == self._amp_sig and device == self._amp_device:
+            return self._amp_handle
+        self._amp_release()
+        L = _lib.lib()
+        desc = self._amp_desc()
+        h = ctypes.c_void_p()
+        _lib.check(L.amp_gen_create(ctypes.byref(desc), ctypes.byref(h)))
+        fin = weakref.finalize(self, _destroy_handle, h.value)
+        try:
+            for key, t in self.state_dict().items():
+                c = t.detach().to("cpu", torch.float32).contiguous()
+                shape = (ctypes.c_int64 * c.dim())(*c.shape)
+                _lib.check(L.amp_gen_set_weight(h, key.encode(), ctypes.c_void_p(c.data_ptr()), shape, c.dim()))
+            with torch.cuda.device(device):
+                _lib.check(L.amp_gen_finalize(h))
+                if self._amp_profiling:
+                    _lib.check(L.amp_gen_set_profiling(h, 1))
+        except Exception:
+            fin()
+            raise
+        self._amp_handle, self._amp_finalizer, self._amp_sig, self._amp_device = h, fin, sig, device
+        return h
+
+    def _amp_forward(self, x, g=None):
+        x = _lib.require_device_tensor(x, "generator input")
+        if x.dim() != 3:
+            raise ValueError(f"expected [B, C, T] input, got {tuple(x.shape)}")
+        dev = x.device
+        p0 = next(self.parameters())
+        if p0.device != dev:
+            raise RuntimeError(f"generator parameters are on {p0.device} but the input is on {dev}")
+        L = _lib.lib()
+        h = self._amp_ensure(dev)
+        B, C, T = x.shape
+        if C != self._amp_n_in:
+            raise ValueError(f"expected {self._amp_n_in} input channels, got {C}")
+        cond_ptr = None
+        if g is not None:
+            g = _lib.require_device_tensor(g, "g")
+            if g.dim() != 3 or g.shape[0] != B or g.shape[2] != 1:
+                raise ValueError(f"g must be [B, gin_channels, 1], got {tuple(g.shape)}")
+            cond_ptr = ctypes.c_void_p(g.data_ptr())
+        hop = L.amp_gen_hop(h)
+        need = L.amp_gen_workspace_bytes(h, B, T)
+        if self._amp_ws is None or self._amp_ws.numel() < need or self._amp_ws.device != dev:
+            self._amp_ws = None
+            self._amp_ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        out = torch.empty((B, 1, T * hop), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.amp_gen_forward(h, ctypes.c_void_p(x.data_ptr()), cond_ptr, B, T,
+                                         ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(self._amp_ws.data_ptr()),
+                                         self._amp_ws.numel(), _lib.current_stream_ptr(dev)))
+        return out
+
+    # ---- profiling hooks used by bench.py ----
+    def set_profiling(self, enabled=True):
+        self._amp_profiling = bool(enabled)
+        if self._amp_handle is not None:
+            _lib.check(_lib.lib().amp_gen_set_profiling(self._amp_handle, int(enabled)))
+
+    def last_timing_ms(self, which=0):
+        """HIP-event time of the last forward on its launch stream. which: 0 whole forward, 1 MRF conv stack."""
+        ms = ctypes.c_float()
+        _lib.check(_lib.lib().amp_gen_last_timing_ms(self._amp_handle, which, ctypes.byref(ms)))
+        return ms.value

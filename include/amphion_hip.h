@@ -1,0 +1,166 @@
+/*
+ * amphion_hip.h -- C ABI of libamphion_hip.so: the MI355X (gfx950) vocoder-inference hot path.
+ *
+ * The reference (open-mmlab/Amphion) has NO native code on this path: its "kernels" are
+ * torch.nn.functional calls.  The entry points below are what a ctypes binding of the reference's
+ * generator / front-end would call instead of those torch ops; each one cites the reference
+ * interface it replaces (paths relative to the reference tree).  INTEGRATION.md shows the
+ * reference-side binding.
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; no torch types.
+ *   - every function returns amp_status (0 = OK, <0 = error); amp_last_error() gives the text
+ *     (thread-local).  Nothing calls abort().
+ *   - `*_dev` pointers are device (HBM) pointers on the current HIP device; `*_host` are host
+ *     pointers.  The caller owns inputs, outputs and the workspace; a handle owns only its packed
+ *     weights.  No allocation and no host synchronisation inside *_forward: all work is enqueued on
+ *     `stream` (a hipStream_t passed as void*; NULL = the default stream).
+ *   - all tensors are fp32, contiguous, layout [B, C, T] (time fastest), as in the reference.
+ */
+#ifndef AMPHION_HIP_H
+#define AMPHION_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum amp_status {
+    AMP_OK = 0,
+    AMP_ERR_INVALID = -1,        /* bad argument / shape */
+    AMP_ERR_MISSING_WEIGHT = -2, /* finalize(): a tensor the architecture needs was never set */
+    AMP_ERR_HIP = -3,            /* a HIP runtime call failed */
+    AMP_ERR_UNSUPPORTED = -4,    /* configuration outside what the kernels cover */
+    AMP_ERR_STATE = -5           /* call order violated (e.g. forward before finalize) */
+} amp_status;
+
+typedef enum amp_arch {
+    AMP_ARCH_HIFIGAN = 0,      /* models/vocoders/gan/generator/hifigan.py:151-219  HiFiGAN       */
+    AMP_ARCH_BIGVGAN = 1,      /* models/vocoders/gan/generator/bigvgan.py:232-331  BigVGAN       */
+    AMP_ARCH_HIFIGAN_VITS = 2  /* models/vocoders/gan/generator/hifigan.py:376-449  HiFiGAN_vits  */
+} amp_arch;
+
+typedef enum amp_activation {
+    AMP_ACT_LRELU = 0,     /* F.leaky_relu(x, 0.1)            hifigan.py:14,95-97          */
+    AMP_ACT_SNAKE = 1,     /* Activation1d(Snake)             bigvgan.py:85-102, snake.py:51-61   */
+    AMP_ACT_SNAKEBETA = 2  /* Activation1d(SnakeBeta)         bigvgan.py:104-124, snake.py:110-122 */
+} amp_activation;
+
+#define AMP_MAX_STAGES 8
+#define AMP_MAX_KERNELS 8
+#define AMP_MAX_DILATIONS 8
+
+/* Mirrors cfg.model.hifigan.* / cfg.model.bigvgan.* (hifigan.py:155-199, bigvgan.py:237-306) and the
+ * explicit HiFiGAN_vits constructor arguments (hifigan.py:377-387). */
+typedef struct amp_gen_desc {
+    int32_t arch;                     /* amp_arch */
+    int32_t n_in;                     /* cfg.preprocess.n_mel, or initial_channel for HiFiGAN_vits */
+    int32_t upsample_initial_channel;
+    int32_t n_stages;                 /* len(upsample_rates) */
+    int32_t upsample_rates[AMP_MAX_STAGES];
+    int32_t upsample_kernel_sizes[AMP_MAX_STAGES];
+    int32_t n_kernels;                /* len(resblock_kernel_sizes) */
+    int32_t resblock_kernel_sizes[AMP_MAX_KERNELS];
+    int32_t n_dilations[AMP_MAX_KERNELS];
+    int32_t resblock_dilation_sizes[AMP_MAX_KERNELS][AMP_MAX_DILATIONS];
+    int32_t resblock_type;            /* 1 = ResBlock1/AMPBlock1, 2 = ResBlock2/AMPBlock2 */
+    int32_t activation;               /* amp_activation (BigVGAN: cfg.model.bigvgan.activation) */
+    int32_t snake_logscale;           /* cfg.model.bigvgan.snake_logscale */
+    int32_t gin_channels;             /* HiFiGAN_vits only; 0 = no `cond` conv */
+} amp_gen_desc;
+
+typedef struct amp_gen amp_gen;
+
+/* Library / device probes. */
+int amp_version(void);
+const char* amp_last_error(void);
+/* Number of HIP devices visible (0 when there is no GPU); never fails. */
+int amp_device_count(void);
+
+/* ---- Generator handle: replaces nn.Module construction + forward of HiFiGAN / BigVGAN / HiFiGAN_vits ---- */
+
+/* Replaces HiFiGAN.__init__ (hifigan.py:151-201) / BigVGAN.__init__ (bigvgan.py:232-311) /
+ * HiFiGAN_vits.__init__ (hifigan.py:376-422): validates the architecture, allocates nothing on the device. */
+int amp_gen_create(const amp_gen_desc* desc, amp_gen** out);
+
+/* Replaces load_state_dict for one tensor (vocoder_inference.py:270-332).  `ref_key` is the
+ * reference state_dict key: "...weight_g"/"...weight_v" pairs or folded
+ * "...weight", "...bias", Snake "...act.alpha"/"...act.beta", "...filter" buffers.  The data is
+ * copied from host memory.  Unknown keys are rejected (AMP_ERR_INVALID). */
+int amp_gen_set_weight(amp_gen* g, const char* ref_key, const float* data_host, const int64_t* shape, int ndim);
+
+/* Folds weight-norm (w = g*v/||v||, torch.nn.utils.weight_norm; hifigan.py:23,157,176,199),
+ * packs the weights into MFMA fragment order and uploads them to the current device. */
+int amp_gen_finalize(amp_gen* g);
+
+/* Output samples per input frame (prod(upsample_rates)) and scratch size for a (B, T) forward. */
+int amp_gen_hop(const amp_gen* g);
+size_t amp_gen_workspace_bytes(const amp_gen* g, int B, int T);
+
+/* Replaces HiFiGAN.forward (hifigan.py:203-219), BigVGAN.forward (bigvgan.py:313-331) and
+ * HiFiGAN_vits.forward (hifigan.py:424-443):  mel_dev [B, n_in, T]  ->  wav_dev [B, 1, T*hop].
+ * cond_dev: optional speaker embedding g [B, gin_channels, 1] (HiFiGAN_vits), else NULL. */
+int amp_gen_forward(amp_gen* g, const float* mel_dev, const float* cond_dev, int B, int T, float* wav_dev,
+                    void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* Duration [ms] of the kernels of the LAST amp_gen_forward on this handle, measured with HIP events
+ * recorded on the launch stream when profiling is on.  which: 0 = whole forward, 1 = MRF conv stack
+ * (all ResBlock/AMPBlock convs).  Synchronises on the events.  Returns <0 on error. */
+int amp_gen_set_profiling(amp_gen* g, int enabled);
+int amp_gen_last_timing_ms(amp_gen* g, int which, float* ms_out);
+
+void amp_gen_destroy(amp_gen* g);
+
+/* ---- Op level (used by tests and by callers that want one fused op) ---- */
+
+typedef struct amp_conv amp_conv;
+
+/* One Conv1d (nn.Conv1d(cin, cout, k, 1, dilation=d, padding=get_padding(k, d)), gan_utils.py:12) or
+ * ConvTranspose1d(cin, cout, k, stride, padding) (hifigan.py:176-186).  weight_host is the FOLDED
+ * weight: [cout, cin, k] for a conv, [cin, cout, k] for a transposed conv.  bias_host may be NULL. */
+int amp_conv_create(int transposed, int cin, int cout, int k, int stride, int dilation, int padding,
+                    const float* weight_host, const float* bias_host, amp_conv** out);
+int amp_conv_out_len(const amp_conv* c, int T);
+/* y = lrelu_out( conv( lrelu_in(x) ) + bias + res ).  slope == 1.0f disables an activation;
+ * res_dev may be NULL or alias y_dev (in-place residual).  x_dev [B, cin, T] -> y_dev [B, cout, T_out]. */
+int amp_conv_forward(const amp_conv* c, const float* x_dev, int B, int T, float slope_in, const float* res_dev,
+                     float slope_out, float* y_dev, void* stream);
+void amp_conv_destroy(amp_conv* c);
+
+/* Activation1d(Snake|SnakeBeta) (modules/anti_aliasing/act.py:31-36; resample.py:36-45,62-65;
+ * filter.py:92-99; snake.py:51-61,110-122), ratio 2, 12-tap filters.  alpha_dev/beta_dev: per-channel
+ * parameters AS STORED (the kernel applies exp() when logscale); beta_dev NULL -> Snake.
+ * filt_up_host/filt_down_host: the 12 filter taps.  x_dev [B, C, T] -> y_dev [B, C, T]. */
+int amp_antialias_snake(const float* x_dev, int B, int C, int T, const float* alpha_dev, const float* beta_dev,
+                        int logscale, const float* filt_up_host, const float* filt_down_host, float* y_dev,
+                        void* stream);
+
+/* Mel / STFT front end descriptor: cfg.preprocess.{sample_rate,n_fft,win_size,hop_size,n_mel,fmin,fmax}. */
+typedef struct amp_mel_desc {
+    int32_t n_fft;
+    int32_t win_size;
+    int32_t hop_size;
+    int32_t n_mel;       /* 0 = linear spectrogram only */
+    int32_t pad_mode;    /* 0: reflect-pad (n_fft-hop)/2, center=False (utils/mel.py:145-164);
+                            1: reflect-pad n_fft/2 (utils/stft.py:152-165, TacotronSTFT) */
+    float mag_eps;       /* added under the sqrt: 1e-9 (mel.py:166), 1e-6 (mel.py:99), 0 (stft.py:177) */
+    float log_clip;      /* clamp before log: 1e-5 (mel.py:10-12); <=0 -> no log (raw mel / magnitude) */
+} amp_mel_desc;
+
+/* Number of frames produced for L samples. */
+int amp_mel_num_frames(const amp_mel_desc* d, int L);
+/* Replaces extract_mel_features / mel_spectrogram_torch / extract_linear_features (utils/mel.py:20-170)
+ * and TacotronSTFT.mel_spectrogram (utils/stft.py:259-278).
+ * wav_dev [B, L]; window_dev [n_fft] (already centre-padded to n_fft); melbasis_dev [n_mel, n_fft/2+1]
+ * (may be NULL when n_mel == 0).  Outputs (any may be NULL): mel_dev [B, n_mel, F] (log-mel),
+ * mag_dev [B, n_fft/2+1, F] (magnitude), re_dev/im_dev [B, n_fft/2+1, F]. */
+int amp_mel_forward(const amp_mel_desc* d, const float* wav_dev, int B, int L, const float* window_dev,
+                    const float* melbasis_dev, float* mel_dev, float* mag_dev, float* re_dev, float* im_dev,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMPHION_HIP_H */

@@ -1,0 +1,49 @@
+"""ctypes-level helpers for the GPU parity tests (call the C ABI with raw device pointers)."""
+import ctypes
+
+import torch
+
+from amphion_amd import _lib
+
+
+def conv_forward(w, b, x, *, transposed=False, stride=1, dilation=1, padding=0, slope_in=1.0, res=None,
+                 slope_out=1.0):
+    """Run amp_conv_* on cuda:0.  w/b are CPU tensors (folded weight), x a CPU tensor [B, Cin, T]."""
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    w = w.contiguous().float()
+    cin = w.shape[0] if transposed else w.shape[1]
+    cout = w.shape[1] if transposed else w.shape[0]
+    bptr = ctypes.c_void_p(b.contiguous().float().data_ptr()) if b is not None else None
+    _lib.check(L.amp_conv_create(int(transposed), cin, cout, w.shape[2], stride, dilation, padding,
+                                 ctypes.c_void_p(w.data_ptr()), bptr, ctypes.byref(h)))
+    try:
+        xd = x.contiguous().float().cuda()
+        B, _, T = xd.shape
+        Tout = L.amp_conv_out_len(h, T)
+        y = torch.full((B, cout, Tout), float("nan"), device="cuda")
+        rd = res.contiguous().float().cuda() if res is not None else None
+        _lib.check(L.amp_conv_forward(h, ctypes.c_void_p(xd.data_ptr()), B, T, slope_in,
+                                      ctypes.c_void_p(rd.data_ptr()) if rd is not None else None, slope_out,
+                                      ctypes.c_void_p(y.data_ptr()), _lib.current_stream_ptr(xd.device)))
+        torch.cuda.synchronize()
+        return y.cpu()
+    finally:
+        L.amp_conv_destroy(h)
+
+
+def act1d_forward(x, alpha, beta, logscale, fu, fd):
+    L = _lib.lib()
+    xd = x.contiguous().float().cuda()
+    B, C, T = xd.shape
+    y = torch.full_like(xd, float("nan"))
+    ad = alpha.contiguous().float().cuda()
+    bd = beta.contiguous().float().cuda() if beta is not None else None
+    fu = fu.contiguous().float()
+    fd = fd.contiguous().float()
+    _lib.check(L.amp_antialias_snake(ctypes.c_void_p(xd.data_ptr()), B, C, T, ctypes.c_void_p(ad.data_ptr()),
+                                     ctypes.c_void_p(bd.data_ptr()) if bd is not None else None, int(logscale),
+                                     ctypes.c_void_p(fu.data_ptr()), ctypes.c_void_p(fd.data_ptr()),
+                                     ctypes.c_void_p(y.data_ptr()), _lib.current_stream_ptr(xd.device)))
+    torch.cuda.synchronize()
+    return y.cpu()

@@ -1,0 +1,93 @@
+"""GPU parity: the fused implicit-GEMM conv kernel vs the CPU oracle ops (F.conv1d / F.conv_transpose1d)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+CONV_CASES = [
+    # cin, cout, k, dilation, B, T
+    (8, 32, 3, 1, 1, 40),
+    (16, 128, 3, 3, 2, 300),     # WM=4
+    (24, 64, 7, 5, 2, 523),      # WM=2, ragged tile
+    (32, 32, 11, 5, 1, 1500),    # WM=1, several tiles
+    (80, 512, 7, 1, 2, 33),      # conv_pre shape
+    (100, 96, 7, 1, 1, 17),      # Cin not a multiple of 8, M not a multiple of 32
+    (32, 32, 5, 6, 2, 77),       # k5 (recipe net)
+    (64, 64, 7, 12, 1, 700),     # dilation 12 -> 128-column halo variant
+    (192, 384, 1, 1, 2, 19),     # 1x1 conv (VITS)
+    (5, 7, 3, 1, 1, 1),          # T = 1
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,d,B,T", CONV_CASES)
+def test_conv1d_matches_oracle(cin, cout, k, d, B, T):
+    from hip_helpers import conv_forward
+
+    w = _rand(cout, cin, k, seed=1, scale=(cin * k) ** -0.5)
+    b = _rand(cout, seed=2, scale=0.1)
+    x = _rand(B, cin, T, seed=3)
+    pad = (k * d - d) // 2
+    ref = F.conv1d(x, w, b, dilation=d, padding=pad)
+    y = conv_forward(w, b, x, dilation=d, padding=pad)
+    assert y.shape == ref.shape
+    assert (y - ref).abs().max().item() <= 2e-5
+
+
+def test_conv1d_fused_prologue_epilogue():
+    from hip_helpers import conv_forward
+
+    cin = cout = 64
+    k, d, B, T = 7, 3, 2, 411
+    w = _rand(cout, cin, k, seed=1, scale=(cin * k) ** -0.5)
+    b = _rand(cout, seed=2, scale=0.1)
+    x = _rand(B, cin, T, seed=3)
+    res = _rand(B, cout, T, seed=4)
+    pad = (k * d - d) // 2
+    ref = F.leaky_relu(F.conv1d(F.leaky_relu(x, 0.1), w, b, dilation=d, padding=pad) + res, 0.2)
+    y = conv_forward(w, b, x, dilation=d, padding=pad, slope_in=0.1, res=res, slope_out=0.2)
+    assert (y - ref).abs().max().item() <= 2e-5
+    # no bias
+    ref = F.conv1d(x, w, None, dilation=d, padding=pad)
+    y = conv_forward(w, None, x, dilation=d, padding=pad)
+    assert (y - ref).abs().max().item() <= 2e-5
+
+
+CONVT_CASES = [
+    # cin, cout, k, stride, B, T
+    (512, 256, 16, 8, 1, 9),
+    (128, 64, 4, 2, 2, 130),
+    (64, 32, 4, 2, 1, 700),
+    (256, 128, 8, 4, 2, 33),
+    (16, 8, 8, 4, 1, 1),
+    (24, 40, 6, 2, 1, 50),      # k = 3*stride -> three polyphase taps
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,u,B,T", CONVT_CASES)
+def test_conv_transpose1d_matches_oracle(cin, cout, k, u, B, T):
+    from hip_helpers import conv_forward
+
+    w = _rand(cin, cout, k, seed=5, scale=(cin * k / u) ** -0.5)
+    b = _rand(cout, seed=6, scale=0.1)
+    x = _rand(B, cin, T, seed=7)
+    pad = (k - u) // 2
+    ref = F.conv_transpose1d(F.leaky_relu(x, 0.1), w, b, stride=u, padding=pad)
+    y = conv_forward(w, b, x, transposed=True, stride=u, padding=pad, slope_in=0.1)
+    assert y.shape == ref.shape
+    assert (y - ref).abs().max().item() <= 2e-5
+
+
+def test_unsupported_receptive_field_is_an_error():
+    from amphion_amd._lib import AmpError
+    from hip_helpers import conv_forward
+
+    w = _rand(8, 8, 11, seed=1)
+    with pytest.raises(AmpError):
+        conv_forward(w, None, _rand(1, 8, 64), dilation=20, padding=100)
