@@ -143,6 +143,15 @@ class HipGenerator(nn.Module):
         d.activation, d.snake_logscale, d.gin_channels = int(activation), int(bool(logscale)), int(gin)
         return d
 
+    @property
+    def hop_factor(self) -> int:
+        """Output samples per input frame = prod(upsample_rates)."""
+        d = self._amp_desc()
+        h = 1
+        for i in range(d.n_stages):
+            h *= d.upsample_rates[i]
+        return h
+
     def _amp_signature(self):
         return tuple((k, v.data_ptr(), v._version, tuple(v.shape)) for k, v in self.state_dict(keep_vars=True).items())
 

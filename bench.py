@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""bench.py -- vocoder-inference throughput on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one forward of the hot path (HiFi-GAN V1 generator, mel -> waveform) over one batch of
+synthetic mels already resident in HBM: BASELINE.json configs[1] = B=64 x 80 mel x 256 frames per GPU
+(weak scaling: every rank runs its own B=64 shard; for N>1 the step includes the RCCL gather of the
+audio to rank 0).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+from types import SimpleNamespace as NS  # noqa: E402
+
+SAMPLE_RATE = 22050
+B_PER_GPU, N_MEL, T_FRAMES = 64, 80, 256
+# Algorithmic cost per OUTPUT SAMPLE of HiFi-GAN V1 (SURVEY.md §8d / BASELINE.md §3):
+FLOP_PER_SAMPLE_ALL = 2_398_848
+FLOP_PER_SAMPLE_MRF = 2_322_432      # the 72 ResBlock convs (96.8 %)
+BYTES_PER_SAMPLE_MRF = 14_976        # layer-wise minimum fp32 HBM traffic of those convs
+PEAK_FP32_TFLOPS = 157.3             # MI355X_MICROARCH.md: fp32 MFMA == fp32 vector peak
+PEAK_HBM_GBS = 8000.0
+
+
+def build_model(device):
+    from amphion_amd.models.vocoders.gan.generator.hifigan import HiFiGAN
+    from oracle import synth
+    from oracle import vocoder_oracle as vo
+
+    hp = vo.hifigan_v1_hp()
+    cfg = NS(preprocess=NS(n_mel=N_MEL, hop_size=256, sample_rate=SAMPLE_RATE), model=NS(hifigan=NS(**hp)))
+    model = HiFiGAN(cfg)
+    sd = synth.synth_state_dict(synth.hifigan_param_shapes(N_MEL, hp), 1234)
+    model.load_state_dict(sd)
+    return model.to(device).eval(), sd, hp
+
+
+def cpu_baseline(sd, hp, budget_s=20.0):
+    """Reference CPU path (oracle = the reference's own torch ops) on the host cores, bounded sample."""
+    from oracle import synth
+    from oracle import vocoder_oracle as vo
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    with torch.no_grad():
+        vo.hifigan_forward(sd, hp, synth.synth_mel(1, N_MEL, 32, seed=1))  # warm-up
+        B, T = 4, T_FRAMES
+        mel = synth.synth_mel(B, N_MEL, T, seed=2)
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            vo.hifigan_forward(sd, hp, mel)
+            reps += 1
+            el = time.perf_counter() - t0
+            if el >= budget_s * 0.5 or reps >= 16:
+                break
+    samples = reps * B * T * 256
+    return {
+        "value": samples / el,
+        "unit": "samples/s",
+        "x_realtime": samples / el / SAMPLE_RATE,
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"{reps} x HiFi-GAN V1 forward at B={B}, T={T} (oracle/vocoder_oracle.py, torch CPU fp32, "
+                  f"{torch.get_num_threads()} threads), {el:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from amphion_amd.distributed import gather_audio
+    from oracle import synth
+
+    model, sd, hp = build_model(device)
+    mel = synth.synth_mel(B_PER_GPU, N_MEL, T_FRAMES, seed=rank).to(device)  # resident in HBM before timing
+    L = T_FRAMES * model.hop_factor
+    total_items = B_PER_GPU * world
+
+    def step():
+        with torch.no_grad():
+            wav = model(mel)
+            if world > 1:
+                return gather_audio(wav.squeeze(1), total_items, dst=0)
+            return wav
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+
+    # per-kernel-group time of one more (untimed) step, HIP events on the launch stream
+    model.set_profiling(True)
+    step()
+    torch.cuda.synchronize()
+    fwd_ms, mrf_ms = [], []
+    for _ in range(max(3, min(args.steps, 10))):
+        step()
+        fwd_ms.append(model.last_timing_ms(0))
+        mrf_ms.append(model.last_timing_ms(1))
+    model.set_profiling(False)
+
+    if rank == 0:
+        samples_per_step = total_items * L
+        value = samples_per_step * args.steps / elapsed
+        n_local = B_PER_GPU * L
+        mrf_s = (sum(mrf_ms) / len(mrf_ms)) * 1e-3
+        fwd_s = (sum(fwd_ms) / len(fwd_ms)) * 1e-3
+        mrf_tflops = FLOP_PER_SAMPLE_MRF * n_local / mrf_s / 1e12
+        mrf_gbs = BYTES_PER_SAMPLE_MRF * n_local / mrf_s / 1e9
+        result = {
+            "metric": "audio samples/sec (HiFi-GAN V1 22.05 kHz generator, mel->wav)",
+            "value": value,
+            "unit": "samples/s",
+            "x_realtime": value / SAMPLE_RATE,
+            "x_realtime_per_gpu": value / SAMPLE_RATE / world,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"HiFi-GAN V1 22.05 kHz, batch={B_PER_GPU}/GPU synthetic {N_MEL}-ch x {T_FRAMES}-frame mels "
+                            f"(BASELINE.json configs[1]), random-init weights, fp32",
+                "global_batch": total_items,
+                "frames": T_FRAMES,
+                "samples_per_step": samples_per_step,
+                "parallelism": f"batch-sharded x{world}, result gather on rank 0" if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "kernel": "MRF conv stack (72 fused dilated Conv1d, conv_mfma_kernel)",
+                "bound": "mfma",
+                "achieved": mrf_tflops,
+                "peak": PEAK_FP32_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": mrf_tflops / PEAK_FP32_TFLOPS,
+                "traffic": None,
+                "hbm_term": {"achieved": mrf_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": mrf_gbs / PEAK_HBM_GBS},
+                "mrf_ms": mrf_s * 1e3,
+                "forward_ms": fwd_s * 1e3,
+                "whole_forward_tflops": FLOP_PER_SAMPLE_ALL * n_local / fwd_s / 1e12,
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline(sd, hp)
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

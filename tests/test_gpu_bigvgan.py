@@ -1,0 +1,112 @@
+"""GPU parity: fused anti-aliased Snake kernel and the whole BigVGAN generator."""
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import synth
+from oracle import vocoder_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+
+def test_activation1d_golden(golden):
+    from hip_helpers import act1d_forward
+
+    x = torch.from_numpy(golden["act1d_x"])
+    f = torch.from_numpy(golden["act1d_filter"])
+    y = act1d_forward(x, torch.from_numpy(golden["act1d_snakebeta_log_alpha"]), torch.from_numpy(golden["act1d_snakebeta_log_beta"]), True, f, f)
+    assert np.abs(y.numpy() - golden["act1d_snakebeta_log_y"]).max() <= 5e-6
+    y = act1d_forward(x, torch.from_numpy(golden["act1d_snake_lin_alpha"]), None, False, f, f)
+    assert np.abs(y.numpy() - golden["act1d_snake_lin_y"]).max() <= 5e-6
+    y = act1d_forward(torch.from_numpy(golden["act1d_T1_x"]), torch.from_numpy(golden["act1d_snake_lin_alpha"]), None, False, f, f)
+    assert np.abs(y.numpy() - golden["act1d_T1_y"]).max() <= 5e-6
+
+
+@pytest.mark.parametrize("B,C,T", [(1, 3, 2), (2, 32, 1023), (1, 7, 1024), (2, 5, 1025), (1, 2, 5000)])
+def test_activation1d_vs_oracle(B, C, T):
+    from hip_helpers import act1d_forward
+
+    g = torch.Generator().manual_seed(B * 7 + C + T)
+    x = torch.randn(B, C, T, generator=g) * 1.5
+    al = torch.randn(C, generator=g) * 0.3
+    be = torch.randn(C, generator=g) * 0.3
+    f = vo.kaiser_sinc_filter1d(0.25, 0.3, 12)
+    ref = vo.activation1d(x, al, be, True)
+    y = act1d_forward(x, al, be, True, f, f)
+    assert (y - ref).abs().max().item() <= 5e-6
+
+
+def test_activation1d_module():
+    from amphion_amd.modules.activation_functions import SnakeBeta
+    from amphion_amd.modules.anti_aliasing import Activation1d
+
+    act = Activation1d(activation=SnakeBeta(6, alpha_logscale=True))
+    g = torch.Generator().manual_seed(3)
+    act.act.alpha.data = torch.randn(6, generator=g) * 0.3
+    act.act.beta.data = torch.randn(6, generator=g) * 0.3
+    x = torch.randn(2, 6, 333, generator=g)
+    ref = vo.activation1d(x, act.act.alpha.data, act.act.beta.data, True)
+    y = act.cuda()(x.cuda()).cpu()
+    assert (y - ref).abs().max().item() <= 5e-6
+    with pytest.raises(RuntimeError):
+        act(x)  # CPU tensor: no fallback
+
+
+def _bigvgan(hp, n_mel, sd):
+    from amphion_amd.models.vocoders.gan.generator.bigvgan import BigVGAN
+
+    cfg = NS(preprocess=NS(n_mel=n_mel, hop_size=256), model=NS(bigvgan=NS(**hp)))
+    m = BigVGAN(cfg)
+    m.load_state_dict(sd)
+    return m.cuda().eval()
+
+
+@pytest.mark.parametrize("tag", ["b1_t8", "b2_t13"])
+def test_bigvgan_base_golden(golden, tag):
+    hp = vo.bigvgan_base_hp()
+    sd = synth.synth_state_dict(synth.bigvgan_param_shapes(100, hp), 1234, g_gain=0.75)
+    m = _bigvgan(hp, 100, sd)
+    with torch.no_grad():
+        y = m(torch.from_numpy(golden[f"bigvgan_base_{tag}_mel"]).cuda()).cpu().numpy()
+    ref = golden[f"bigvgan_base_{tag}_wav"]
+    assert y.shape == ref.shape
+    assert np.abs(y - ref).max() <= 1e-4
+
+
+def test_bigvgan_small_ampblock2_snake_golden(golden):
+    hp = dict(resblock="2", activation="snake", snake_logscale=False, upsample_rates=[4, 2], upsample_kernel_sizes=[8, 4],
+              upsample_initial_channel=64, resblock_kernel_sizes=[3, 5], resblock_dilation_sizes=[[1, 2], [2, 6]])
+    sd = synth.synth_state_dict(synth.bigvgan_param_shapes(20, hp), seed=9, g_gain=0.75)
+    for k in sd:
+        if k.endswith(".alpha"):
+            sd[k] = sd[k].abs() + 0.5
+    m = _bigvgan(hp, 20, sd)
+    with torch.no_grad():
+        y = m(torch.from_numpy(golden["bigvgan_small_mel"]).cuda()).cpu().numpy()
+    assert np.abs(y - golden["bigvgan_small_wav"]).max() <= 1e-4
+
+
+def test_bigvgan_base_vs_oracle_with_fp64_reference():
+    hp = vo.bigvgan_base_hp()
+    sd = synth.synth_state_dict(synth.bigvgan_param_shapes(100, hp), 1234, g_gain=0.75)
+    m = _bigvgan(hp, 100, sd)
+    g = torch.Generator().manual_seed(4)
+    mel = torch.randn(2, 100, 40, generator=g)
+    with torch.no_grad():
+        y = m(mel.cuda()).cpu()
+        ref = vo.bigvgan_forward(sd, hp, mel)
+        ref64 = vo.bigvgan_forward(sd, hp, mel, dtype=torch.float64)
+    err = (y - ref).abs().max().item()
+    print(f"|hip-oracle32|={err:.2e} |hip-oracle64|={(y.double()-ref64).abs().max().item():.2e} "
+          f"|oracle32-oracle64|={(ref.double()-ref64).abs().max().item():.2e}")
+    assert err <= 1e-4
+
+
+def test_bigvgan_bad_activation():
+    from amphion_amd.models.vocoders.gan.generator.bigvgan import BigVGAN
+
+    hp = dict(vo.bigvgan_base_hp(), activation="gelu")
+    with pytest.raises(NotImplementedError):
+        BigVGAN(NS(preprocess=NS(n_mel=100), model=NS(bigvgan=NS(**hp))))

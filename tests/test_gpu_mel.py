@@ -1,0 +1,96 @@
+"""GPU parity: the fused STFT/mel front-end kernel vs golden vectors of the reference's utils/mel.py
+and utils/stft.py, and vs the CPU oracle on seeded audio.
+
+Tolerances (fp32): linear spectra 2e-5 relative to the spectrum's max (FFT rounding differs from
+pocketfft's); log-mel 1e-3 absolute (the log amplifies rounding of small mel energies)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vocoder_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+
+def _wav(golden):
+    y = torch.from_numpy(golden["wav_pcm16"].astype(np.float32) / 32768.0).unsqueeze(0)
+    return y, torch.stack([y[0], torch.roll(y[0], 777) * 0.5])
+
+
+@pytest.mark.parametrize("tag,pp", [("22k", vo.preprocess_22k()), ("24k", vo.preprocess_24k())])
+def test_mel_front_end_golden(golden, tag, pp):
+    from amphion_amd.utils import mel as M
+
+    y, y2 = _wav(golden)
+    out = M.extract_mel_features(y.cuda(), pp).cpu().numpy()
+    ref = golden[f"mel_{tag}_extract"]
+    assert out.shape == ref.shape
+    assert np.abs(out - ref).max() <= 1e-3
+    out = M.mel_spectrogram_torch(y2.cuda(), pp).cpu().numpy()
+    assert out.shape == golden[f"mel_{tag}_melspec_b2"].shape
+    assert np.abs(out - golden[f"mel_{tag}_melspec_b2"]).max() <= 1e-3
+    lin = M.extract_linear_features(y.cuda(), pp).cpu().numpy()
+    ref = golden[f"mel_{tag}_linear"]
+    assert lin.shape == ref.shape
+    assert np.abs(lin - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    la, ph, re, im = (t.cpu().numpy() for t in M.amplitude_phase_spectrum(y2.cuda(), pp))
+    scale = max(1.0, float(np.abs(golden[f"mel_{tag}_re"]).max()))
+    assert np.abs(re - golden[f"mel_{tag}_re"]).max() <= 2e-5 * scale
+    assert np.abs(im - golden[f"mel_{tag}_im"]).max() <= 2e-5 * scale
+    # log-amplitude: compare where the bin is not rounding noise
+    big = np.exp(golden[f"mel_{tag}_logamp"]) > 1e-3
+    assert np.abs(la - golden[f"mel_{tag}_logamp"])[big].max() <= 5e-2
+
+
+@pytest.mark.parametrize("tag,pp", [("22k", vo.preprocess_22k()), ("24k", vo.preprocess_24k())])
+def test_tacotron_stft_golden(golden, tag, pp):
+    from amphion_amd.utils.stft import TacotronSTFT
+
+    _, y2 = _wav(golden)
+    taco = TacotronSTFT(pp.n_fft, pp.hop_size, pp.win_size, pp.n_mel, pp.sample_rate, pp.fmin, pp.fmax).cuda()
+    mel, energy = taco.mel_spectrogram(y2.cuda())
+    assert np.abs(mel.cpu().numpy() - golden[f"taco_{tag}_mel"]).max() <= 1e-3
+    ref_e = golden[f"taco_{tag}_energy"]
+    assert np.abs(energy.cpu().numpy() - ref_e).max() <= 2e-5 * max(1.0, ref_e.max())
+    mag, phase = taco.stft_fn.transform(y2.cuda())
+    ref = golden[f"taco_{tag}_mag"]
+    assert mag.shape == ref.shape
+    assert np.abs(mag.cpu().numpy() - ref).max() <= 2e-5 * max(1.0, ref.max())
+
+
+@pytest.mark.parametrize("B,L", [(1, 256 * 3), (3, 256 * 17), (2, 22016), (1, 1000)])
+def test_mel_vs_oracle_seeded(B, L):
+    from amphion_amd.utils import mel as M
+
+    pp = vo.preprocess_22k()
+    g = torch.Generator().manual_seed(L)
+    y = (torch.rand(B, L, generator=g) * 2 - 1) * 0.8
+    ref = vo.mel_spectrogram_torch(y, pp)
+    out = M.mel_spectrogram_torch(y.cuda(), pp).cpu()
+    assert out.shape == ref.shape
+    assert (out - ref).abs().max().item() <= 1e-3
+
+
+def test_mel_small_nfft_and_window_shorter_than_fft():
+    from types import SimpleNamespace as NS
+
+    from amphion_amd.utils import mel as M
+
+    pp = NS(sample_rate=16000, n_fft=512, win_size=400, hop_size=160, n_mel=40, fmin=20, fmax=None)
+    g = torch.Generator().manual_seed(1)
+    y = (torch.rand(2, 4000, generator=g) * 2 - 1) * 0.5
+    ref = vo.mel_spectrogram_torch(y, pp)
+    out = M.mel_spectrogram_torch(y.cuda(), pp).cpu()
+    assert out.shape == ref.shape
+    assert (out - ref).abs().max().item() <= 1e-3
+
+
+def test_mel_errors():
+    from amphion_amd._lib import AmpError
+    from amphion_amd.utils import mel as M
+
+    pp = vo.preprocess_22k()
+    with pytest.raises(RuntimeError):
+        M.extract_mel_features(torch.zeros(1, 4096), pp)          # CPU tensor
+    with pytest.raises(AmpError):
+        M.extract_mel_features(torch.zeros(1, 100).cuda(), pp)    # shorter than the reflect padding
