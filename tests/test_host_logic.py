@@ -1,0 +1,166 @@
+"""CPU-only: host-side logic and the C-ABI surface (no compute calls -- there is no GPU here)."""
+import ctypes
+import os
+import re
+from types import SimpleNamespace as NS
+
+import pytest
+import torch
+
+from amphion_amd import _lib
+from oracle import synth
+from oracle import vocoder_oracle as vo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "amphion_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(amp_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 19
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in amphion_hip.h but not exported"
+    assert declared == set(_lib.EXPORTED_SYMBOLS)
+    assert _lib.lib().amp_version() >= 100
+
+
+def _desc(**over):
+    hp = vo.hifigan_v1_hp()
+    from amphion_amd.models.vocoders.gan.generator._engine import HipGenerator
+
+    d = HipGenerator._fill_desc(_lib.AMP_ARCH_HIFIGAN, 80, 512, hp["upsample_rates"], hp["upsample_kernel_sizes"],
+                                hp["resblock_kernel_sizes"], hp["resblock_dilation_sizes"], "1")
+    for k, v in over.items():
+        setattr(d, k, v)
+    return d
+
+
+def test_gen_create_validation_and_weight_keys():
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    with pytest.raises(_lib.AmpError):
+        _lib.check(L.amp_gen_create(ctypes.byref(_desc(arch=7)), ctypes.byref(h)))
+    with pytest.raises(_lib.AmpError) as ei:  # bigvgan.py:132-135 message
+        _lib.check(L.amp_gen_create(ctypes.byref(_desc(arch=_lib.AMP_ARCH_BIGVGAN, activation=0)), ctypes.byref(h)))
+    assert "activation incorrectly specified" in str(ei.value)
+    with pytest.raises(_lib.AmpError):
+        _lib.check(L.amp_gen_create(ctypes.byref(_desc(n_stages=0)), ctypes.byref(h)))
+
+    _lib.check(L.amp_gen_create(ctypes.byref(_desc()), ctypes.byref(h)))
+    try:
+        assert L.amp_gen_hop(h) == 256
+        w = torch.zeros(512, 80, 7)
+        shp = (ctypes.c_int64 * 3)(512, 80, 7)
+        _lib.check(L.amp_gen_set_weight(h, b"conv_pre.weight_v", ctypes.c_void_p(w.data_ptr()), shp, 3))
+        _lib.check(L.amp_gen_set_weight(h, b"module.conv_pre.weight_v", ctypes.c_void_p(w.data_ptr()), shp, 3))
+        with pytest.raises(_lib.AmpError) as ei:
+            _lib.check(L.amp_gen_set_weight(h, b"conv_pre.nonsense", ctypes.c_void_p(w.data_ptr()), shp, 3))
+        assert "unexpected key" in str(ei.value)
+        bad = (ctypes.c_int64 * 3)(512, 81, 7)
+        with pytest.raises(_lib.AmpError) as ei:
+            _lib.check(L.amp_gen_set_weight(h, b"conv_pre.weight_v", ctypes.c_void_p(w.data_ptr()), bad, 3))
+        assert "shape" in str(ei.value)
+        if L.amp_device_count() == 0:
+            # no CPU fallback: finalize/forward refuse loudly without a device
+            with pytest.raises(_lib.AmpError):
+                _lib.check(L.amp_gen_finalize(h))
+            with pytest.raises(_lib.AmpError):
+                _lib.check(L.amp_gen_forward(h, ctypes.c_void_p(8), None, 1, 4, ctypes.c_void_p(8), ctypes.c_void_p(8), 1 << 30, None))
+    finally:
+        L.amp_gen_destroy(h)
+
+
+def test_conv_create_refuses_without_device():
+    L = _lib.lib()
+    if L.amp_device_count() != 0:
+        pytest.skip("GPU present")
+    w = torch.zeros(4, 4, 3)
+    h = ctypes.c_void_p()
+    with pytest.raises(_lib.AmpError) as ei:
+        _lib.check(L.amp_conv_create(0, 4, 4, 3, 1, 1, 1, ctypes.c_void_p(w.data_ptr()), None, ctypes.byref(h)))
+    assert "no CPU fallback" in str(ei.value)
+
+
+def test_mel_num_frames():
+    L = _lib.lib()
+    d = _lib.amp_mel_desc(1024, 1024, 256, 80, 0, 1e-9, 1e-5)
+    assert L.amp_mel_num_frames(ctypes.byref(d), 22016) == 86
+    assert L.amp_mel_num_frames(ctypes.byref(d), 256 * 40) == 40
+    d.pad_mode = 1
+    assert L.amp_mel_num_frames(ctypes.byref(d), 256 * 40) == 41    # TacotronSTFT: L/hop + 1
+
+
+def _model(seed=1234):
+    from amphion_amd.models.vocoders.gan.generator.hifigan import HiFiGAN
+
+    hp = vo.hifigan_v1_hp()
+    cfg = NS(preprocess=NS(n_mel=80, hop_size=256), model=NS(hifigan=NS(**hp)))
+    m = HiFiGAN(cfg)
+    sd = synth.synth_state_dict(synth.hifigan_param_shapes(80, hp), seed)
+    m.load_state_dict(sd)
+    return m, sd
+
+
+def test_state_dict_round_trip_both_forms():
+    m, sd = _model()
+    out = m.state_dict()
+    assert list(out.keys()) == list(sd.keys())
+    assert all(torch.equal(out[k], sd[k]) for k in sd)
+    # folded form: keys collapse to .weight exactly like torch.nn.utils.remove_weight_norm
+    m.remove_weight_norm()
+    folded = m.state_dict()
+    assert "conv_pre.weight" in folded and "conv_pre.weight_g" not in folded
+    w = vo.fold_weight_norm(sd["ups.0.weight_g"], sd["ups.0.weight_v"])
+    assert (folded["ups.0.weight"] - w).abs().max().item() <= 1e-6
+    with pytest.raises(ValueError):
+        m.conv_pre.remove_weight_norm()
+    # a weight-normed module accepts a folded checkpoint and vice versa
+    m2, _ = _model(seed=7)
+    m2.load_state_dict(folded)
+    assert torch.equal(m2.state_dict()["conv_post.weight"], folded["conv_post.weight"])
+    m.load_state_dict(sd)
+    assert "conv_pre.weight_g" in m.state_dict()
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({k: v for k, v in sd.items() if k != "conv_post.bias"})
+
+
+def test_signature_tracks_parameter_changes():
+    m, sd = _model()
+    s0 = m._amp_signature()
+    assert m._amp_signature() == s0
+    with torch.no_grad():
+        m.conv_post.bias.add_(1.0)
+    assert m._amp_signature() != s0
+    s1 = m._amp_signature()
+    m.load_state_dict(sd)
+    assert m._amp_signature() != s1
+    assert m.hop_factor == 256
+
+
+def test_pad_mels_to_tensors_matches_reference_semantics():
+    from amphion_amd.utils.util import pad_mels_to_tensors
+
+    mels = [torch.full((3, T), float(i + 1)) for i, T in enumerate((4, 7, 2, 5, 6))]
+    t, f = pad_mels_to_tensors(mels, None)
+    assert len(t) == 1 and tuple(t[0].shape) == (5, 3, 7) and f[0].tolist() == [4, 7, 2, 5, 6]
+    assert t[0][2, :, 2:].abs().sum() == 0 and t[0][2, :, :2].eq(3).all()
+    t, f = pad_mels_to_tensors(mels, 2)
+    assert [tuple(x.shape) for x in t] == [(2, 3, 7), (2, 3, 5), (1, 3, 6)]
+    assert [x.tolist() for x in f] == [[4, 7], [2, 5], [6]] and f[0].dtype == torch.int32
+    t, f = pad_mels_to_tensors(mels[:4], 2)
+    assert [tuple(x.shape) for x in t] == [(2, 3, 7), (2, 3, 5)]
+
+
+def test_registry_surface():
+    from amphion_amd.models.vocoders import vocoder_inference as vi
+    from amphion_amd.models.vocoders.gan import gan_vocoder_inference as gi
+
+    assert set(vi._vocoders) == {"hifigan", "bigvgan"}
+    assert vi._vocoder_forward_funcs["hifigan"] is gi.vocoder_inference
+    assert vi._vocoder_infer_funcs["bigvgan"] is gi.synthesis_audios
+    import inspect
+
+    assert list(inspect.signature(gi.vocoder_inference).parameters)[:6] == ["cfg", "model", "mels", "f0s", "device", "fast_inference"]
+    assert list(inspect.signature(vi.synthesis).parameters) == ["cfg", "vocoder_weight_file", "n_samples", "pred", "f0s", "batch_size", "fast_inference"]
