@@ -40,11 +40,66 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     const int q0 = tile * NT;
     const int mb = blockIdx.y * WM + wm;        // 32-row block of W'
 
+    // Accumulators start from bias (+ residual) (+ the running MRF sum): the epilogue is then
+    // store-only, and these loads overlap the first staging instead of serialising behind stores
+    // (res / y may alias, so the compiler cannot batch epilogue loads across stores).
+    const int up = a.up;
+    const int qw = q0 + wn * (32 * NI) + l31;
+    // wave-uniform: whole 32 x (32*NI) wave tile in range and no polyphase scatter -> straight-line
+    // loads/stores with scalar row bases (no per-element predicates)
+    const bool fast = (up == 1) && (mb * 32 + 32 <= a.M) && (q0 + wn * (32 * NI) + 32 * NI <= a.Tq);
+    const size_t wave_base = ((size_t)item * a.Cout + (size_t)mb * 32) * a.Tout;  // uniform
+    const int lane_off = (4 * hi) * a.Tout + qw;                                  // per lane
     f32x16 acc[NI];
+    if (fast) {
 #pragma unroll
-    for (int t = 0; t < NI; ++t)
+        for (int r = 0; r < 16; ++r) {
+            const int rowc = (r & 3) + 8 * (r >> 2);
+            const float bv = a.bias ? a.bias[mb * 32 + rowc + 4 * hi] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            for (int t = 0; t < NI; ++t) acc[t][r] = bv;
+        }
+        if (a.res) {
+            const float* rp = a.res + wave_base;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float* rr_ = rp + (size_t)((r & 3) + 8 * (r >> 2)) * a.Tout;
+#pragma unroll
+                for (int t = 0; t < NI; ++t) acc[t][r] += rr_[lane_off + 32 * t];
+            }
+        }
+        if (a.mode != 0) {
+            const float* yp = a.y + wave_base;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float* yr_ = yp + (size_t)((r & 3) + 8 * (r >> 2)) * a.Tout;
+#pragma unroll
+                for (int t = 0; t < NI; ++t) acc[t][r] += yr_[lane_off + 32 * t];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int m = mb * 32 + row;
+            const bool mok = m < a.M;
+            const int o = (up == 1) ? m : m / up;
+            const int rr = m - o * up;
+            const float bv = (mok && a.bias) ? a.bias[o] : 0.f;
+            const size_t rowoff = ((size_t)item * a.Cout + o) * a.Tout;
+#pragma unroll
+            for (int t = 0; t < NI; ++t) {
+                const int q = qw + 32 * t;
+                const int n = q * up + rr - a.up_pad;
+                float v = bv;
+                if (mok && q < a.Tq && n >= 0 && n < a.Tout) {
+                    if (a.res) v += a.res[rowoff + n];
+                    if (a.mode != 0) v += a.y[rowoff + n];
+                }
+                acc[t][r] = v;
+            }
+        }
+    }
 
     const float* xb = a.x + (size_t)item * a.Cin * a.Tin;
     const int tbase = q0 - a.halo_left;
@@ -114,29 +169,42 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue: bias, residual, MRF accumulate, activation-on-store, (polyphase) scatter ----
-    const int up = a.up;
-    const int qw = q0 + wn * (32 * NI) + l31;
+    // ---- epilogue: MRF mean, activation-on-store, (polyphase) scatter ----
+    const float slope_out = a.slope_out;
+    if (fast) {
+        const float scale = a.mode == 2 ? 1.f / a.div : 1.f;
+        float* yp = a.y + wave_base;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        const int m = mb * 32 + row;
-        if (m < a.M) {
-            const int o = (up == 1) ? m : m / up;
-            const int rr = m - o * up;
-            const float bv = a.bias ? a.bias[o] : 0.f;
-            const size_t rowoff = ((size_t)item * a.Cout + o) * a.Tout;
+        for (int r = 0; r < 16; ++r) {
+            float* yr_ = yp + (size_t)((r & 3) + 8 * (r >> 2)) * a.Tout;
 #pragma unroll
             for (int t = 0; t < NI; ++t) {
-                const int q = qw + 32 * t;
-                const int n = q * up + rr - a.up_pad;
-                if (q < a.Tq && n >= 0 && n < a.Tout) {
-                    float v = acc[t][r] + bv;
-                    if (a.res) v += a.res[rowoff + n];
-                    if (a.mode == 1) v = a.y[rowoff + n] + v;
-                    else if (a.mode == 2) v = (a.y[rowoff + n] + v) / a.div;
-                    v = v > 0.f ? v : v * a.slope_out;
-                    a.y[rowoff + n] = v;
+                float v = acc[t][r];
+                if (a.mode == 2) v = v / a.div;
+                (void)scale;
+                v = v > 0.f ? v : v * slope_out;
+                yr_[lane_off + 32 * t] = v;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int m = mb * 32 + row;
+            if (m < a.M) {
+                const int o = (up == 1) ? m : m / up;
+                const int rr = m - o * up;
+                const size_t rowoff = ((size_t)item * a.Cout + o) * a.Tout;
+#pragma unroll
+                for (int t = 0; t < NI; ++t) {
+                    const int q = qw + 32 * t;
+                    const int n = q * up + rr - a.up_pad;
+                    if (q < a.Tq && n >= 0 && n < a.Tout) {
+                        float v = acc[t][r];
+                        if (a.mode == 2) v = v / a.div;
+                        v = v > 0.f ? v : v * slope_out;
+                        a.y[rowoff + n] = v;
+                    }
                 }
             }
         }

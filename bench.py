@@ -50,9 +50,10 @@ def cpu_baseline(sd, hp, budget_s=20.0):
     from oracle import synth
     from oracle import vocoder_oracle as vo
 
-    # torch's CPU convs collapse when oversubscribed (256 threads on this node: 0.17x real time,
-    # measured); 32 threads is the best of {8,16,32,64} here, so that is the baseline we report.
-    cores = min(os.cpu_count() or 1, int(os.environ.get("AMP_CPU_BASELINE_THREADS", "32")))
+    # torch's CPU convs collapse when oversubscribed on the 2 x EPYC 9575F GPU host (measured with
+    # tools/cpu_threads_sweep.py at B=4,T=256: 8 thr x5.3 RT, 16 thr x6.7, 32 thr x4.3, 64 thr x2.4,
+    # 128 thr x1.3, 256 thr x0.17); 16 threads is the best, so that is the baseline we report.
+    cores = min(os.cpu_count() or 1, int(os.environ.get("AMP_CPU_BASELINE_THREADS", "16")))
     torch.set_num_threads(cores)
     with torch.no_grad():
         vo.hifigan_forward(sd, hp, synth.synth_mel(1, N_MEL, 32, seed=1))  # warm-up

@@ -71,8 +71,11 @@ def test_remove_weight_norm_and_reload_give_same_output():
         m2, _ = _hifigan(hp, 80, 999)      # different weights ...
         m2.load_state_dict(folded)          # ... replaced by the folded checkpoint
         y2 = m2(mel)
-    assert (y0 - y1).abs().max().item() <= 2e-6
-    assert (y0 - y2).abs().max().item() <= 2e-6
+    # the handle folds g*v/||v|| with a double-precision norm, torch's remove_weight_norm in fp32:
+    # weights differ by <= 1 ulp, which shows up as a few 1e-6 on the waveform
+    assert (y0 - y1).abs().max().item() <= 2e-5
+    assert (y0 - y2).abs().max().item() <= 2e-5
+    assert torch.equal(y1, y2)
 
 
 def test_forward_is_deterministic_and_batch_independent():
