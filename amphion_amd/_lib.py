@@ -75,7 +75,14 @@ _SIGNATURES = {
     "amp_conv_create": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, POINTER(c_void_p)]),
     "amp_conv_out_len": (c_int, [c_void_p, c_int]),
     "amp_conv_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_float, c_void_p, c_void_p]),
+    "amp_conv_forward_strided": (c_int, [c_void_p, c_void_p, ctypes.c_longlong, c_int, c_int, c_float, c_void_p, c_float, c_void_p, c_void_p]),
     "amp_conv_destroy": (None, [c_void_p]),
+    "amp_wn_gate": (c_int, [c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "amp_wn_accumulate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "amp_sequence_mask": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "amp_coupling_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "amp_flip_channels": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "amp_posterior_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "amp_antialias_snake": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "amp_mel_num_frames": (c_int, [POINTER(amp_mel_desc), c_int]),
     "amp_mel_forward": (c_int, [POINTER(amp_mel_desc), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -24,6 +24,7 @@ struct ConvArgs {
     const float* res;    // [B, Cout, Tout] or nullptr (may alias y)
     float* y;            // [B, Cout, Tout]
     int B, Cin, Tin;
+    long long xbs;       // batch stride of x in elements (Cin*Tin when dense; larger for a channel slice)
     int nchunks;         // ceil(Cin / KC)
     int M;               // GEMM rows = Cout * up
     int Tq;              // GEMM columns per batch item
@@ -63,6 +64,18 @@ hipError_t launch_act1d(const float* x, float* y, int B, int C, int T, const flo
 
 // y[b,c,t] += cond[b,c]   (HiFiGAN_vits `x + self.cond(g)` with g of length 1)
 hipError_t launch_add_channel_bias(float* y, const float* cb, int B, int C, int T, hipStream_t stream);
+
+// VITS posterior-encoder / flow element-wise kernels (small_kernels.hip)
+hipError_t launch_wn_gate(const float* a, const float* cond, long long cond_bs, float* out, int B, int H, int T,
+                          hipStream_t stream);
+hipError_t launch_wn_accumulate(float* x, float* out, const float* rs, const int* lens, int B, int H, int T, int last,
+                                int first, hipStream_t stream);
+hipError_t launch_mask(float* x, const int* lens, int B, int C, int T, hipStream_t stream);
+hipError_t launch_coupling(float* x, const float* m, const int* lens, int B, int h, int T, int reverse,
+                           hipStream_t stream);
+hipError_t launch_flip_channels(const float* x, float* y, int B, int C, int T, hipStream_t stream);
+hipError_t launch_posterior_sample(const float* stats, const float* eps, const int* lens, float* z, int B, int C, int T,
+                                   hipStream_t stream);
 
 // mel front end (mel.hip)
 hipError_t launch_mel(const amp_mel_desc& d, const float* wav, int B, int L, int F, const float* window,

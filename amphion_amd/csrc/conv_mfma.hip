@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         }
     }
 
-    const float* xb = a.x + (size_t)item * a.Cin * a.Tin;
+    const float* xb = a.x + (size_t)item * (size_t)a.xbs;
     const int tbase = q0 - a.halo_left;
     const float slope_in = a.slope_in;
 

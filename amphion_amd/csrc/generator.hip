@@ -173,13 +173,13 @@ static int conv_out_len(const amp_conv* c, int T) {
 
 // mode 0: y = v, 1: y += v, 2: y = (y + v) / div
 static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope_in, const float* res, float slope_out,
-                    float* y, int mode, float div, hipStream_t stream) {
+                    float* y, int mode, float div, hipStream_t stream, long long xbs = 0) {
     if (B <= 0 || T <= 0) { set_error("amp_conv_forward: B=%d T=%d", B, T); return AMP_ERR_INVALID; }
     const int Tout = conv_out_len(c, T);
     if (Tout <= 0) { set_error("amp_conv_forward: input too short (T=%d)", T); return AMP_ERR_INVALID; }
     ConvArgs a{};
     a.x = x; a.wp = c->wp_dev; a.bias = c->bias_dev; a.res = res; a.y = y;
-    a.B = B; a.Cin = c->cin; a.Tin = T; a.nchunks = c->nchunks; a.M = c->M;
+    a.B = B; a.Cin = c->cin; a.Tin = T; a.xbs = xbs > 0 ? xbs : (long long)c->cin * T; a.nchunks = c->nchunks; a.M = c->M;
     a.Tq = c->transposed ? T + c->ntaps - 1 : Tout;
     const int NT = c->plan.NT();
     a.tiles_per_item = (a.Tq + NT - 1) / NT;
@@ -667,7 +667,57 @@ int amp_conv_forward(const amp_conv* c, const float* x_dev, int B, int T, float 
     return conv_run(c, x_dev, B, T, slope_in, res_dev, slope_out, y_dev, 0, 1.f, (hipStream_t)stream);
 }
 
+int amp_conv_forward_strided(const amp_conv* c, const float* x_dev, long long x_batch_stride, int B, int T,
+                             float slope_in, const float* res_dev, float slope_out, float* y_dev, void* stream) {
+    if (!c || !x_dev || !y_dev) { set_error("amp_conv_forward_strided: null argument"); return AMP_ERR_INVALID; }
+    if (x_batch_stride < (long long)c->cin * T) { set_error("amp_conv_forward_strided: batch stride %lld < cin*T", x_batch_stride); return AMP_ERR_INVALID; }
+    return conv_run(c, x_dev, B, T, slope_in, res_dev, slope_out, y_dev, 0, 1.f, (hipStream_t)stream, x_batch_stride);
+}
+
 void amp_conv_destroy(amp_conv* c) { delete c; }
+
+// ---- VITS posterior encoder / flow element-wise ops ----------------------------------------------
+#define AMP_EW_CHECK(name, cond) do { if (!(cond)) { set_error(name ": bad argument"); return AMP_ERR_INVALID; } } while (0)
+
+int amp_wn_gate(const float* a_dev, const float* cond_dev, long long cond_batch_stride, float* out_dev, int B, int H,
+                int T, void* stream) {
+    AMP_EW_CHECK("amp_wn_gate", a_dev && out_dev && B > 0 && H > 0 && T > 0);
+    AMP_HIP(launch_wn_gate(a_dev, cond_dev, cond_batch_stride, out_dev, B, H, T, (hipStream_t)stream));
+    return AMP_OK;
+}
+
+int amp_wn_accumulate(float* x_dev, float* out_dev, const float* rs_dev, const int32_t* lens_dev, int B, int H, int T,
+                      int first, int last, void* stream) {
+    AMP_EW_CHECK("amp_wn_accumulate", x_dev && out_dev && rs_dev && B > 0 && H > 0 && T > 0);
+    AMP_HIP(launch_wn_accumulate(x_dev, out_dev, rs_dev, lens_dev, B, H, T, last, first, (hipStream_t)stream));
+    return AMP_OK;
+}
+
+int amp_sequence_mask(float* x_dev, const int32_t* lens_dev, int B, int C, int T, void* stream) {
+    AMP_EW_CHECK("amp_sequence_mask", x_dev && lens_dev && B > 0 && C > 0 && T > 0);
+    AMP_HIP(launch_mask(x_dev, lens_dev, B, C, T, (hipStream_t)stream));
+    return AMP_OK;
+}
+
+int amp_coupling_apply(float* x_dev, const float* m_dev, const int32_t* lens_dev, int B, int half_channels, int T,
+                       int reverse, void* stream) {
+    AMP_EW_CHECK("amp_coupling_apply", x_dev && m_dev && B > 0 && half_channels > 0 && T > 0);
+    AMP_HIP(launch_coupling(x_dev, m_dev, lens_dev, B, half_channels, T, reverse, (hipStream_t)stream));
+    return AMP_OK;
+}
+
+int amp_flip_channels(const float* x_dev, float* y_dev, int B, int C, int T, void* stream) {
+    AMP_EW_CHECK("amp_flip_channels", x_dev && y_dev && x_dev != y_dev && B > 0 && C > 0 && T > 0);
+    AMP_HIP(launch_flip_channels(x_dev, y_dev, B, C, T, (hipStream_t)stream));
+    return AMP_OK;
+}
+
+int amp_posterior_sample(const float* stats_dev, const float* eps_dev, const int32_t* lens_dev, float* z_dev, int B,
+                         int C, int T, void* stream) {
+    AMP_EW_CHECK("amp_posterior_sample", stats_dev && eps_dev && z_dev && B > 0 && C > 0 && T > 0);
+    AMP_HIP(launch_posterior_sample(stats_dev, eps_dev, lens_dev, z_dev, B, C, T, (hipStream_t)stream));
+    return AMP_OK;
+}
 
 int amp_antialias_snake(const float* x_dev, int B, int C, int T, const float* alpha_dev, const float* beta_dev,
                         int logscale, const float* filt_up_host, const float* filt_down_host, float* y_dev,

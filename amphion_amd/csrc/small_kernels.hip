@@ -158,4 +158,134 @@ hipError_t launch_add_channel_bias(float* y, const float* cb, int B, int C, int 
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// VITS posterior encoder / flow element-wise kernels.  All are one pass over [B, C, T] with
+// time-contiguous float4-free coalesced access (T is arbitrary), grid = B*C rows x time blocks.
+// ---------------------------------------------------------------------------------------------
+#define AMP_ROW_LOOP(rows, T)                                             \
+    const int tb = (T + 1023) / 1024;                                     \
+    const int row = blockIdx.x / tb;                                      \
+    const int tstart = (blockIdx.x - row * tb) * 1024 + threadIdx.x;      \
+    const int tend = min(T, (int)((blockIdx.x - row * tb) * 1024 + 1024));
+static inline unsigned row_grid(int rows, int T) { return (unsigned)((size_t)rows * ((T + 1023) / 1024)); }
+
+// fused_add_tanh_sigmoid_multiply (utils/util.py:602-609) with the time-constant condition g_l:
+// out[b,c,t] = tanh(a[b,c,t] + g[b,c]) * sigmoid(a[b,c+H,t] + g[b,c+H])     modules/flow/modules.py:141
+__global__ __launch_bounds__(256) void wn_gate_kernel(const float* __restrict__ a, const float* __restrict__ cond,
+                                                      long long cond_bs, float* __restrict__ out, int H, int T) {
+    AMP_ROW_LOOP(B * H, T)
+    const int b = row / H, c = row - b * H;
+    const float gt = cond ? cond[(size_t)b * cond_bs + c] : 0.f;
+    const float gs = cond ? cond[(size_t)b * cond_bs + c + H] : 0.f;
+    const float* at = a + ((size_t)b * 2 * H + c) * T;
+    const float* as = at + (size_t)H * T;
+    float* o = out + (size_t)row * T;
+    for (int t = tstart; t < tend; t += 256) {
+        const float tv = tanhf(at[t] + gt);
+        const float sv = 1.0f / (1.0f + expf(-(as[t] + gs)));
+        o[t] = tv * sv;
+    }
+}
+
+// x = (x + rs[:, :H]) * mask ; out (+)= rs[:, H:]      (last layer: out (+)= rs)   modules.py:146-151
+__global__ __launch_bounds__(256) void wn_accumulate_kernel(float* __restrict__ x, float* __restrict__ out,
+                                                            const float* __restrict__ rs,
+                                                            const int* __restrict__ lens, int H, int T, int last,
+                                                            int first) {
+    AMP_ROW_LOOP(B * H, T)
+    const int b = row / H, c = row - b * H;
+    const int len = lens ? lens[b] : T;
+    float* xr = x + (size_t)row * T;
+    float* orow = out + (size_t)row * T;
+    if (last) {
+        const float* r = rs + ((size_t)b * H + c) * T;
+        for (int t = tstart; t < tend; t += 256) orow[t] = (first ? 0.f : orow[t]) + r[t];
+    } else {
+        const float* r0 = rs + ((size_t)b * 2 * H + c) * T;
+        const float* r1 = r0 + (size_t)H * T;
+        for (int t = tstart; t < tend; t += 256) {
+            xr[t] = (xr[t] + r0[t]) * (t < len ? 1.f : 0.f);
+            orow[t] = (first ? 0.f : orow[t]) + r1[t];
+        }
+    }
+}
+
+// x *= sequence_mask(lens)                                  utils/util.py:618-622
+__global__ __launch_bounds__(256) void mask_kernel(float* __restrict__ x, const int* __restrict__ lens, int C, int T) {
+    AMP_ROW_LOOP(B * C, T)
+    const int len = lens[row / C];
+    float* xr = x + (size_t)row * T;
+    for (int t = tstart; t < tend; t += 256)
+        if (t >= len) xr[t] = 0.f;
+        else xr[t] = xr[t] * 1.f;
+}
+
+// mean-only coupling (modules/flow/modules.py:379-397): forward x1 = m + x1*mask, reverse x1 = (x1 - m)*mask
+__global__ __launch_bounds__(256) void coupling_kernel(float* __restrict__ x, const float* __restrict__ m,
+                                                       const int* __restrict__ lens, int h, int T, int reverse) {
+    AMP_ROW_LOOP(B * h, T)
+    const int b = row / h, c = row - b * h;
+    const int len = lens ? lens[b] : T;
+    float* x1 = x + ((size_t)b * 2 * h + h + c) * T;
+    const float* mr = m + (size_t)row * T;
+    for (int t = tstart; t < tend; t += 256) {
+        const float mk = t < len ? 1.f : 0.f;
+        x1[t] = reverse ? (x1[t] - mr[t]) * mk : mr[t] + x1[t] * mk;
+    }
+}
+
+// Flip: torch.flip(x, [1])                                   modules/flow/modules.py:314-321
+__global__ __launch_bounds__(256) void flip_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int T) {
+    AMP_ROW_LOOP(B * C, T)
+    const int b = row / C, c = row - b * C;
+    const float* xr = x + ((size_t)b * C + (C - 1 - c)) * T;
+    float* yr = y + (size_t)row * T;
+    for (int t = tstart; t < tend; t += 256) yr[t] = xr[t];
+}
+
+// z = (m + eps * exp(logs)) * mask,  stats = [m ; logs]       models/tts/vits/vits.py:150-151
+__global__ __launch_bounds__(256) void posterior_sample_kernel(const float* __restrict__ stats,
+                                                               const float* __restrict__ eps,
+                                                               const int* __restrict__ lens, float* __restrict__ z,
+                                                               int C, int T) {
+    AMP_ROW_LOOP(B * C, T)
+    const int b = row / C, c = row - b * C;
+    const int len = lens ? lens[b] : T;
+    const float* mr = stats + ((size_t)b * 2 * C + c) * T;
+    const float* lr = mr + (size_t)C * T;
+    const float* er = eps + (size_t)row * T;
+    float* zr = z + (size_t)row * T;
+    for (int t = tstart; t < tend; t += 256) zr[t] = (mr[t] + er[t] * expf(lr[t])) * (t < len ? 1.f : 0.f);
+}
+
+hipError_t launch_wn_gate(const float* a, const float* cond, long long cond_bs, float* out, int B, int H, int T,
+                          hipStream_t stream) {
+    hipLaunchKernelGGL(wn_gate_kernel, dim3(row_grid(B * H, T)), dim3(256), 0, stream, a, cond, cond_bs, out, H, T);
+    return hipGetLastError();
+}
+hipError_t launch_wn_accumulate(float* x, float* out, const float* rs, const int* lens, int B, int H, int T, int last,
+                                int first, hipStream_t stream) {
+    hipLaunchKernelGGL(wn_accumulate_kernel, dim3(row_grid(B * H, T)), dim3(256), 0, stream, x, out, rs, lens, H, T,
+                       last, first);
+    return hipGetLastError();
+}
+hipError_t launch_mask(float* x, const int* lens, int B, int C, int T, hipStream_t stream) {
+    hipLaunchKernelGGL(mask_kernel, dim3(row_grid(B * C, T)), dim3(256), 0, stream, x, lens, C, T);
+    return hipGetLastError();
+}
+hipError_t launch_coupling(float* x, const float* m, const int* lens, int B, int h, int T, int reverse,
+                           hipStream_t stream) {
+    hipLaunchKernelGGL(coupling_kernel, dim3(row_grid(B * h, T)), dim3(256), 0, stream, x, m, lens, h, T, reverse);
+    return hipGetLastError();
+}
+hipError_t launch_flip_channels(const float* x, float* y, int B, int C, int T, hipStream_t stream) {
+    hipLaunchKernelGGL(flip_kernel, dim3(row_grid(B * C, T)), dim3(256), 0, stream, x, y, C, T);
+    return hipGetLastError();
+}
+hipError_t launch_posterior_sample(const float* stats, const float* eps, const int* lens, float* z, int B, int C, int T,
+                                   hipStream_t stream) {
+    hipLaunchKernelGGL(posterior_sample_kernel, dim3(row_grid(B * C, T)), dim3(256), 0, stream, stats, eps, lens, z, C, T);
+    return hipGetLastError();
+}
+
 }  // namespace amp

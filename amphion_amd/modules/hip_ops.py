@@ -1,0 +1,117 @@
+"""Thin torch-tensor wrappers over the op-level C ABI (conv + VITS element-wise kernels)."""
+from __future__ import annotations
+
+import ctypes
+import weakref
+
+import torch
+
+from amphion_amd import _lib
+from amphion_amd.models.vocoders.gan.generator._engine import ConvParams
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _destroy_conv(ptr):
+    try:
+        _lib.lib().amp_conv_destroy(ctypes.c_void_p(ptr))
+    except Exception:
+        pass
+
+
+class HipConv1d(ConvParams):
+    """A Conv1d / ConvTranspose1d whose forward is the fused gfx950 implicit-GEMM kernel:
+    ``y = lrelu_out(conv(lrelu_in(x)) + bias + res)``.  Parameters keep torch's key names
+    (``weight``/``bias`` or ``weight_g``/``weight_v`` under weight-norm); the packed device copy is
+    rebuilt lazily when they change."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self._h = None
+        self._fin = None
+        self._sig = None
+
+    def _ensure(self, device):
+        sig = tuple((n, p.data_ptr(), p._version) for n, p in self.named_parameters()) + (str(device),)
+        if self._h is not None and sig == self._sig:
+            return self._h
+        if self._fin is not None:
+            self._fin()
+        w = self.folded_weight().detach().to("cpu", torch.float32).contiguous()
+        b = self.bias.detach().to("cpu", torch.float32).contiguous() if self.bias is not None else None
+        h = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(_lib.lib().amp_conv_create(int(self.transposed), self.cin, self.cout, self.k, self.stride,
+                                                  self.dilation, self.padding, _ptr(w), _ptr(b), ctypes.byref(h)))
+        self._h, self._fin, self._sig = h, weakref.finalize(self, _destroy_conv, h.value), sig
+        return h
+
+    def forward(self, x, *, slope_in=1.0, res=None, slope_out=1.0, out=None, x_batch_stride=None, T=None):
+        """x [B, cin, T] (or a channel slice of a wider tensor when ``x_batch_stride`` is given)."""
+        x = _lib.require_device_tensor(x, "conv input") if x_batch_stride is None else x
+        dev = x.device
+        B = x.shape[0]
+        T = x.shape[-1] if T is None else T
+        L = _lib.lib()
+        h = self._ensure(dev)
+        Tout = L.amp_conv_out_len(h, T)
+        if out is None:
+            out = torch.empty((B, self.cout, Tout), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            if x_batch_stride is None:
+                _lib.check(L.amp_conv_forward(h, _ptr(x), B, T, slope_in, _ptr(res), slope_out, _ptr(out),
+                                              _lib.current_stream_ptr(dev)))
+            else:
+                _lib.check(L.amp_conv_forward_strided(h, _ptr(x), int(x_batch_stride), B, T, slope_in, _ptr(res),
+                                                      slope_out, _ptr(out), _lib.current_stream_ptr(dev)))
+        return out
+
+
+def lens_tensor(lengths, device):
+    """int32 device tensor of valid lengths (sequence_mask argument), or None."""
+    if lengths is None:
+        return None
+    return torch.as_tensor(lengths).to(device=device, dtype=torch.int32).contiguous()
+
+
+def wn_gate(a, cond, out):
+    B, H2, T = a.shape
+    bs = cond.stride(0) if cond is not None else 0
+    _lib.check(_lib.lib().amp_wn_gate(_ptr(a), _ptr(cond), bs, _ptr(out), B, H2 // 2, T, _lib.current_stream_ptr(a.device)))
+    return out
+
+
+def wn_accumulate(x, out, rs, lens, first, last):
+    B, H, T = x.shape
+    _lib.check(_lib.lib().amp_wn_accumulate(_ptr(x), _ptr(out), _ptr(rs), _ptr(lens), B, H, T, int(first), int(last),
+                                            _lib.current_stream_ptr(x.device)))
+
+
+def sequence_mask_(x, lens):
+    B, C, T = x.shape
+    _lib.check(_lib.lib().amp_sequence_mask(_ptr(x), _ptr(lens), B, C, T, _lib.current_stream_ptr(x.device)))
+    return x
+
+
+def coupling_apply_(x, m, lens, reverse):
+    B, C, T = x.shape
+    _lib.check(_lib.lib().amp_coupling_apply(_ptr(x), _ptr(m), _ptr(lens), B, C // 2, T, int(reverse),
+                                             _lib.current_stream_ptr(x.device)))
+    return x
+
+
+def flip_channels(x):
+    B, C, T = x.shape
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().amp_flip_channels(_ptr(x), _ptr(y), B, C, T, _lib.current_stream_ptr(x.device)))
+    return y
+
+
+def posterior_sample(stats, eps, lens):
+    B, C2, T = stats.shape
+    z = torch.empty((B, C2 // 2, T), dtype=torch.float32, device=stats.device)
+    _lib.check(_lib.lib().amp_posterior_sample(_ptr(stats), _ptr(eps), _ptr(lens), _ptr(z), B, C2 // 2, T,
+                                               _lib.current_stream_ptr(stats.device)))
+    return z

@@ -127,7 +127,37 @@ int amp_conv_out_len(const amp_conv* c, int T);
  * res_dev may be NULL or alias y_dev (in-place residual).  x_dev [B, cin, T] -> y_dev [B, cout, T_out]. */
 int amp_conv_forward(const amp_conv* c, const float* x_dev, int B, int T, float slope_in, const float* res_dev,
                      float slope_out, float* y_dev, void* stream);
+/* Same, reading x from a channel slice of a wider tensor: batch item b starts at x_dev + b*x_batch_stride
+ * (elements).  Used by ResidualCouplingLayer.pre on x0 = x[:, :half] (modules/flow/modules.py:380-381). */
+int amp_conv_forward_strided(const amp_conv* c, const float* x_dev, long long x_batch_stride, int B, int T,
+                             float slope_in, const float* res_dev, float slope_out, float* y_dev, void* stream);
 void amp_conv_destroy(amp_conv* c);
+
+/* ---- VITS posterior encoder + flow (config 5): element-wise pieces between the convs ---- */
+
+/* fused_add_tanh_sigmoid_multiply (utils/util.py:602-609) as called by WN.forward
+ * (modules/flow/modules.py:141): out[b,c,t] = tanh(a[b,c,t] + g[b,c]) * sigmoid(a[b,c+H,t] + g[b,c+H]).
+ * a_dev [B, 2H, T]; cond_dev: this layer's slice of cond_layer(g) (time-constant), element (b, c) at
+ * cond_dev[b*cond_batch_stride + c], or NULL when g is None; out_dev [B, H, T]. */
+int amp_wn_gate(const float* a_dev, const float* cond_dev, long long cond_batch_stride, float* out_dev, int B, int H,
+                int T, void* stream);
+/* WN residual/skip update (modules/flow/modules.py:144-151): not last: x = (x + rs[:, :H]) * mask,
+ * out += rs[:, H:]; last: out += rs.  first != 0 starts `out` from zero (torch.zeros_like, :127).
+ * lens_dev: int32 [B] valid lengths (sequence_mask, utils/util.py:618-622) or NULL for no mask. */
+int amp_wn_accumulate(float* x_dev, float* out_dev, const float* rs_dev, const int32_t* lens_dev, int B, int H, int T,
+                      int first, int last, void* stream);
+/* x[b, :, t >= lens[b]] = 0   (`* x_mask`, vits.py:147,149; modules/flow/modules.py:152,381,383) */
+int amp_sequence_mask(float* x_dev, const int32_t* lens_dev, int B, int C, int T, void* stream);
+/* Mean-only ResidualCouplingLayer update on the second half of x [B, 2h, T] in place
+ * (modules/flow/modules.py:390-397): forward x1 = m + x1*mask; reverse x1 = (x1 - m)*mask. */
+int amp_coupling_apply(float* x_dev, const float* m_dev, const int32_t* lens_dev, int B, int half_channels, int T,
+                       int reverse, void* stream);
+/* Flip.forward: torch.flip(x, [1]) (modules/flow/modules.py:314-321); y must not alias x. */
+int amp_flip_channels(const float* x_dev, float* y_dev, int B, int C, int T, void* stream);
+/* PosteriorEncoder sampling (models/tts/vits/vits.py:150-151): stats = [m ; logs] [B, 2C, T],
+ * z = (m + eps * exp(logs)) * mask. */
+int amp_posterior_sample(const float* stats_dev, const float* eps_dev, const int32_t* lens_dev, float* z_dev, int B,
+                         int C, int T, void* stream);
 
 /* Activation1d(Snake|SnakeBeta) (modules/anti_aliasing/act.py:31-36; resample.py:36-45,62-65;
  * filter.py:92-99; snake.py:51-61,110-122), ratio 2, 12-tap filters.  alpha_dev/beta_dev: per-channel

@@ -124,3 +124,40 @@ def synth_mel(B, n_mel, T, seed=0):
     """Log-mel-like input: randn*2-5."""
     gen = torch.Generator().manual_seed(seed)
     return torch.randn(B, n_mel, T, generator=gen) * 2 - 5
+
+
+def _plain_conv(s, prefix, cout, cin, k):
+    s[prefix + ".weight"] = (cout, cin, k)
+    s[prefix + ".bias"] = (cout,)
+
+
+def wn_param_shapes(s, prefix, hidden, kernel_size, n_layers, gin_channels=0):
+    """WN.__init__ modules/flow/modules.py:74-124 (module registration order: in_layers,
+    res_skip_layers, then cond_layer)."""
+    for i in range(n_layers):
+        _wn_conv(s, f"{prefix}.in_layers.{i}", 2 * hidden, hidden, kernel_size)
+    for i in range(n_layers):
+        _wn_conv(s, f"{prefix}.res_skip_layers.{i}", 2 * hidden if i < n_layers - 1 else hidden, hidden, 1)
+    if gin_channels:
+        _wn_conv(s, f"{prefix}.cond_layer", 2 * hidden * n_layers, gin_channels, 1)
+    return s
+
+
+def posterior_encoder_param_shapes(in_ch=513, out_ch=192, hidden=192, n_layers=16, gin_channels=0):
+    """PosteriorEncoder.__init__ vits.py:116-143"""
+    s = OrderedDict()
+    _plain_conv(s, "pre", hidden, in_ch, 1)
+    wn_param_shapes(s, "enc", hidden, 5, n_layers, gin_channels)
+    _plain_conv(s, "proj", 2 * out_ch, hidden, 1)
+    return s
+
+
+def coupling_block_param_shapes(channels=192, hidden=192, n_layers=4, n_flows=4, gin_channels=0):
+    """ResidualCouplingBlock.__init__ vits.py:71-103 (Flip has no parameters; indices 0,2,4,6)."""
+    s = OrderedDict()
+    for f in range(n_flows):
+        p = f"flows.{2 * f}"
+        _plain_conv(s, f"{p}.pre", hidden, channels // 2, 1)
+        wn_param_shapes(s, f"{p}.enc", hidden, 5, n_layers, gin_channels)
+        _plain_conv(s, f"{p}.post", channels // 2, hidden, 1)
+    return s

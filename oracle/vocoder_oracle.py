@@ -430,3 +430,82 @@ def preprocess_22k():
 def preprocess_24k():
     """config/vocoder.json:34-40."""
     return SimpleNamespace(sample_rate=24000, n_fft=1024, win_size=1024, hop_size=256, n_mel=100, fmin=0, fmax=12000)
+
+
+# ----------------------------------------------------------------------------
+# VITS posterior encoder + flow (BASELINE.json config 5)
+# ----------------------------------------------------------------------------
+def _j(prefix, name):
+    return name if not prefix else f"{prefix}.{name}"
+
+
+def sequence_mask(lengths, max_length):
+    """utils/util.py:618-622"""
+    lengths = torch.as_tensor(lengths)
+    return torch.arange(max_length).unsqueeze(0) < lengths.unsqueeze(1)
+
+
+def wn_forward(sd, prefix, x, x_mask, n_layers, hidden, kernel_size, dilation_rate, dtype, g=None):
+    """WN.forward modules/flow/modules.py:126-151 (fused_add_tanh_sigmoid_multiply utils/util.py:602-609)."""
+    output = torch.zeros_like(x)
+    if g is not None:
+        wc, bc = conv_params(sd, _j(prefix, "cond_layer"), dtype)
+        g = F.conv1d(g, wc, bc)
+    for i in range(n_layers):
+        d = dilation_rate**i
+        w, b = conv_params(sd, _j(prefix, f"in_layers.{i}"), dtype)
+        x_in = F.conv1d(x, w, b, dilation=d, padding=int((kernel_size * d - d) / 2))
+        g_l = g[:, i * 2 * hidden:(i + 1) * 2 * hidden, :] if g is not None else torch.zeros_like(x_in)
+        in_act = x_in + g_l
+        acts = torch.tanh(in_act[:, :hidden]) * torch.sigmoid(in_act[:, hidden:])
+        w, b = conv_params(sd, _j(prefix, f"res_skip_layers.{i}"), dtype)
+        rs = F.conv1d(acts, w, b)
+        if i < n_layers - 1:
+            x = (x + rs[:, :hidden]) * x_mask
+            output = output + rs[:, hidden:]
+        else:
+            output = output + rs
+    return output * x_mask
+
+
+def posterior_encoder_forward(sd, prefix, y, y_lengths, noise, out_channels=192, hidden=192, n_layers=16, dtype=torch.float32, g=None):
+    """PosteriorEncoder.forward models/tts/vits/vits.py:145-152 with the Gaussian noise passed in."""
+    y = torch.as_tensor(y).to(dtype)
+    x_mask = sequence_mask(y_lengths, y.size(2)).unsqueeze(1).to(dtype)
+    w, b = conv_params(sd, _j(prefix, "pre"), dtype)
+    x = F.conv1d(y, w, b) * x_mask
+    x = wn_forward(sd, _j(prefix, "enc"), x, x_mask, n_layers, hidden, 5, 1, dtype, g=g)
+    w, b = conv_params(sd, _j(prefix, "proj"), dtype)
+    stats = F.conv1d(x, w, b) * x_mask
+    m, logs = torch.split(stats, out_channels, dim=1)
+    z = (m + torch.as_tensor(noise).to(dtype) * torch.exp(logs)) * x_mask
+    return z, m, logs, x_mask
+
+
+def coupling_block_forward(sd, prefix, x, x_mask, reverse=False, channels=192, hidden=192, n_flows=4, n_layers=4, dtype=torch.float32, g=None):
+    """ResidualCouplingBlock.forward vits.py:105-112 with mean-only ResidualCouplingLayer
+    (modules/flow/modules.py:379-397) and Flip (:314-321)."""
+    x = torch.as_tensor(x).to(dtype)
+    half = channels // 2
+
+    def layer(idx, x):
+        p = _j(prefix, f"flows.{idx}")
+        x0, x1 = torch.split(x, [half, half], 1)
+        w, b = conv_params(sd, f"{p}.pre", dtype)
+        h = F.conv1d(x0, w, b) * x_mask
+        h = wn_forward(sd, f"{p}.enc", h, x_mask, n_layers, hidden, 5, 1, dtype, g=g)
+        w, b = conv_params(sd, f"{p}.post", dtype)
+        m = F.conv1d(h, w, b) * x_mask
+        logs = torch.zeros_like(m)
+        if not reverse:
+            x1 = m + x1 * torch.exp(logs) * x_mask
+        else:
+            x1 = (x1 - m) * torch.exp(-logs) * x_mask
+        return torch.cat([x0, x1], 1)
+
+    order = list(range(2 * n_flows))
+    if reverse:
+        order = order[::-1]
+    for idx in order:
+        x = layer(idx, x) if idx % 2 == 0 else torch.flip(x, [1])
+    return x
