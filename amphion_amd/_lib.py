@@ -18,6 +18,8 @@ AMP_MAX_DILATIONS = 8
 
 AMP_ARCH_HIFIGAN, AMP_ARCH_BIGVGAN, AMP_ARCH_HIFIGAN_VITS = 0, 1, 2
 AMP_ACT_LRELU, AMP_ACT_SNAKE, AMP_ACT_SNAKEBETA = 0, 1, 2
+AMP_PRECISION_F32, AMP_PRECISION_F16X3 = 0, 1
+PRECISIONS = {"f32": AMP_PRECISION_F32, "fp32": AMP_PRECISION_F32, "f16x3": AMP_PRECISION_F16X3}
 
 
 class AmpError(RuntimeError):
@@ -63,6 +65,8 @@ _SIGNATURES = {
     "amp_version": (c_int, []),
     "amp_last_error": (c_char_p, []),
     "amp_device_count": (c_int, []),
+    "amp_set_precision": (c_int, [c_int]),
+    "amp_get_precision": (c_int, []),
     "amp_gen_create": (c_int, [POINTER(amp_gen_desc), POINTER(c_void_p)]),
     "amp_gen_set_weight": (c_int, [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int]),
     "amp_gen_finalize": (c_int, [c_void_p]),
@@ -109,6 +113,18 @@ def lib():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+def set_precision(name):
+    """Arithmetic of the conv contractions for handles created from now on: "f16x3" (default, split-f16
+    MFMA with fp32 accumulate) or "f32" (exact fp32 MFMA).  include/amphion_hip.h: amp_precision."""
+    if name not in PRECISIONS:
+        raise ValueError(f"precision must be one of {sorted(PRECISIONS)}, got {name!r}")
+    check(lib().amp_set_precision(PRECISIONS[name]))
+
+
+def get_precision():
+    return "f32" if lib().amp_get_precision() == AMP_PRECISION_F32 else "f16x3"
 
 
 def check(status):

@@ -30,6 +30,7 @@ def _units():
              ("mel.hip", "mel.o", [])]
     for kt in CONV_TAPS:
         units.append(("conv_mfma.hip", f"conv_mfma_kt{kt}.o", [f"-DAMP_KT={kt}"]))
+        units.append(("conv_f16x3.hip", f"conv_f16x3_kt{kt}.o", [f"-DAMP_KT={kt}"]))
     return units
 
 

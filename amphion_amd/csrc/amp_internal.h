@@ -10,7 +10,11 @@
 
 namespace amp {
 
-constexpr int KC = 8;  // input channels staged per K-chunk (2 per MFMA k-step, 4 k-steps per tap)
+constexpr int KC = 8;     // f32 kernel: input channels staged per K-chunk (2 per MFMA k-step, 4 k-steps per tap)
+constexpr int KC16 = 16;  // f16x3 kernel: input channels per K-chunk (one 32x32x16 MFMA k-extent per tap)
+
+// Arithmetic of the conv contraction (amp_set_precision / AMP_PRECISION).
+enum { PREC_F32 = 0, PREC_F16X3 = 1 };
 
 // Arguments of the implicit-GEMM conv kernel (conv_mfma.hip).
 //   Y'[m, q] = sum_i sum_j  W'[m, i, j] * act_in(X[i, q + off0 + j*dstep])          (zero outside [0, Tin))
@@ -19,7 +23,7 @@ constexpr int KC = 8;  // input channels staged per K-chunk (2 per MFMA k-step, 
 //                        the result is scattered to n = q*up + r - up_pad.
 struct ConvArgs {
     const float* x;      // [B, Cin, Tin]
-    const float* wp;     // packed A fragments, see pack_weights()
+    const void* wp;      // packed A fragments (f32, or f16 hi/lo planes for f16x3), see conv_build()
     const float* bias;   // [Cout] or nullptr
     const float* res;    // [B, Cout, Tout] or nullptr (may alias y)
     float* y;            // [B, Cout, Tout]
@@ -37,6 +41,7 @@ struct ConvArgs {
     float slope_in, slope_out;  // 1.0f = identity
     int mode;                   // 0: y = v   1: y = y + v   2: y = (y + v) / div
     float div;
+    float acc_scale, inv_scale; // f16x3 only: 16 * 2^s (operand scaling) and its reciprocal
 };
 
 struct ConvPlan {
@@ -51,7 +56,8 @@ struct ConvPlan {
 // Chooses the kernel variant for a conv with `ntaps` taps, GEMM rows M, halo_total columns and Tq
 // columns per item.  Returns false if unsupported.
 bool choose_plan(int ntaps, int M, int halo_total, int Tq, ConvPlan* plan);
-hipError_t launch_conv(const ConvPlan& plan, const ConvArgs& a, hipStream_t stream);
+hipError_t launch_conv(const ConvPlan& plan, const ConvArgs& a, hipStream_t stream);        // exact f32 MFMA
+hipError_t launch_conv_f16x3(const ConvPlan& plan, const ConvArgs& a, hipStream_t stream);  // split-f16 MFMA
 
 // conv_post: y[b,0,t] = tanh( bias + sum_i sum_j w[i][j] * act_in(x[b,i,t+j-pad]) )   (Cout == 1)
 hipError_t launch_conv_post(const float* x, const float* w_dev /*[Cin*K]*/, const float* bias_dev /*[1] or null*/,

@@ -1,0 +1,313 @@
+// Implicit-GEMM 1-D convolution on the gfx950 f16 matrix cores with SPLIT operands
+// (3 x v_mfma_f32_32x32x16_f16 per product term, f32 accumulate) -- "f16x3".
+//
+// Same contract as conv_mfma.hip (the exact-f32 kernel): replaces the reference's F.conv1d /
+// nn.ConvTranspose1d calls (hifigan.py:93-100,204,207,216; bigvgan.py:137-146,314-329) with the
+// leaky_relu / bias / residual / MRF-accumulate ops around them fused in.  What differs is the
+// arithmetic of the contraction: f32 MFMA runs at the f32 vector rate (157 TFLOP/s), f16 MFMA at 16x
+// that, so each f32 operand is split as  v = hi + lo  with hi = f16(v), lo = f16(v - hi)  (22 mantissa
+// bits together) and the product is formed as  Whi*Xhi + Whi*Xlo + Wlo*Xhi  in the f32 accumulator
+// (the dropped Wlo*Xlo term is 2^-22 relative).  End to end through HiFi-GAN V1 this is as close to an
+// fp64 run of the reference as the reference's own fp32 run is (tools/numerics_f16x3.py, tests).
+//
+//   scaling (all exact powers of two, undone in the epilogue): activations x16 while staging, so that
+//   `lo` of anything >= 2^-7 is a normal f16 and |x| up to 4094 is representable; weights by the
+//   per-conv 2^s that puts max|w| in [2^12, 2^13] (host, conv_build()).
+//
+//   GEMM view (per batch item):  Y'[M, Tq] = W'[M, K] * Xcol[K, Tq],   K = Cin * taps
+//   - A operand: packed on the host in MFMA fragment order as hi/lo f16 planes and streamed from L2
+//     into VGPRs: one 16-B load per lane = the 8 channels that lane group owns, for one tap.
+//   - B operand: a 16-channel chunk is staged global -> VGPR -> LDS once per chunk as
+//     [plane hi|lo][channel octet h][column][8 x f16]: a lane's B fragment for ANY tap is ONE
+//     ds_read_b128 at column + tap*dilation (16-B aligned, conflict-free: 16 consecutive lanes cover
+//     all 64 banks).  leaky_relu-on-load, zero padding and the f32 -> hi/lo split happen while staging.
+//
+// This file is compiled once per tap count:  -DAMP_KT=<1|2|3|5|7|11>.
+#include "amp_internal.h"
+
+#ifndef AMP_KT
+#error "compile with -DAMP_KT=<taps>"
+#endif
+
+namespace amp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+union Frag {
+    uint4 u;
+    f16x8 h;
+};
+
+// VMEM and MFMA may not cross (VALU, SALU, DS may): pins where the global loads are issued relative to
+// the MFMA blocks and their issue ORDER, on which the
+// counted s_waitcnt vmcnt(N) the compiler derives depends (loads return in order).
+#define AMP_PIN_VMEM() __builtin_amdgcn_sched_barrier(0x386)
+
+template <int KT, int WM, int WN, int NI, int HALO>
+__global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
+    constexpr int NT = 32 * NI * WN;           // output columns per workgroup
+    constexpr int S = NT + HALO;               // staged columns
+    constexpr int NST = (4 * S) / 256;         // staging items (column x channel quad) per thread
+    constexpr int BUF = 4 * S;                 // uint4 per LDS buffer: [plane hi|lo][octet h][S]
+    static_assert(S % 64 == 0, "the channel quad of a staging item must be wave-uniform");
+    extern __shared__ __attribute__((aligned(16))) uint4 smem4[];  // [2][BUF]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int item = blockIdx.x / a.tiles_per_item;
+    const int tile = blockIdx.x - item * a.tiles_per_item;
+    const int q0 = tile * NT;
+    const int mb = blockIdx.y * WM + wm;       // 32-row block of W'
+
+    // accumulators start from (bias + residual + running MRF sum) * acc_scale, see conv_mfma.hip
+    const int up = a.up;
+    const int qw = q0 + wn * (32 * NI) + l31;
+    const bool fast = (up == 1) && (mb * 32 + 32 <= a.M) && (q0 + wn * (32 * NI) + 32 * NI <= a.Tq);
+    const size_t wave_base = ((size_t)item * a.Cout + (size_t)mb * 32) * a.Tout;  // uniform
+    const int lane_off = (4 * hi) * a.Tout + qw;                                  // per lane
+    const float asc = a.acc_scale;
+    f32x16 acc[NI];
+    if (fast) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rowc = (r & 3) + 8 * (r >> 2);
+            const float bv = a.bias ? a.bias[mb * 32 + rowc + 4 * hi] : 0.f;
+#pragma unroll
+            for (int t = 0; t < NI; ++t) acc[t][r] = bv;
+        }
+        if (a.res) {
+            const float* rp = a.res + wave_base;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float* rr_ = rp + (size_t)((r & 3) + 8 * (r >> 2)) * a.Tout;
+#pragma unroll
+                for (int t = 0; t < NI; ++t) acc[t][r] += rr_[lane_off + 32 * t];
+            }
+        }
+        if (a.mode != 0) {
+            const float* yp = a.y + wave_base;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float* yr_ = yp + (size_t)((r & 3) + 8 * (r >> 2)) * a.Tout;
+#pragma unroll
+                for (int t = 0; t < NI; ++t) acc[t][r] += yr_[lane_off + 32 * t];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int m = mb * 32 + row;
+            const bool mok = m < a.M;
+            const int o = (up == 1) ? m : m / up;
+            const int rr = m - o * up;
+            const float bv = (mok && a.bias) ? a.bias[o] : 0.f;
+            const size_t rowoff = ((size_t)item * a.Cout + o) * a.Tout;
+#pragma unroll
+            for (int t = 0; t < NI; ++t) {
+                const int q = qw + 32 * t;
+                const int n = q * up + rr - a.up_pad;
+                float v = bv;
+                if (mok && q < a.Tq && n >= 0 && n < a.Tout) {
+                    if (a.res) v += a.res[rowoff + n];
+                    if (a.mode != 0) v += a.y[rowoff + n];
+                }
+                acc[t][r] = v;
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NI; ++t) acc[t] *= asc;
+
+    const float* xb = a.x + (size_t)item * (size_t)a.xbs;
+    const int tbase = q0 - a.halo_left;
+    const float kpos = 16.f, kneg = 16.f * a.slope_in;  // x16 and leaky_relu-on-load in one multiply
+
+    // Staging item = (column, channel quad): 4 global dword loads (lanes = consecutive columns, so
+    // every load instruction is one coalesced 256-B row segment) -> two 8-B LDS writes (hi, lo).
+    // Split in two so that the loads of chunk c+1 fly under the MFMAs of chunk c: stage_load issues
+    // UNCONDITIONAL loads from clamped addresses (a predicated load makes hipcc branch around it and
+    // lose its vmcnt bookkeeping), stage_store applies the zero padding as a select, then leaky_relu,
+    // the x16 scaling and the hi/lo split.  4*S is a multiple of 256 and S of 64: every thread has
+    // exactly NST items and an item's quad is wave-uniform.
+    float xs[NST][4];
+    auto stage_load = [&](int chunk) {
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int ibase = wave * 64 + 256 * it;          // wave-uniform
+            const int qd = ibase / S;                        // channel quad 0..3
+            const int col = ibase - qd * S + lane;
+            int t = tbase + col;
+            t = t < 0 ? 0 : t;
+            t = t > a.Tin - 1 ? a.Tin - 1 : t;
+            const int ch0 = chunk * KC16 + 4 * qd;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int ch = ch0 + e;
+                ch = ch > a.Cin - 1 ? a.Cin - 1 : ch;        // scalar clamp
+                xs[it][e] = xb[(size_t)ch * a.Tin + t];
+            }
+        }
+    };
+    auto stage_store = [&](int chunk, int buf) {
+        uint2* dst = reinterpret_cast<uint2*>(smem4 + buf * BUF);
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int ibase = wave * 64 + 256 * it;
+            const int qd = ibase / S;
+            const int col = ibase - qd * S + lane;
+            const int t = tbase + col;
+            const bool tok = (col < a.wd) && (t >= 0) && (t < a.Tin);
+            const int ch0 = chunk * KC16 + 4 * qd;
+            union { uint2 u; _Float16 h[4]; } fh, fl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = (tok && (ch0 + e) < a.Cin) ? xs[it][e] : 0.f;
+                v = v * (v > 0.f ? kpos : kneg);
+                const _Float16 h16 = (_Float16)v;
+                fh.h[e] = h16;
+                fl.h[e] = (_Float16)(v - (float)h16);
+            }
+            // uint2 index inside a plane: ((octet * S + col) * 2 + half)
+            const int o2 = (((qd >> 1) * S + col) << 1) + (qd & 1);
+            dst[o2] = fh.u;
+            dst[4 * S + o2] = fl.u;
+        }
+    };
+
+    // A fragments: [mb][chunk][tap][plane][lane] x uint4.  ONE register set for a whole chunk: tap g's
+    // pair is re-loaded for the NEXT chunk right after its last use, so during the MFMAs of a chunk every
+    // wait is for a load issued one chunk earlier -- older than the staging loads in flight (loads
+    // return in order: a wait for a younger load would drain them).  The reload after the last chunk
+    // reads the next mb block / the allocation pad (conv_build()).
+    const uint4* wa = static_cast<const uint4*>(a.wp) + (size_t)mb * a.nchunks * (KT * 128) + lane;
+    Frag a_h[KT], a_l[KT];
+
+    const int rd0 = hi * S + wn * (32 * NI) + l31 + a.halo_left + a.off0;
+    const int dstep = a.dstep;
+
+    stage_load(0);
+#pragma unroll
+    for (int g = 0; g < KT; ++g) {
+        a_h[g].u = wa[g * 128];
+        a_l[g].u = wa[g * 128 + 64];
+    }
+    AMP_PIN_VMEM();
+    stage_store(0, 0);
+    __syncthreads();
+
+    const int nchunks = a.nchunks;
+    for (int c = 0; c < nchunks; ++c) {
+        const bool more = (c + 1) < nchunks;
+        stage_load(more ? c + 1 : c);  // unconditional (a branch around loads would blur the vmcnt counts)
+        AMP_PIN_VMEM();
+        wa += KT * 128;
+        const uint4* base = smem4 + (c & 1) * BUF + rd0;
+#pragma unroll
+        for (int g = 0; g < KT; ++g) {
+            const uint4* bg = base + g * dstep;
+            Frag bh[NI], bl[NI];
+#pragma unroll
+            for (int t = 0; t < NI; ++t) {
+                bh[t].u = bg[32 * t];
+                bl[t].u = bg[2 * S + 32 * t];
+            }
+#pragma unroll
+            for (int t = 0; t < NI; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[g].h, bh[t].h, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NI; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[g].h, bl[t].h, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NI; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l[g].h, bh[t].h, acc[t], 0, 0, 0);
+            a_h[g].u = wa[g * 128];
+            a_l[g].u = wa[g * 128 + 64];
+            AMP_PIN_VMEM();
+        }
+        if (more) stage_store(c + 1, (c + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: undo the operand scaling, MRF mean, activation-on-store, (polyphase) scatter ----
+    const float slope_out = a.slope_out;
+    const bool exact_div = a.mode == 2;  // x = xs / num_kernels is a true division (hifigan.py:214)
+    if (fast) {
+        float* yp = a.y + wave_base;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float* yr_ = yp + (size_t)((r & 3) + 8 * (r >> 2)) * a.Tout;
+#pragma unroll
+            for (int t = 0; t < NI; ++t) {
+                float v = acc[t][r] * a.inv_scale;
+                if (exact_div) v = v / a.div;
+                v = v > 0.f ? v : v * slope_out;
+                yr_[lane_off + 32 * t] = v;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int m = mb * 32 + row;
+            if (m < a.M) {
+                const int o = (up == 1) ? m : m / up;
+                const int rr = m - o * up;
+                const size_t rowoff = ((size_t)item * a.Cout + o) * a.Tout;
+#pragma unroll
+                for (int t = 0; t < NI; ++t) {
+                    const int q = qw + 32 * t;
+                    const int n = q * up + rr - a.up_pad;
+                    if (q < a.Tq && n >= 0 && n < a.Tout) {
+                        float v = acc[t][r] * a.inv_scale;
+                        if (exact_div) v = v / a.div;
+                        v = v > 0.f ? v : v * slope_out;
+                        a.y[rowoff + n] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int KT, int WM, int WN, int NI, int HALO>
+static hipError_t launch_one_h(const ConvArgs& a, hipStream_t stream) {
+    constexpr int NT = 32 * NI * WN;
+    constexpr int S = NT + HALO;
+    const size_t lds = (size_t)2 * 4 * S * sizeof(uint4);
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16x3_kernel<KT, WM, WN, NI, HALO>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(a.B * a.tiles_per_item), (unsigned)((a.M + 32 * WM - 1) / (32 * WM)));
+    hipLaunchKernelGGL((conv_f16x3_kernel<KT, WM, WN, NI, HALO>), grid, dim3(256), lds, stream, a);
+    return hipGetLastError();
+}
+
+#define AMP_CAT2(a, b) a##b
+#define AMP_CAT(a, b) AMP_CAT2(a, b)
+
+hipError_t AMP_CAT(launch_conv_h_kt, AMP_KT)(const ConvPlan& p, const ConvArgs& a, hipStream_t stream) {
+    constexpr int KT = AMP_KT;
+    // every variant keeps 4 accumulator tiles (64 VGPRs) per wave: the register budget goes to the
+    // per-chunk A-fragment set (8 * KT VGPRs) instead, see the kernel
+    if (p.HALO == 64) {
+        if (p.WM == 4) return launch_one_h<KT, 4, 1, 4, 64>(a, stream);
+        if (p.WM == 2) return launch_one_h<KT, 2, 2, 4, 64>(a, stream);
+        return launch_one_h<KT, 1, 4, 4, 64>(a, stream);
+    } else {
+        if (p.WM == 4) return launch_one_h<KT, 4, 1, 4, 128>(a, stream);
+        if (p.WM == 2) return launch_one_h<KT, 2, 2, 4, 128>(a, stream);
+        return launch_one_h<KT, 1, 4, 4, 128>(a, stream);
+    }
+}
+
+}  // namespace amp

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         }
     };
 
-    const float4* wa = reinterpret_cast<const float4*>(a.wp) + (size_t)mb * a.nchunks * (KT * 64) + lane;
+    const float4* wa = static_cast<const float4*>(a.wp) + (size_t)mb * a.nchunks * (KT * 64) + lane;
     // One register set for the A fragments: a tap's float4 is re-loaded for the NEXT chunk right
     // after its last use, so the L2 latency hides under the remaining KT-1 taps of MFMAs.
     float4 a_cur[KT];

@@ -3,6 +3,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -45,7 +46,24 @@ hipError_t launch_conv_kt5(const ConvPlan&, const ConvArgs&, hipStream_t);
 hipError_t launch_conv_kt7(const ConvPlan&, const ConvArgs&, hipStream_t);
 hipError_t launch_conv_kt11(const ConvPlan&, const ConvArgs&, hipStream_t);
 
+hipError_t launch_conv_h_kt1(const ConvPlan&, const ConvArgs&, hipStream_t);
+hipError_t launch_conv_h_kt2(const ConvPlan&, const ConvArgs&, hipStream_t);
+hipError_t launch_conv_h_kt3(const ConvPlan&, const ConvArgs&, hipStream_t);
+hipError_t launch_conv_h_kt5(const ConvPlan&, const ConvArgs&, hipStream_t);
+hipError_t launch_conv_h_kt7(const ConvPlan&, const ConvArgs&, hipStream_t);
+hipError_t launch_conv_h_kt11(const ConvPlan&, const ConvArgs&, hipStream_t);
+
 static const int kSupportedKT[] = {1, 2, 3, 5, 7, 11};
+
+// Process-wide default for handles created from now on: AMP_PRECISION=f32|f16x3, amp_set_precision().
+static int g_precision = -1;
+static int default_precision() {
+    if (g_precision < 0) {
+        const char* e = getenv("AMP_PRECISION");
+        g_precision = (e && (!strcmp(e, "f32") || !strcmp(e, "fp32"))) ? PREC_F32 : PREC_F16X3;
+    }
+    return g_precision;
+}
 
 static int round_up_taps(int ntaps) {
     for (int kt : kSupportedKT)
@@ -77,6 +95,18 @@ hipError_t launch_conv(const ConvPlan& p, const ConvArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
+hipError_t launch_conv_f16x3(const ConvPlan& p, const ConvArgs& a, hipStream_t s) {
+    switch (p.KT) {
+        case 1: return launch_conv_h_kt1(p, a, s);
+        case 2: return launch_conv_h_kt2(p, a, s);
+        case 3: return launch_conv_h_kt3(p, a, s);
+        case 5: return launch_conv_h_kt5(p, a, s);
+        case 7: return launch_conv_h_kt7(p, a, s);
+        case 11: return launch_conv_h_kt11(p, a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
 }  // namespace amp
 
 using namespace amp;
@@ -89,8 +119,10 @@ struct amp_conv {
     // GEMM view
     int M = 0, ntaps = 0, KT = 0, off0 = 0, dstep = 0, halo_left = 0, halo_right = 0, up = 1, up_pad = 0;
     int nchunks = 0;
+    int precision = PREC_F32;  // arithmetic of the contraction, fixed at build time
+    float wscale = 1.f;        // f16x3: power of two applied to the packed weights
     ConvPlan plan{};
-    float* wp_dev = nullptr;
+    void* wp_dev = nullptr;
     float* bias_dev = nullptr;
     // folded weights kept on the host for the Cout==1 path (conv_post)
     ~amp_conv() {
@@ -130,35 +162,63 @@ static int conv_build(amp_conv* c, const float* w, const float* bias) {
         set_error("amp_conv: receptive field (k=%d, dilation=%d) exceeds the 128-column staged halo", c->k, c->dilation);
         return AMP_ERR_UNSUPPORTED;
     }
-    c->nchunks = (c->cin + KC - 1) / KC;
-    // ---- pack W' into MFMA A-fragment order: [mb][chunk][tap][lane][p] ----
+    c->precision = default_precision();
+    if (c->precision == PREC_F16X3) c->plan.NI = 4;  // conv_f16x3.hip keeps 4 accumulator tiles per wave
     const int Mg = c->plan.Mgroup();
     const int Mpad = ((c->M + Mg - 1) / Mg) * Mg;
     const int nmb = Mpad / 32;
-    const size_t n = (size_t)nmb * c->nchunks * c->KT * 64 * 4;
-    std::vector<float> wp(n, 0.f);
     const int cin = c->cin, cout = c->cout, k = c->k, up = c->up;
-    for (int mb = 0; mb < nmb; ++mb)
-        for (int ch = 0; ch < c->nchunks; ++ch)
-            for (int g = 0; g < c->KT; ++g)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int p = 0; p < 4; ++p) {
-                        const int m = mb * 32 + (lane & 31);
-                        const int i = ch * KC + 2 * p + (lane >> 5);
-                        float v = 0.f;
-                        if (m < c->M && i < cin && g < c->ntaps) {
-                            if (!c->transposed) {
-                                v = w[((size_t)m * cin + i) * k + g];
-                            } else {
-                                const int o = m / up, r = m - o * up;
-                                const int j = r + g * up;
-                                if (j < k) v = w[((size_t)i * cout + o) * k + j];
-                            }
+    // W'[m, i, g]: the GEMM-view weight (polyphase rows for a transposed conv), 0 outside
+    auto wview = [&](int m, int i, int g) -> float {
+        if (m >= c->M || i >= cin || g >= c->ntaps) return 0.f;
+        if (!c->transposed) return w[((size_t)m * cin + i) * k + g];
+        const int o = m / up, r = m - o * up;
+        const int j = r + g * up;
+        return j < k ? w[((size_t)i * cout + o) * k + j] : 0.f;
+    };
+    if (c->precision == PREC_F32) {
+        // ---- f32 MFMA A-fragment order: [mb][chunk8][tap][lane][p] ----
+        c->nchunks = (c->cin + KC - 1) / KC;
+        const size_t n = (size_t)nmb * c->nchunks * c->KT * 64 * 4;
+        std::vector<float> wp(n, 0.f);
+        for (int mb = 0; mb < nmb; ++mb)
+            for (int ch = 0; ch < c->nchunks; ++ch)
+                for (int g = 0; g < c->KT; ++g)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int p = 0; p < 4; ++p)
+                            wp[((((size_t)mb * c->nchunks + ch) * c->KT + g) * 64 + lane) * 4 + p] =
+                                wview(mb * 32 + (lane & 31), ch * KC + 2 * p + (lane >> 5), g);
+        AMP_HIP(hipMalloc(&c->wp_dev, n * sizeof(float)));
+        AMP_HIP(hipMemcpy(c->wp_dev, wp.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    } else {
+        // ---- f16x3: [mb][chunk16][tap][plane hi|lo][lane][8 x f16], weights scaled by 2^s so that
+        //      max|w| lands in (2^12, 2^13]: lo = f16(w*2^s - hi) is then a normal f16 for every weight
+        //      above 2^-16 of the largest, and hi stays far from the f16 overflow (conv_f16x3.hip) ----
+        c->nchunks = (c->cin + KC16 - 1) / KC16;
+        float wmax = 0.f;
+        const size_t nw = (size_t)cin * cout * k;
+        for (size_t i = 0; i < nw; ++i) wmax = fmaxf(wmax, fabsf(w[i]));
+        if (!(wmax < 1e30f)) { set_error("amp_conv: non-finite weight"); return AMP_ERR_INVALID; }
+        int e2 = 0;
+        if (wmax > 0.f) { (void)frexpf(wmax, &e2); if (ldexpf(1.f, e2 - 1) == wmax) e2 -= 1; }  // wmax <= 2^e2
+        c->wscale = wmax > 0.f ? ldexpf(1.f, 13 - e2) : 1.f;
+        const size_t n16 = ((size_t)nmb * c->nchunks + 1) * c->KT * 2 * 64 * 8;  // +1 chunk: the kernel's A reload runs one chunk ahead
+        std::vector<_Float16> wp(n16, (_Float16)0.f);
+        for (int mb = 0; mb < nmb; ++mb)
+            for (int ch = 0; ch < c->nchunks; ++ch)
+                for (int g = 0; g < c->KT; ++g)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const float v = wview(mb * 32 + (lane & 31), ch * KC16 + 8 * (lane >> 5) + e, g) * c->wscale;
+                            const _Float16 h = (_Float16)v;
+                            const _Float16 l = (_Float16)(v - (float)h);
+                            const size_t ent = (((size_t)mb * c->nchunks + ch) * c->KT + g) * 2;
+                            wp[((ent + 0) * 64 + lane) * 8 + e] = h;
+                            wp[((ent + 1) * 64 + lane) * 8 + e] = l;
                         }
-                        wp[((((size_t)mb * c->nchunks + ch) * c->KT + g) * 64 + lane) * 4 + p] = v;
-                    }
-    AMP_HIP(hipMalloc((void**)&c->wp_dev, n * sizeof(float)));
-    AMP_HIP(hipMemcpy(c->wp_dev, wp.data(), n * sizeof(float), hipMemcpyHostToDevice));
+        AMP_HIP(hipMalloc(&c->wp_dev, n16 * sizeof(_Float16)));
+        AMP_HIP(hipMemcpy(c->wp_dev, wp.data(), n16 * sizeof(_Float16), hipMemcpyHostToDevice));
+    }
     if (bias) {
         AMP_HIP(hipMalloc((void**)&c->bias_dev, (size_t)cout * sizeof(float)));
         AMP_HIP(hipMemcpy(c->bias_dev, bias, (size_t)cout * sizeof(float), hipMemcpyHostToDevice));
@@ -187,7 +247,14 @@ static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope
     a.wd = NT + c->halo_left + c->halo_right;
     a.Cout = c->cout; a.Tout = Tout; a.up = c->up; a.up_pad = c->up_pad;
     a.slope_in = slope_in; a.slope_out = slope_out; a.mode = mode; a.div = div;
-    AMP_HIP(launch_conv(c->plan, a, stream));
+    if (c->precision == PREC_F32) {
+        a.acc_scale = a.inv_scale = 1.f;
+        AMP_HIP(launch_conv(c->plan, a, stream));
+    } else {
+        a.acc_scale = 16.f * c->wscale;
+        a.inv_scale = 1.f / a.acc_scale;
+        AMP_HIP(launch_conv_f16x3(c->plan, a, stream));
+    }
     return AMP_OK;
 }
 
@@ -268,6 +335,17 @@ extern "C" {
 
 int amp_version(void) { return 100; }
 const char* amp_last_error(void) { return g_err; }
+
+int amp_set_precision(int precision) {
+    if (precision != AMP_PRECISION_F32 && precision != AMP_PRECISION_F16X3) {
+        set_error("amp_set_precision: unknown precision %d", precision);
+        return AMP_ERR_INVALID;
+    }
+    g_precision = precision;
+    return AMP_OK;
+}
+
+int amp_get_precision(void) { return default_precision(); }
 
 int amp_device_count(void) {
     int n = 0;
@@ -541,6 +619,8 @@ int amp_gen_last_timing_ms(amp_gen* g, int which, float* ms_out) {
             tot += ms;
         }
         *ms_out = tot;
+    } else if (which >= 2 && which < 2 + g->d.n_stages) {
+        AMP_HIP(hipEventElapsedTime(ms_out, g->ev_mrf[2 * (which - 2)], g->ev_mrf[2 * (which - 2) + 1]));
     } else {
         set_error("amp_gen_last_timing_ms: which=%d", which);
         return AMP_ERR_INVALID;

@@ -29,7 +29,14 @@ FLOP_PER_SAMPLE_ALL = 2_398_848
 FLOP_PER_SAMPLE_MRF = 2_322_432      # the 72 ResBlock convs (96.8 %)
 BYTES_PER_SAMPLE_MRF = 14_976        # layer-wise minimum fp32 HBM traffic of those convs
 PEAK_FP32_TFLOPS = 157.3             # MI355X_MICROARCH.md: fp32 MFMA == fp32 vector peak
+PEAK_F16_TFLOPS = 2516.6             # dense f16 MFMA (256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz)
 PEAK_HBM_GBS = 8000.0
+# arithmetic of the conv contractions -> (dtype string, peak for ALGORITHMIC flops, note)
+PRECISIONS = {
+    "f16x3": ("f32 (split-f16 MFMA: 3 x v_mfma_f32_32x32x16_f16 per term, f32 accumulate)", PEAK_F16_TFLOPS / 3.0,
+              "dense f16 MFMA peak / 3 MFMAs per algorithmic product term"),
+    "f32": ("f32", PEAK_FP32_TFLOPS, "fp32 MFMA (= fp32 vector) peak"),
+}
 
 
 def build_model(device):
@@ -85,6 +92,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=sorted(PRECISIONS), default="f16x3",
+                    help="arithmetic of the conv contractions (include/amphion_hip.h: amp_precision)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -100,8 +109,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
 
+    from amphion_amd import _lib
     from amphion_amd.distributed import gather_audio
     from oracle import synth
+
+    _lib.set_precision(args.precision)
+    dtype_str, peak_tflops, peak_note = PRECISIONS[args.precision]
 
     model, sd, hp = build_model(device)
     mel = synth.synth_mel(B_PER_GPU, N_MEL, T_FRAMES, seed=rank).to(device)  # resident in HBM before timing
@@ -137,11 +150,12 @@ def main():
     model.set_profiling(True)
     step()
     torch.cuda.synchronize()
-    fwd_ms, mrf_ms = [], []
+    fwd_ms, mrf_ms, stage_ms = [], [], []
     for _ in range(max(3, min(args.steps, 10))):
         step()
         fwd_ms.append(model.last_timing_ms(0))
         mrf_ms.append(model.last_timing_ms(1))
+        stage_ms.append([model.last_timing_ms(2 + i) for i in range(len(hp["upsample_rates"]))])
     model.set_profiling(False)
 
     if rank == 0:
@@ -165,26 +179,29 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": dtype_str,
             "data": "synthetic",
             "config": {
                 "workload": f"HiFi-GAN V1 22.05 kHz, batch={B_PER_GPU}/GPU synthetic {N_MEL}-ch x {T_FRAMES}-frame mels "
-                            f"(BASELINE.json configs[1]), random-init weights, fp32",
+                            f"(BASELINE.json configs[1]), random-init weights, fp32 in/out, conv arithmetic {args.precision}",
                 "global_batch": total_items,
                 "frames": T_FRAMES,
                 "samples_per_step": samples_per_step,
                 "parallelism": f"batch-sharded x{world}, result gather on rank 0" if world > 1 else "single GPU",
             },
             "roofline": {
-                "kernel": "MRF conv stack (72 fused dilated Conv1d, conv_mfma_kernel)",
+                "kernel": "MRF conv stack (72 fused dilated Conv1d, "
+                          + ("conv_f16x3_kernel" if args.precision == "f16x3" else "conv_mfma_kernel") + ")",
                 "bound": "mfma",
                 "achieved": mrf_tflops,
-                "peak": PEAK_FP32_TFLOPS,
+                "peak": peak_tflops,
+                "peak_note": peak_note,
                 "unit": "TFLOP/s",
-                "frac": mrf_tflops / PEAK_FP32_TFLOPS,
+                "frac": mrf_tflops / peak_tflops,
                 "traffic": None,
                 "hbm_term": {"achieved": mrf_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": mrf_gbs / PEAK_HBM_GBS},
                 "mrf_ms": mrf_s * 1e3,
+                "mrf_ms_per_stage": [sum(v[i] for v in stage_ms) / len(stage_ms) for i in range(len(stage_ms[0]))],
                 "forward_ms": fwd_s * 1e3,
                 "whole_forward_tflops": FLOP_PER_SAMPLE_ALL * n_local / fwd_s / 1e12,
             },

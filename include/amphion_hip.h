@@ -48,6 +48,15 @@ typedef enum amp_activation {
     AMP_ACT_SNAKEBETA = 2  /* Activation1d(SnakeBeta)         bigvgan.py:104-124, snake.py:110-122 */
 } amp_activation;
 
+/* Arithmetic of the conv contractions (every Conv1d / ConvTranspose1d of the path; the reference runs
+ * them as fp32 torch ops).  Inputs, outputs, accumulators and everything stored in HBM are fp32 in both
+ * modes; results of both modes meet the same 1e-4 max-abs parity bound against the fp32 reference. */
+typedef enum amp_precision {
+    AMP_PRECISION_F32 = 0,   /* v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 fmaf chain (157 TFLOP/s peak)       */
+    AMP_PRECISION_F16X3 = 1  /* operands split hi+lo in f16 (22 mantissa bits), 3 x v_mfma_f32_32x32x16_f16 per
+                                term, fp32 accumulate (838 TFLOP/s effective peak) -- the default                */
+} amp_precision;
+
 #define AMP_MAX_STAGES 8
 #define AMP_MAX_KERNELS 8
 #define AMP_MAX_DILATIONS 8
@@ -79,6 +88,12 @@ const char* amp_last_error(void);
 /* Number of HIP devices visible (0 when there is no GPU); never fails. */
 int amp_device_count(void);
 
+/* Process-wide default for handles created AFTER the call (also settable with the environment variable
+ * AMP_PRECISION=f32|f16x3 before the first handle is created).  A handle keeps the precision it was
+ * built with. */
+int amp_set_precision(int precision /* amp_precision */);
+int amp_get_precision(void);
+
 /* ---- Generator handle: replaces nn.Module construction + forward of HiFiGAN / BigVGAN / HiFiGAN_vits ---- */
 
 /* Replaces HiFiGAN.__init__ (hifigan.py:151-201) / BigVGAN.__init__ (bigvgan.py:232-311) /
@@ -107,7 +122,8 @@ int amp_gen_forward(amp_gen* g, const float* mel_dev, const float* cond_dev, int
 
 /* Duration [ms] of the kernels of the LAST amp_gen_forward on this handle, measured with HIP events
  * recorded on the launch stream when profiling is on.  which: 0 = whole forward, 1 = MRF conv stack
- * (all ResBlock/AMPBlock convs).  Synchronises on the events.  Returns <0 on error. */
+ * (all ResBlock/AMPBlock convs), 2 + i = the MRF convs of upsampling stage i.  Synchronises on the events.
+ * Returns <0 on error. */
 int amp_gen_set_profiling(amp_gen* g, int enabled);
 int amp_gen_last_timing_ms(amp_gen* g, int which, float* ms_out);
 

@@ -17,3 +17,14 @@ def golden():
     import numpy as np
 
     return np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
+
+
+@pytest.fixture(params=["f16x3", "f32"])
+def conv_precision(request):
+    """Runs a GPU test once per arithmetic of the conv contractions (include/amphion_hip.h: amp_precision);
+    both must meet the same parity bounds.  Handles pick the mode up when they are created."""
+    from amphion_amd import _lib
+
+    _lib.set_precision(request.param)
+    yield request.param
+    _lib.set_precision("f16x3")

@@ -8,7 +8,7 @@ import torch
 from oracle import synth
 from oracle import vocoder_oracle as vo
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("conv_precision")]
 
 
 def test_activation1d_golden(golden):

@@ -3,7 +3,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("conv_precision")]
 
 
 def _rand(*shape, seed=0, scale=1.0):
@@ -82,6 +82,23 @@ def test_conv_transpose1d_matches_oracle(cin, cout, k, u, B, T):
     y = conv_forward(w, b, x, transposed=True, stride=u, padding=pad, slope_in=0.1)
     assert y.shape == ref.shape
     assert (y - ref).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("xscale,wscale", [(1e-3, 1.0), (300.0, 1.0), (1.0, 1e-4), (1.0, 50.0), (1e-2, 1e3)])
+def test_conv1d_operand_range(xscale, wscale):
+    """The split-f16 path rescales operands by powers of two; results must stay at fp32 level for
+    activations / weights far from O(1) (relative to the output scale)."""
+    from hip_helpers import conv_forward
+
+    cin, cout, k, d, B, T = 64, 64, 7, 3, 1, 300
+    w = _rand(cout, cin, k, seed=1, scale=wscale * (cin * k) ** -0.5)
+    b = _rand(cout, seed=2, scale=0.1 * xscale * wscale)
+    x = _rand(B, cin, T, seed=3, scale=xscale)
+    pad = (k * d - d) // 2
+    ref = F.conv1d(x.double(), w.double(), b.double(), dilation=d, padding=pad)
+    y = conv_forward(w, b, x, dilation=d, padding=pad)
+    rel = (y.double() - ref).abs().max().item() / ref.abs().max().item()
+    assert rel <= 5e-6, rel
 
 
 def test_unsupported_receptive_field_is_an_error():

@@ -10,7 +10,7 @@ import torch
 from oracle import synth
 from oracle import vocoder_oracle as vo
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("conv_precision")]
 TOL = 1e-4
 
 

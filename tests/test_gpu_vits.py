@@ -9,7 +9,7 @@ import torch
 from oracle import synth
 from oracle import vocoder_oracle as vo
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("conv_precision")]
 HERE = os.path.dirname(os.path.abspath(__file__))
 TOL = 1e-4
 

@@ -6,7 +6,9 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 python -c "import torch; print(torch.cuda.get_device_name(0))" > $OUT/device.txt 2>&1
-( timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 ) > $OUT/pytest_gpu.txt
+( timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -40 ) > $OUT/pytest_gpu.txt
+( timeout 600 python tools/conv_bench.py > $OUT/conv_bench.csv 2> $OUT/conv_bench.err )
+( timeout 300 python bench.py --steps 10 --warmup 3 --precision f32 --no-cpu-baseline 2> $OUT/bench_f32.err | tail -1 ) > $OUT/bench_f32.json
 ( timeout 600 python bench.py --steps 10 --warmup 3 2> $OUT/bench.err | tail -1 ) > $OUT/bench.json
 REPO=$PWD
 ( cd /tmp && timeout 600 rocprofv3 --output-format csv --kernel-trace --stats -d $REPO/$OUT/prof -o kt -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $REPO/$OUT/prof_bench.json 2> $REPO/$OUT/prof.err )
@@ -15,5 +17,6 @@ REPO=$PWD
 # keep only the small summaries
 find $OUT -name '*.db' -delete 2>/dev/null
 du -sh $OUT
-cat $OUT/pytest_gpu.txt | tail -5
+tail -12 $OUT/pytest_gpu.txt
+cat $OUT/conv_bench.csv; tail -3 $OUT/conv_bench.err
 cat $OUT/bench.json
