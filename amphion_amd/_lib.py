@@ -72,6 +72,7 @@ _SIGNATURES = {
     "amp_gen_finalize": (c_int, [c_void_p]),
     "amp_gen_hop": (c_int, [c_void_p]),
     "amp_gen_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "amp_set_group_mb": (c_int, [c_int]),
     "amp_gen_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "amp_gen_set_profiling": (c_int, [c_void_p, c_int]),
     "amp_gen_last_timing_ms": (c_int, [c_void_p, c_int, POINTER(c_float)]),
@@ -80,6 +81,7 @@ _SIGNATURES = {
     "amp_conv_out_len": (c_int, [c_void_p, c_int]),
     "amp_conv_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_float, c_void_p, c_void_p]),
     "amp_conv_forward_strided": (c_int, [c_void_p, c_void_p, ctypes.c_longlong, c_int, c_int, c_float, c_void_p, c_float, c_void_p, c_void_p]),
+    "amp_pair_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
     "amp_conv_destroy": (None, [c_void_p]),
     "amp_wn_gate": (c_int, [c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_int, c_int, c_int, c_void_p]),
     "amp_wn_accumulate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),

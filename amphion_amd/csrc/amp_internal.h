@@ -44,6 +44,24 @@ struct ConvArgs {
     float acc_scale, inv_scale; // f16x3 only: 16 * 2^s (operand scaling) and its reciprocal
 };
 
+// Arguments of the fused ResBlock-pair kernel (pair_f16x3.hip):
+//   y = x + c2(lrelu(c1(lrelu(x))))   [mode 1: y += ..., mode 2: y = (y + ...) / div]
+struct PairArgs {
+    const float* x;            // [B, C, T] input and residual
+    float* y;                  // [B, C, T] output; must NOT alias x (other tiles read x's halo)
+    const void* wp1;           // conv1 (kernel k, dilation dil): packed f16x3 A fragments
+    const float* bias1;
+    const void* wp2;           // conv2 (kernel k, dilation 1)
+    const float* bias2;
+    int B, C, T;
+    int tiles_per_item;        // ceil(T / NT)
+    int dil;
+    float slope;               // leaky_relu slope (on x while staging, on conv1's output at the seam)
+    float sc1, isc1, sc2, isc2;  // 16 * 2^s operand scaling of each conv and its reciprocal
+    int mode;
+    float div;
+};
+
 struct ConvPlan {
     int KT;      // taps compiled into the kernel (1,2,3,5,7,11)
     int WM, WN;  // waves along M / N (WM*WN == 4)
@@ -58,6 +76,9 @@ struct ConvPlan {
 bool choose_plan(int ntaps, int M, int halo_total, int Tq, ConvPlan* plan);
 hipError_t launch_conv(const ConvPlan& plan, const ConvArgs& a, hipStream_t stream);        // exact f32 MFMA
 hipError_t launch_conv_f16x3(const ConvPlan& plan, const ConvArgs& a, hipStream_t stream);  // split-f16 MFMA
+// fused pair: output columns per workgroup for (C, k, dilation), 0 = not covered; launch
+int pair_tile(int k, int C, int dil);
+hipError_t launch_pair(int k, const PairArgs& a, hipStream_t stream);
 
 // conv_post: y[b,0,t] = tanh( bias + sum_i sum_j w[i][j] * act_in(x[b,i,t+j-pad]) )   (Cout == 1)
 hipError_t launch_conv_post(const float* x, const float* w_dev /*[Cin*K]*/, const float* bias_dev /*[1] or null*/,
@@ -88,5 +109,16 @@ hipError_t launch_mel(const amp_mel_desc& d, const float* wav, int B, int L, int
                       const float* melbasis, float* mel, float* mag, float* re, float* im, hipStream_t stream);
 
 void set_error(const char* fmt, ...);
+
+// v = hi + lo with hi = f16(v), lo = f16(v - hi): the split-f16 operand form of the f16x3 kernels.
+// The empty asm makes `v` opaque: under HIP's default -ffp-contract=fast hipcc otherwise folds the
+// multiply that produced v into the conversions (v_fma_mix*: f16(x*k) rounded ONCE from the exact
+// product) for `lo` but not for the stored `hi` (v_cvt_pk_f16_f32 of the fp32-rounded product): in the
+// rare double-rounding cases the two disagree by one f16 ulp and the pair (hi, lo) is off by 2^-11.
+__device__ __forceinline__ void split_f16(float v, _Float16& h, _Float16& l) {
+    asm("" : "+v"(v));
+    h = (_Float16)v;
+    l = (_Float16)(v - (float)h);
+}
 
 }  // namespace amp

@@ -59,8 +59,13 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int hi = lane >> 5, l31 = lane & 31;
-    const int item = blockIdx.x / a.tiles_per_item;
-    const int tile = blockIdx.x - item * a.tiles_per_item;
+    // Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8), each with its own
+    // L2: hand every XCD a contiguous run of tiles, so the halo columns two neighbouring tiles share
+    // are fetched into ONE L2 instead of two.
+    const int nbx = gridDim.x;
+    const int bx = (nbx & 7) == 0 ? (int)(blockIdx.x & 7) * (nbx >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int item = bx / a.tiles_per_item;
+    const int tile = bx - item * a.tiles_per_item;
     const int q0 = tile * NT;
     const int mb = blockIdx.y * WM + wm;       // 32-row block of W'
 
@@ -169,9 +174,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
             for (int e = 0; e < 4; ++e) {
                 float v = (tok && (ch0 + e) < a.Cin) ? xs[it][e] : 0.f;
                 v = v * (v > 0.f ? kpos : kneg);
-                const _Float16 h16 = (_Float16)v;
-                fh.h[e] = h16;
-                fl.h[e] = (_Float16)(v - (float)h16);
+                split_f16(v, fh.h[e], fl.h[e]);
             }
             // uint2 index inside a plane: ((octet * S + col) * 2 + half)
             const int o2 = (((qd >> 1) * S + col) << 1) + (qd & 1);

@@ -35,8 +35,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int hi = lane >> 5, l31 = lane & 31;
-    const int item = blockIdx.x / a.tiles_per_item;
-    const int tile = blockIdx.x - item * a.tiles_per_item;
+    // Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8), each with its own
+    // L2: hand every XCD a contiguous run of tiles, so the halo columns two neighbouring tiles share
+    // are fetched into ONE L2 instead of two.
+    const int nbx = gridDim.x;
+    const int bx = (nbx & 7) == 0 ? (int)(blockIdx.x & 7) * (nbx >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int item = bx / a.tiles_per_item;
+    const int tile = bx - item * a.tiles_per_item;
     const int q0 = tile * NT;
     const int mb = blockIdx.y * WM + wm;        // 32-row block of W'
 

@@ -95,6 +95,45 @@ hipError_t launch_conv(const ConvPlan& p, const ConvArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
+int pair_tile_kt3(int, int);
+int pair_tile_kt5(int, int);
+int pair_tile_kt7(int, int);
+int pair_tile_kt11(int, int);
+hipError_t launch_pair_kt3(const PairArgs&, hipStream_t);
+hipError_t launch_pair_kt5(const PairArgs&, hipStream_t);
+hipError_t launch_pair_kt7(const PairArgs&, hipStream_t);
+hipError_t launch_pair_kt11(const PairArgs&, hipStream_t);
+
+int pair_tile(int k, int C, int dil) {
+    switch (k) {
+        case 3: return pair_tile_kt3(C, dil);
+        case 5: return pair_tile_kt5(C, dil);
+        case 7: return pair_tile_kt7(C, dil);
+        case 11: return pair_tile_kt11(C, dil);
+    }
+    return 0;
+}
+
+hipError_t launch_pair(int k, const PairArgs& a, hipStream_t s) {
+    switch (k) {
+        case 3: return launch_pair_kt3(a, s);
+        case 5: return launch_pair_kt5(a, s);
+        case 7: return launch_pair_kt7(a, s);
+        case 11: return launch_pair_kt11(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// AMP_FUSE_PAIRS=0 runs every ResBlock pair as two conv launches (A/B switch for the fused kernel).
+static int g_fuse_pairs = -1;
+static bool fuse_pairs_enabled() {
+    if (g_fuse_pairs < 0) {
+        const char* e = getenv("AMP_FUSE_PAIRS");
+        g_fuse_pairs = (e && !strcmp(e, "0")) ? 0 : 1;
+    }
+    return g_fuse_pairs != 0;
+}
+
 hipError_t launch_conv_f16x3(const ConvPlan& p, const ConvArgs& a, hipStream_t s) {
     switch (p.KT) {
         case 1: return launch_conv_h_kt1(p, a, s);
@@ -258,6 +297,36 @@ static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope
     return AMP_OK;
 }
 
+// Fused ResBlock1 pair (pair_f16x3.hip): y = x + c2(lrelu(c1(lrelu(x)))).  Returns false when this
+// (channels, kernel, dilation, precision) is not covered and the caller must run the two convs.
+static bool pair_supported(const amp_conv* c1, const amp_conv* c2) {
+    if (!fuse_pairs_enabled()) return false;
+    if (c1->precision != PREC_F16X3 || c2->precision != PREC_F16X3) return false;
+    if (c1->transposed || c2->transposed || c1->cin != c1->cout || c2->cin != c2->cout || c1->cin != c2->cin) return false;
+    if (c1->k != c2->k || c2->dilation != 1 || c1->k != c1->KT) return false;
+    if (c1->padding != (c1->k - 1) / 2 * c1->dilation || c2->padding != (c2->k - 1) / 2) return false;
+    if (!c1->bias_dev || !c2->bias_dev) return false;
+    return pair_tile(c1->k, c1->cin, c1->dilation) > 0;
+}
+
+static int pair_run(const amp_conv* c1, const amp_conv* c2, const float* x, int B, int T, float slope, float* y,
+                    int mode, float div, hipStream_t stream) {
+    if (x == y) { set_error("pair_run: x and y must not alias"); return AMP_ERR_INVALID; }
+    PairArgs a{};
+    a.x = x; a.y = y;
+    a.wp1 = c1->wp_dev; a.bias1 = c1->bias_dev; a.wp2 = c2->wp_dev; a.bias2 = c2->bias_dev;
+    a.B = B; a.C = c1->cin; a.T = T;
+    const int NT = pair_tile(c1->k, c1->cin, c1->dilation);
+    a.tiles_per_item = (T + NT - 1) / NT;
+    a.dil = c1->dilation;
+    a.slope = slope;
+    a.sc1 = 16.f * c1->wscale; a.isc1 = 1.f / a.sc1;
+    a.sc2 = 16.f * c2->wscale; a.isc2 = 1.f / a.sc2;
+    a.mode = mode; a.div = div;
+    AMP_HIP(launch_pair(c1->k, a, stream));
+    return AMP_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // generator handle
 // ------------------------------------------------------------------------------------------------
@@ -299,7 +368,8 @@ struct amp_gen {
     // profiling
     bool profiling = false;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-    std::vector<hipEvent_t> ev_mrf;  // begin/end per stage
+    std::vector<hipEvent_t> ev_mrf;  // begin/end per (batch group, stage)
+    int ev_groups = 0;
     bool timing_valid = false;
     ~amp_gen() {
         for (float* p : dev_allocs) (void)hipFree(p);
@@ -587,9 +657,41 @@ static size_t gen_buf_elems(const amp_gen* g, int B, int T) {
 
 static int gen_num_bufs(const amp_gen* g) { return g->d.arch == AMP_ARCH_BIGVGAN ? 6 : 5; }
 
+// Optional depth-first batch grouping: a group of items runs through the WHOLE generator before the
+// next one starts, with a working set (the scratch tensors of its largest stage) bounded by
+// AMP_GROUP_MB / amp_set_group_mb().  It bounds the workspace (168 MB instead of 2.7 GB at config 2) but
+// is OFF by default (0 = whole batch per layer): sized to the 256 MiB Infinity Cache it was measured
+// SLOWER on MI355X (36.2 ms ungrouped vs 45.6 / 49.9 / 62.4 ms at 200 / 144 / 104 MB groups,
+// profiles/r1_exp_group.txt) -- the small grids under-fill 256 CUs and the cache brings no bandwidth win.
+static size_t g_group_bytes = (size_t)-1;
+static size_t group_target_bytes() {
+    if (g_group_bytes == (size_t)-1) {
+        const char* e = getenv("AMP_GROUP_MB");
+        g_group_bytes = e ? (size_t)atol(e) << 20 : 0;
+    }
+    return g_group_bytes;
+}
+
+static int gen_group_items(const amp_gen* g, int B, int T) {
+    const size_t target = group_target_bytes();
+    if (target == 0) return B;
+    // live tensors of a stage: U, R, TMP, XS (+ ACT) -- X is dead once the stage's ConvTranspose has run
+    const size_t per_item = gen_buf_elems(g, 1, T) * sizeof(float) * (size_t)(gen_num_bufs(g) - 1);
+    size_t n = target / (per_item ? per_item : 1);
+    if (n < 1) n = 1;
+    return n < (size_t)B ? (int)n : B;
+}
+
 size_t amp_gen_workspace_bytes(const amp_gen* g, int B, int T) {
     if (!g || B <= 0 || T <= 0) return 0;
-    return gen_buf_elems(g, B, T) * sizeof(float) * gen_num_bufs(g) + (size_t)B * g->d.upsample_initial_channel * sizeof(float) + 256;
+    const int G = gen_group_items(g, B, T);
+    return gen_buf_elems(g, G, T) * sizeof(float) * gen_num_bufs(g) + (size_t)G * g->d.upsample_initial_channel * sizeof(float) + 256;
+}
+
+int amp_set_group_mb(int megabytes) {
+    if (megabytes < 0) { set_error("amp_set_group_mb: %d", megabytes); return AMP_ERR_INVALID; }
+    g_group_bytes = (size_t)megabytes << 20;
+    return AMP_OK;
 }
 
 int amp_gen_set_profiling(amp_gen* g, int enabled) {
@@ -598,8 +700,6 @@ int amp_gen_set_profiling(amp_gen* g, int enabled) {
     if (g->profiling && !g->ev_begin) {
         AMP_HIP(hipEventCreate(&g->ev_begin));
         AMP_HIP(hipEventCreate(&g->ev_end));
-        g->ev_mrf.resize(2 * (size_t)g->d.n_stages);
-        for (auto& e : g->ev_mrf) AMP_HIP(hipEventCreate(&e));
     }
     g->timing_valid = false;
     return AMP_OK;
@@ -611,16 +711,18 @@ int amp_gen_last_timing_ms(amp_gen* g, int which, float* ms_out) {
     AMP_HIP(hipEventSynchronize(g->ev_end));
     if (which == 0) {
         AMP_HIP(hipEventElapsedTime(ms_out, g->ev_begin, g->ev_end));
-    } else if (which == 1) {
+    } else if (which >= 1 && which < 2 + g->d.n_stages) {
+        // sum over the batch groups (and, for which == 1, over the stages)
         float tot = 0.f;
-        for (int i = 0; i < g->d.n_stages; ++i) {
-            float ms = 0.f;
-            AMP_HIP(hipEventElapsedTime(&ms, g->ev_mrf[2 * i], g->ev_mrf[2 * i + 1]));
-            tot += ms;
-        }
+        for (int gi = 0; gi < g->ev_groups; ++gi)
+            for (int i = 0; i < g->d.n_stages; ++i) {
+                if (which >= 2 && i != which - 2) continue;
+                float ms = 0.f;
+                const size_t e = 2 * ((size_t)g->d.n_stages * gi + i);
+                AMP_HIP(hipEventElapsedTime(&ms, g->ev_mrf[e], g->ev_mrf[e + 1]));
+                tot += ms;
+            }
         *ms_out = tot;
-    } else if (which >= 2 && which < 2 + g->d.n_stages) {
-        AMP_HIP(hipEventElapsedTime(ms_out, g->ev_mrf[2 * (which - 2)], g->ev_mrf[2 * (which - 2) + 1]));
     } else {
         set_error("amp_gen_last_timing_ms: which=%d", which);
         return AMP_ERR_INVALID;
@@ -630,18 +732,11 @@ int amp_gen_last_timing_ms(amp_gen* g, int which, float* ms_out) {
 
 #define AMP_RC(expr) do { int rc__ = (expr); if (rc__ != AMP_OK) return rc__; } while (0)
 
-int amp_gen_forward(amp_gen* g, const float* mel_dev, const float* cond_dev, int B, int T, float* wav_dev,
-                    void* workspace_dev, size_t workspace_bytes, void* stream_) {
-    if (!g || !mel_dev || !wav_dev || !workspace_dev) { set_error("amp_gen_forward: null argument"); return AMP_ERR_INVALID; }
-    if (!g->finalized) { set_error("amp_gen_forward: call amp_gen_finalize first"); return AMP_ERR_STATE; }
-    if (B <= 0 || T <= 0) { set_error("amp_gen_forward: B=%d T=%d", B, T); return AMP_ERR_INVALID; }
-    if (workspace_bytes < amp_gen_workspace_bytes(g, B, T)) { set_error("amp_gen_forward: workspace too small (%zu < %zu)", workspace_bytes, amp_gen_workspace_bytes(g, B, T)); return AMP_ERR_INVALID; }
-    if (cond_dev && !g->cond) { set_error("amp_gen_forward: cond given but gin_channels == 0"); return AMP_ERR_INVALID; }
-    hipStream_t st = (hipStream_t)stream_;
+// One group of `B` items through the whole generator (buffers sized for `be` elements each).
+static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond_dev, int B, int T, float* wav_dev,
+                             float* base, size_t be, hipStream_t st, hipEvent_t* ev_mrf /* 2 per stage, or null */) {
     const amp_gen_desc& d = g->d;
     const bool big = d.arch == AMP_ARCH_BIGVGAN;
-    const size_t be = gen_buf_elems(g, B, T);
-    float* base = (float*)workspace_dev;
     float* X = base;            // stage input / MRF accumulator (ping-pong with XS)
     float* XS = base + be;
     float* U = base + 2 * be;   // upsampled stage tensor (input of every resblock)
@@ -651,7 +746,6 @@ int amp_gen_forward(amp_gen* g, const float* mel_dev, const float* cond_dev, int
     float* CB = base + (size_t)gen_num_bufs(g) * be;  // cond(g): [B, C0]
     const float slope = 0.1f;  // LRELU_SLOPE hifigan.py:14
 
-    if (g->profiling) AMP_HIP(hipEventRecord(g->ev_begin, st));
     AMP_RC(conv_run(g->conv_pre.get(), mel_dev, B, T, 1.f, nullptr, 1.f, X, 0, 1.f, st));
     if (cond_dev) {  // x = x + self.cond(g), hifigan.py:426-427 (g has length 1 -> per-channel bias)
         AMP_RC(conv_run(g->cond.get(), cond_dev, B, 1, 1.f, nullptr, 1.f, CB, 0, 1.f, st));
@@ -664,7 +758,7 @@ int amp_gen_forward(amp_gen* g, const float* mel_dev, const float* cond_dev, int
         // HiFiGAN: leaky_relu(0.1) before the transposed conv (hifigan.py:206); BigVGAN: none (bigvgan.py:316-318)
         AMP_RC(conv_run(g->ups[i].get(), X, B, t, big ? 1.f : slope, nullptr, 1.f, U, 0, 1.f, st));
         t *= d.upsample_rates[i];
-        if (g->profiling) AMP_HIP(hipEventRecord(g->ev_mrf[2 * i], st));
+        if (ev_mrf) AMP_HIP(hipEventRecord(ev_mrf[2 * i], st));
         for (int j = 0; j < nk; ++j) {
             const ResBlock& rb = g->rbs[(size_t)i * nk + j];
             const int nd = (int)rb.dil.size();
@@ -673,8 +767,18 @@ int amp_gen_forward(amp_gen* g, const float* mel_dev, const float* cond_dev, int
             for (int p = 0; p < nd; ++p) {
                 const bool last = p == nd - 1;
                 if (d.resblock_type == 1) {
-                    if (!big) {
+                    if (!big && pair_supported(rb.c1[p].get(), rb.c2[p].get())) {
+                        // the whole pair in one kernel; the output ping-pongs R <-> TMP (never in place:
+                        // other tiles still read the input's halo)
+                        float* dst = last ? XS : (cur == R ? TMP : R);
+                        AMP_RC(pair_run(rb.c1[p].get(), rb.c2[p].get(), cur, B, t, slope, dst, last ? mode_last : 0, (float)nk, st));
+                        cur = dst;
+                    } else if (!big) {
                         // xt = lrelu(c1(lrelu(x))) ; x = c2(xt) + x        hifigan.py:93-100
+                        if (cur == TMP) {  // previous pair was fused into TMP: keep the unfused ping-pong legal
+                            AMP_HIP(hipMemcpyAsync(R, TMP, (size_t)B * C * t * sizeof(float), hipMemcpyDeviceToDevice, st));
+                            cur = R;
+                        }
                         AMP_RC(conv_run(rb.c1[p].get(), cur, B, t, slope, nullptr, slope, TMP, 0, 1.f, st));
                         if (!last) { AMP_RC(conv_run(rb.c2[p].get(), TMP, B, t, 1.f, cur, 1.f, R, 0, 1.f, st)); cur = R; }
                         else AMP_RC(conv_run(rb.c2[p].get(), TMP, B, t, 1.f, cur, 1.f, XS, mode_last, (float)nk, st));
@@ -709,7 +813,7 @@ int amp_gen_forward(amp_gen* g, const float* mel_dev, const float* cond_dev, int
                 }
             }
         }
-        if (g->profiling) AMP_HIP(hipEventRecord(g->ev_mrf[2 * i + 1], st));
+        if (ev_mrf) AMP_HIP(hipEventRecord(ev_mrf[2 * i + 1], st));
         float* tmp = X; X = XS; XS = tmp;  // x = xs / num_kernels
     }
     if (big) {
@@ -718,6 +822,40 @@ int amp_gen_forward(amp_gen* g, const float* mel_dev, const float* cond_dev, int
     } else {
         // F.leaky_relu(x) with the DEFAULT slope 0.01 (hifigan.py:215,439), conv_post, tanh
         AMP_HIP(launch_conv_post(X, g->post_w_dev, g->post_b_dev, wav_dev, B, g->post_cin, t, 7, 0.01f, 1, st));
+    }
+    return AMP_OK;
+}
+
+int amp_gen_forward(amp_gen* g, const float* mel_dev, const float* cond_dev, int B, int T, float* wav_dev,
+                    void* workspace_dev, size_t workspace_bytes, void* stream_) {
+    if (!g || !mel_dev || !wav_dev || !workspace_dev) { set_error("amp_gen_forward: null argument"); return AMP_ERR_INVALID; }
+    if (!g->finalized) { set_error("amp_gen_forward: call amp_gen_finalize first"); return AMP_ERR_STATE; }
+    if (B <= 0 || T <= 0) { set_error("amp_gen_forward: B=%d T=%d", B, T); return AMP_ERR_INVALID; }
+    if (workspace_bytes < amp_gen_workspace_bytes(g, B, T)) { set_error("amp_gen_forward: workspace too small (%zu < %zu)", workspace_bytes, amp_gen_workspace_bytes(g, B, T)); return AMP_ERR_INVALID; }
+    if (cond_dev && !g->cond) { set_error("amp_gen_forward: cond given but gin_channels == 0"); return AMP_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)stream_;
+    const amp_gen_desc& d = g->d;
+    const int G = gen_group_items(g, B, T);
+    const int ngroups = (B + G - 1) / G;
+    const size_t be = gen_buf_elems(g, G, T);
+    const size_t L = (size_t)T * g->hop;
+    if (g->profiling) {
+        const size_t need = 2 * (size_t)d.n_stages * ngroups;
+        while (g->ev_mrf.size() < need) {
+            hipEvent_t e;
+            AMP_HIP(hipEventCreate(&e));
+            g->ev_mrf.push_back(e);
+        }
+        g->ev_groups = ngroups;
+        AMP_HIP(hipEventRecord(g->ev_begin, st));
+    }
+    for (int gi = 0; gi < ngroups; ++gi) {
+        const int b0 = gi * G;
+        const int Bg = (B - b0) < G ? (B - b0) : G;
+        AMP_RC(gen_forward_group(g, mel_dev + (size_t)b0 * d.n_in * T,
+                                 cond_dev ? cond_dev + (size_t)b0 * d.gin_channels : nullptr, Bg, T,
+                                 wav_dev + (size_t)b0 * L, (float*)workspace_dev, be, st,
+                                 g->profiling ? g->ev_mrf.data() + 2 * (size_t)d.n_stages * gi : nullptr));
     }
     if (g->profiling) { AMP_HIP(hipEventRecord(g->ev_end, st)); g->timing_valid = true; }
     return AMP_OK;
@@ -752,6 +890,17 @@ int amp_conv_forward_strided(const amp_conv* c, const float* x_dev, long long x_
     if (!c || !x_dev || !y_dev) { set_error("amp_conv_forward_strided: null argument"); return AMP_ERR_INVALID; }
     if (x_batch_stride < (long long)c->cin * T) { set_error("amp_conv_forward_strided: batch stride %lld < cin*T", x_batch_stride); return AMP_ERR_INVALID; }
     return conv_run(c, x_dev, B, T, slope_in, res_dev, slope_out, y_dev, 0, 1.f, (hipStream_t)stream, x_batch_stride);
+}
+
+int amp_pair_forward(const amp_conv* c1, const amp_conv* c2, const float* x_dev, int B, int T, float slope,
+                     float* y_dev, void* stream) {
+    if (!c1 || !c2 || !x_dev || !y_dev) { set_error("amp_pair_forward: null argument"); return AMP_ERR_INVALID; }
+    if (B <= 0 || T <= 0) { set_error("amp_pair_forward: B=%d T=%d", B, T); return AMP_ERR_INVALID; }
+    if (!pair_supported(c1, c2)) {
+        set_error("amp_pair_forward: pair (C=%d k=%d dilation=%d) is not covered by the fused kernel", c1->cin, c1->k, c1->dilation);
+        return AMP_ERR_UNSUPPORTED;
+    }
+    return pair_run(c1, c2, x_dev, B, T, slope, y_dev, 0, 1.f, (hipStream_t)stream);
 }
 
 void amp_conv_destroy(amp_conv* c) { delete c; }

@@ -1,0 +1,327 @@
+// Fused ResBlock pair on the gfx950 f16 matrix cores (split-f16 operands, see conv_f16x3.hip):
+//
+//     y = x + c2( lrelu( c1( lrelu(x) ) ) )         [+ the running MRF sum, / num_kernels]
+//
+// i.e. ONE iteration of ResBlock1.forward (hifigan.py:93-100: xt = lrelu(x); xt = c1(xt); xt = lrelu(xt);
+// xt = c2(xt); x = xt + x) in one kernel.  Unfused, a pair moves 5 tensors through HBM (read x, write
+// xt, read xt, read x again as the residual, write y); here xt never leaves the CU and the residual
+// re-read is an L2 hit, so a pair is one read and one write of the [B, C, T] tensor.
+//
+//   workgroup = all C channels x NT output columns of one batch item.
+//   phase 1   conv1 (kernel KT, dilation d) as in conv_f16x3.hip -- K loop over 16-channel chunks of x
+//             staged through a double-buffered LDS tile -- on N1 = NT + (KT - 1) columns: exactly the
+//             columns conv2 needs, so there is no halo recompute beyond the tile seam itself
+//             (N1 is a multiple of 32; NT is not: rows are stored at 4-B granularity).
+//   seam      bias + leaky_relu + conv2's zero padding + x16 + hi/lo split in registers, written to the
+//             LDS xt tile in B-fragment layout [chunk][plane hi|lo][octet][column][8 x f16].
+//   phase 2   conv2 (kernel KT, dilation 1): K loop over the xt chunks in LDS -- no staging, no
+//             barriers; A fragments streamed from L2 with the one-chunk-ahead rotation.
+//   epilogue  + bias, + residual x (global, L2-hot), MRF accumulate, store.
+//
+// Compiled once per tap count:  -DAMP_KT=<3|5|7|11>.
+#include "amp_internal.h"
+
+#ifndef AMP_KT
+#error "compile with -DAMP_KT=<taps>"
+#endif
+
+namespace amp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+union Frag {
+    uint4 u;
+    f16x8 h;
+};
+
+#define AMP_PIN_VMEM() __builtin_amdgcn_sched_barrier(0x386)
+
+template <int KT, int WM, int WN, int NI, int SX>
+__global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairArgs a) {
+    constexpr int N1 = 32 * NI * WN;          // conv1 output columns = xt columns conv2 reads
+    constexpr int H2 = (KT - 1) / 2;
+    constexpr int NT = N1 - 2 * H2;           // output columns per workgroup
+    constexpr int XT = N1 + 12;               // xt row length: + the read overrun of the unused tail columns
+    constexpr int NCH = 2 * WM;               // 16-channel chunks (C = 32 * WM)
+    constexpr int XBUF = 4 * SX;              // uint4 per x staging buffer [plane][octet][SX]
+    constexpr int XTCH = 4 * XT;              // uint4 per xt chunk       [plane][octet][XT]
+    constexpr int NST = (4 * SX) / 256;       // staging items (column x channel quad) per thread
+    static_assert(SX % 64 == 0, "staging items must have a wave-uniform channel quad");
+    static_assert(KT - 1 <= 12, "xt pad");
+    extern __shared__ __attribute__((aligned(16))) uint4 smem4[];  // [2][XBUF] + [NCH][XTCH]
+    uint4* const xt4 = smem4 + 2 * XBUF;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int nbx = gridDim.x;  // XCD-contiguous tile runs, see conv_f16x3.hip
+    const int bx = (nbx & 7) == 0 ? (int)(blockIdx.x & 7) * (nbx >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int item = bx / a.tiles_per_item;
+    const int tile = bx - item * a.tiles_per_item;
+    const int q0 = tile * NT;                 // first output column
+    const int C = 32 * WM;
+    const int T = a.T;
+    const int dil = a.dil;
+    const int h1 = H2 * dil;
+
+    const float* xb = a.x + (size_t)item * C * T;
+    const int tbase = q0 - H2 - h1;           // global column of staged column 0
+    const float kpos = 16.f, kneg = 16.f * a.slope;
+
+    // ---------------- phase 1: conv1 ----------------
+    f32x16 acc[NI];
+    {
+        const float s1 = a.sc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float bv = a.bias1[32 * wm + (r & 3) + 8 * (r >> 2) + 4 * hi] * s1;
+#pragma unroll
+            for (int t = 0; t < NI; ++t) acc[t][r] = bv;
+        }
+    }
+
+    float xs[NST][4];
+    auto stage_load = [&](int chunk) {
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int ibase = wave * 64 + 256 * it;          // wave-uniform
+            const int qd = ibase / SX;                       // channel quad 0..3
+            const int col = ibase - qd * SX + lane;
+            int t = tbase + col;
+            t = t < 0 ? 0 : t;
+            t = t > T - 1 ? T - 1 : t;
+            const int ch0 = chunk * KC16 + 4 * qd;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xs[it][e] = xb[(size_t)(ch0 + e) * T + t];
+        }
+    };
+    auto stage_store = [&](int buf) {
+        uint2* dst = reinterpret_cast<uint2*>(smem4 + buf * XBUF);
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int ibase = wave * 64 + 256 * it;
+            const int qd = ibase / SX;
+            const int col = ibase - qd * SX + lane;
+            const int t = tbase + col;
+            const bool tok = (t >= 0) && (t < T);
+            union { uint2 u; _Float16 h[4]; } fh, fl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = tok ? xs[it][e] : 0.f;
+                v = v * (v > 0.f ? kpos : kneg);
+                split_f16(v, fh.h[e], fl.h[e]);
+            }
+            const int o2 = (((qd >> 1) * SX + col) << 1) + (qd & 1);
+            dst[o2] = fh.u;
+            dst[4 * SX + o2] = fl.u;
+        }
+    };
+
+    // A fragments [mb][chunk][tap][plane][lane] x uint4, one register set, reloaded one chunk ahead
+    // (conv_f16x3.hip); the reload during conv1's LAST chunk fetches conv2's first chunk.
+    const uint4* wa1 = static_cast<const uint4*>(a.wp1) + (size_t)wm * NCH * (KT * 128) + lane;
+    const uint4* wa2 = static_cast<const uint4*>(a.wp2) + (size_t)wm * NCH * (KT * 128) + lane;
+    Frag a_h[KT], a_l[KT];
+
+    const int colw = wn * (32 * NI) + l31;    // this lane's column inside the tile (n-tile 0)
+    const int rd1 = hi * SX + colw;
+
+    stage_load(0);
+#pragma unroll
+    for (int g = 0; g < KT; ++g) {
+        a_h[g].u = wa1[g * 128];
+        a_l[g].u = wa1[g * 128 + 64];
+    }
+    AMP_PIN_VMEM();
+    stage_store(0);
+    __syncthreads();
+
+    for (int c = 0; c < NCH; ++c) {
+        const bool more = (c + 1) < NCH;
+        stage_load(more ? c + 1 : c);
+        AMP_PIN_VMEM();
+        const uint4* wan = more ? wa1 + (size_t)(c + 1) * (KT * 128) : wa2;
+        const uint4* base = smem4 + (c & 1) * XBUF + rd1;
+#pragma unroll
+        for (int g = 0; g < KT; ++g) {
+            const uint4* bg = base + g * dil;
+            Frag bh[NI], bl[NI];
+#pragma unroll
+            for (int t = 0; t < NI; ++t) {
+                bh[t].u = bg[32 * t];
+                bl[t].u = bg[2 * SX + 32 * t];
+            }
+#pragma unroll
+            for (int t = 0; t < NI; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[g].h, bh[t].h, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NI; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[g].h, bl[t].h, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NI; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l[g].h, bh[t].h, acc[t], 0, 0, 0);
+            a_h[g].u = wan[g * 128];
+            a_l[g].u = wan[g * 128 + 64];
+            AMP_PIN_VMEM();
+        }
+        if (more) stage_store((c + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---------------- seam: xt = lrelu(conv1) -> LDS, split-f16 B layout ----------------
+    {
+        const float i1 = a.isc1;
+        const float slope = a.slope;
+        uint2* xt2 = reinterpret_cast<uint2*>(xt4);
+#pragma unroll
+        for (int t = 0; t < NI; ++t) {
+            const int col = colw + 32 * t;                   // xt column (tile-local)
+            const int q = q0 - H2 + col;                     // its global column
+            const bool qok = (q >= 0) && (q < T);            // conv2 zero-pads xt outside [0, T)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                union { uint2 u; _Float16 h[4]; } fh, fl;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = acc[t][4 * j + i] * i1;
+                    v = v > 0.f ? v : v * slope;
+                    v = qok ? v * 16.f : 0.f;
+                    split_f16(v, fh.h[i], fl.h[i]);
+                }
+                // channels 32*wm + 8*j + 4*hi + i  ->  chunk 2*wm + (j >> 1), octet j & 1, half hi
+                const int o4 = (2 * wm + (j >> 1)) * XTCH + (j & 1) * XT + col;
+                xt2[(o4 << 1) + hi] = fh.u;
+                xt2[((o4 + 2 * XT) << 1) + hi] = fl.u;
+            }
+        }
+    }
+    {
+        const float s2 = a.sc2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float bv = a.bias2[32 * wm + (r & 3) + 8 * (r >> 2) + 4 * hi] * s2;
+#pragma unroll
+            for (int t = 0; t < NI; ++t) acc[t][r] = bv;
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase 2: conv2 over the xt tile ----------------
+    {
+        const int rd2 = hi * XT + colw;
+        for (int c = 0; c < NCH; ++c) {
+            const uint4* wan = wa2 + (size_t)(c + 1) * (KT * 128);   // last: next mb block / pad
+            const uint4* base = xt4 + c * XTCH + rd2;
+#pragma unroll
+            for (int g = 0; g < KT; ++g) {
+                const uint4* bg = base + g;
+                Frag bh[NI], bl[NI];
+#pragma unroll
+                for (int t = 0; t < NI; ++t) {
+                    bh[t].u = bg[32 * t];
+                    bl[t].u = bg[2 * XT + 32 * t];
+                }
+#pragma unroll
+                for (int t = 0; t < NI; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[g].h, bh[t].h, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NI; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[g].h, bl[t].h, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NI; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l[g].h, bh[t].h, acc[t], 0, 0, 0);
+                a_h[g].u = wan[g * 128];
+                a_l[g].u = wan[g * 128 + 64];
+                AMP_PIN_VMEM();
+            }
+        }
+    }
+
+    // ---------------- epilogue: + residual, MRF accumulate, store ----------------
+    // loads are unconditional from clamped addresses (batched, one wait), stores are predicated
+    {
+        const float i2 = a.isc2;
+        const int mode = a.mode;
+        const float* xr = a.x + (size_t)item * C * T + (size_t)(32 * wm + 4 * hi) * T;
+        float* yr = a.y + (size_t)item * C * T + (size_t)(32 * wm + 4 * hi) * T;
+        int qc[NI];
+        bool ok[NI];
+#pragma unroll
+        for (int t = 0; t < NI; ++t) {
+            const int col = colw + 32 * t;
+            const int q = q0 + col;
+            ok[t] = (col < NT) && (q < T);
+            qc[t] = q < T ? q : T - 1;
+        }
+        f32x16 rv[NI];
+#pragma unroll
+        for (int t = 0; t < NI; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[t][r] = xr[(size_t)((r & 3) + 8 * (r >> 2)) * T + qc[t]];
+#pragma unroll
+        for (int t = 0; t < NI; ++t) acc[t] = acc[t] * i2 + rv[t];
+        if (mode != 0) {   // wave-uniform
+#pragma unroll
+            for (int t = 0; t < NI; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[t][r] = yr[(size_t)((r & 3) + 8 * (r >> 2)) * T + qc[t]];
+#pragma unroll
+            for (int t = 0; t < NI; ++t) acc[t] += rv[t];
+            if (mode == 2) {
+#pragma unroll
+                for (int t = 0; t < NI; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] = acc[t][r] / a.div;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NI; ++t)
+            if (ok[t]) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) yr[(size_t)((r & 3) + 8 * (r >> 2)) * T + qc[t]] = acc[t][r];
+            }
+    }
+}
+
+template <int KT, int WM, int WN, int NI, int SX>
+static hipError_t launch_pair_one(const PairArgs& a, hipStream_t stream) {
+    constexpr int N1 = 32 * NI * WN;
+    constexpr int XT = N1 + 12;
+    const size_t lds = ((size_t)2 * 4 * SX + (size_t)2 * WM * 4 * XT) * sizeof(uint4);
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_f16x3_kernel<KT, WM, WN, NI, SX>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(a.B * a.tiles_per_item));
+    hipLaunchKernelGGL((pair_f16x3_kernel<KT, WM, WN, NI, SX>), grid, dim3(256), lds, stream, a);
+    return hipGetLastError();
+}
+
+#define AMP_CAT2(a, b) a##b
+#define AMP_CAT(a, b) AMP_CAT2(a, b)
+
+// Output columns per workgroup for C channels, or 0 when (C, KT, dilation) is not covered.
+int AMP_CAT(pair_tile_kt, AMP_KT)(int C, int dil) {
+    constexpr int KT = AMP_KT;
+    const int span = (KT - 1) * dil;   // 2 * h1
+    if (C == 128) return (96 + span <= 192) ? 96 - (KT - 1) : 0;
+    if (C == 64) return (128 + span <= 192) ? 128 - (KT - 1) : 0;
+    if (C == 32) return (256 + span <= 320) ? 256 - (KT - 1) : 0;
+    return 0;
+}
+
+hipError_t AMP_CAT(launch_pair_kt, AMP_KT)(const PairArgs& a, hipStream_t stream) {
+    constexpr int KT = AMP_KT;
+    if (a.C == 128) return launch_pair_one<KT, 4, 1, 3, 192>(a, stream);
+    if (a.C == 64) return launch_pair_one<KT, 2, 2, 2, 192>(a, stream);
+    if (a.C == 32) return launch_pair_one<KT, 1, 4, 2, 320>(a, stream);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace amp

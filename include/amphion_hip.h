@@ -114,6 +114,12 @@ int amp_gen_finalize(amp_gen* g);
 int amp_gen_hop(const amp_gen* g);
 size_t amp_gen_workspace_bytes(const amp_gen* g, int B, int T);
 
+/* amp_gen_forward can run the batch depth-first in groups of items (each group through the whole
+ * generator) to bound the workspace: target working set in MiB, 0 = whole batch per layer (default; the
+ * faster setting on MI355X).  Also settable with the environment variable AMP_GROUP_MB.
+ * Results do not depend on it. */
+int amp_set_group_mb(int megabytes);
+
 /* Replaces HiFiGAN.forward (hifigan.py:203-219), BigVGAN.forward (bigvgan.py:313-331) and
  * HiFiGAN_vits.forward (hifigan.py:424-443):  mel_dev [B, n_in, T]  ->  wav_dev [B, 1, T*hop].
  * cond_dev: optional speaker embedding g [B, gin_channels, 1] (HiFiGAN_vits), else NULL. */
@@ -147,6 +153,15 @@ int amp_conv_forward(const amp_conv* c, const float* x_dev, int B, int T, float 
  * (elements).  Used by ResidualCouplingLayer.pre on x0 = x[:, :half] (modules/flow/modules.py:380-381). */
 int amp_conv_forward_strided(const amp_conv* c, const float* x_dev, long long x_batch_stride, int B, int T,
                              float slope_in, const float* res_dev, float slope_out, float* y_dev, void* stream);
+/* One ResBlock1 iteration fused in a single kernel (hifigan.py:93-100):
+ *     y = x + c2( leaky_relu( c1( leaky_relu(x, slope) ), slope ) )
+ * c1: Conv1d(C, C, k, dilation d, 'same' padding), c2: Conv1d(C, C, k, dilation 1), both with bias, built
+ * with amp_conv_create under AMP_PRECISION_F16X3.  Covered: C in {32, 64, 128}, k in {3, 5, 7, 11} and
+ * (k-1)*d <= 64; anything else returns AMP_ERR_UNSUPPORTED (amp_gen_forward then runs the two convs).
+ * y_dev must not alias x_dev. */
+int amp_pair_forward(const amp_conv* c1, const amp_conv* c2, const float* x_dev, int B, int T, float slope,
+                     float* y_dev, void* stream);
+
 void amp_conv_destroy(amp_conv* c);
 
 /* ---- VITS posterior encoder + flow (config 5): element-wise pieces between the convs ---- */

@@ -32,6 +32,31 @@ def conv_forward(w, b, x, *, transposed=False, stride=1, dilation=1, padding=0, 
         L.amp_conv_destroy(h)
 
 
+def pair_forward(w1, b1, w2, b2, x, *, dilation, slope=0.1):
+    """amp_pair_forward on cuda:0: y = x + c2(lrelu(c1(lrelu(x))))  (fused ResBlock1 pair)."""
+    L = _lib.lib()
+    C, _, k = w1.shape
+    hs = []
+    try:
+        for w, b, d in ((w1, b1, dilation), (w2, b2, 1)):
+            h = ctypes.c_void_p()
+            w = w.contiguous().float()
+            b = b.contiguous().float()
+            _lib.check(L.amp_conv_create(0, C, C, k, 1, d, (k * d - d) // 2, ctypes.c_void_p(w.data_ptr()),
+                                         ctypes.c_void_p(b.data_ptr()), ctypes.byref(h)))
+            hs.append(h)
+        xd = x.contiguous().float().cuda()
+        B, _, T = xd.shape
+        y = torch.full_like(xd, float("nan"))
+        _lib.check(L.amp_pair_forward(hs[0], hs[1], ctypes.c_void_p(xd.data_ptr()), B, T, slope,
+                                      ctypes.c_void_p(y.data_ptr()), _lib.current_stream_ptr(xd.device)))
+        torch.cuda.synchronize()
+        return y.cpu()
+    finally:
+        for h in hs:
+            L.amp_conv_destroy(h)
+
+
 def act1d_forward(x, alpha, beta, logscale, fu, fd):
     L = _lib.lib()
     xd = x.contiguous().float().cuda()

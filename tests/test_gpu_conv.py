@@ -84,6 +84,22 @@ def test_conv_transpose1d_matches_oracle(cin, cout, k, u, B, T):
     assert (y - ref).abs().max().item() <= 2e-5
 
 
+def test_conv1d_lrelu_on_load_is_exact_at_scale():
+    """Regression: leaky_relu-on-load feeds the hi/lo operand split; hipcc once contracted the scaling
+    multiply into only ONE of the two conversions, leaving rare elements off by 2^-11 (max-abs 3e-5 on a
+    128 k-element tensor while the mean error stayed at fp32 level)."""
+    from hip_helpers import conv_forward
+
+    C, k, d, B, T = 64, 3, 5, 2, 1000
+    w = _rand(C, C, k, seed=1, scale=(C * k) ** -0.5)
+    b = _rand(C, seed=2, scale=0.1)
+    x = _rand(B, C, T, seed=5)
+    pad = (k * d - d) // 2
+    ref = F.leaky_relu(F.conv1d(F.leaky_relu(x.double(), 0.1), w.double(), b.double(), dilation=d, padding=pad), 0.1)
+    y = conv_forward(w, b, x, dilation=d, padding=pad, slope_in=0.1, slope_out=0.1)
+    assert (y.double() - ref).abs().max().item() <= 4e-6
+
+
 @pytest.mark.parametrize("xscale,wscale", [(1e-3, 1.0), (300.0, 1.0), (1.0, 1e-4), (1.0, 50.0), (1e-2, 1e3)])
 def test_conv1d_operand_range(xscale, wscale):
     """The split-f16 path rescales operands by powers of two; results must stay at fp32 level for
