@@ -42,6 +42,10 @@ struct ConvArgs {
     int mode;                   // 0: y = v   1: y = y + v   2: y = (y + v) / div
     float div;
     float acc_scale, inv_scale; // f16x3 only: 16 * 2^s (operand scaling) and its reciprocal
+    // ragged batches: item b's input is valid on [0, lens[b] * len_mul) and reads as zero beyond (every
+    // layer zero-pads at the utterance's OWN end, so a padded batch equals the per-utterance results)
+    const int* lens;            // [B] on the device, or nullptr (all items valid on [0, Tin))
+    int len_mul;
 };
 
 // Arguments of the fused ResBlock-pair kernel (pair_f16x3.hip):
@@ -60,6 +64,8 @@ struct PairArgs {
     float sc1, isc1, sc2, isc2;  // 16 * 2^s operand scaling of each conv and its reciprocal
     int mode;
     float div;
+    const int* lens;           // ragged batches, see ConvArgs
+    int len_mul;
 };
 
 struct ConvPlan {
@@ -83,11 +89,12 @@ hipError_t launch_pair(int k, const PairArgs& a, hipStream_t stream);
 // conv_post: y[b,0,t] = tanh( bias + sum_i sum_j w[i][j] * act_in(x[b,i,t+j-pad]) )   (Cout == 1)
 hipError_t launch_conv_post(const float* x, const float* w_dev /*[Cin*K]*/, const float* bias_dev /*[1] or null*/,
                             float* y, int B, int Cin, int T, int K, float slope_in, int apply_tanh,
-                            hipStream_t stream);
+                            const int* lens, int len_mul, hipStream_t stream);
 
 // Activation1d (anti-aliased Snake); a_dev = alpha (already exp'ed if logscale), invb_dev = 1/(beta+1e-9)
 hipError_t launch_act1d(const float* x, float* y, int B, int C, int T, const float* a_dev, const float* invb_dev,
-                        const float* filt_up12, const float* filt_dn12, hipStream_t stream);
+                        const float* filt_up12, const float* filt_dn12, const int* lens, int len_mul,
+                        hipStream_t stream);
 
 // y[b,c,t] += cond[b,c]   (HiFiGAN_vits `x + self.cond(g)` with g of length 1)
 hipError_t launch_add_channel_bias(float* y, const float* cb, int B, int C, int T, hipStream_t stream);

@@ -8,7 +8,7 @@
 // that, so each f32 operand is split as  v = hi + lo  with hi = f16(v), lo = f16(v - hi)  (22 mantissa
 // bits together) and the product is formed as  Whi*Xhi + Whi*Xlo + Wlo*Xhi  in the f32 accumulator
 // (the dropped Wlo*Xlo term is 2^-22 relative).  End to end through HiFi-GAN V1 this is as close to an
-// fp64 run of the reference as the reference's own fp32 run is (tools/numerics_f16x3.py, tests).
+// fp64 run of the reference as the reference's own fp32 run is (tests/experiments/numerics_f16x3.py, tests).
 //
 //   scaling (all exact powers of two, undone in the epilogue): activations x16 while staging, so that
 //   `lo` of anything >= 2^-7 is a normal f16 and |x| up to 4094 is representable; weights by the
@@ -131,6 +131,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
 
     const float* xb = a.x + (size_t)item * (size_t)a.xbs;
     const int tbase = q0 - a.halo_left;
+    int Tv = a.Tin;                                      // valid input columns of this item (ragged batch)
+    if (a.lens) { const int l = a.lens[item] * a.len_mul; Tv = l < Tv ? l : Tv; }
     const float kpos = 16.f, kneg = 16.f * a.slope_in;  // x16 and leaky_relu-on-load in one multiply
 
     // Staging item = (column, channel quad): 4 global dword loads (lanes = consecutive columns, so
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
             const int qd = ibase / S;
             const int col = ibase - qd * S + lane;
             const int t = tbase + col;
-            const bool tok = (col < a.wd) && (t >= 0) && (t < a.Tin);
+            const bool tok = (col < a.wd) && (t >= 0) && (t < Tv);
             const int ch0 = chunk * KC16 + 4 * qd;
             union { uint2 u; _Float16 h[4]; } fh, fl;
 #pragma unroll

@@ -108,6 +108,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 
     const float* xb = a.x + (size_t)item * (size_t)a.xbs;
     const int tbase = q0 - a.halo_left;
+    int Tv = a.Tin;  // valid input columns of this item (ragged batch)
+    if (a.lens) { const int l = a.lens[item] * a.len_mul; Tv = l < Tv ? l : Tv; }
     const float slope_in = a.slope_in;
 
     float xs[NST];
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
             const int col = idx - row * S;
             const int ch = chunk * KC + row;
             const int t = tbase + col;
-            const bool ok = (idx < KC * S) && (col < a.wd) && (ch < a.Cin) && (t >= 0) && (t < a.Tin);
+            const bool ok = (idx < KC * S) && (col < a.wd) && (ch < a.Cin) && (t >= 0) && (t < Tv);
             float v = 0.f;
             if (ok) v = xb[(size_t)ch * a.Tin + t];
             xs[it] = v;

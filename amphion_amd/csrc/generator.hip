@@ -272,7 +272,8 @@ static int conv_out_len(const amp_conv* c, int T) {
 
 // mode 0: y = v, 1: y += v, 2: y = (y + v) / div
 static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope_in, const float* res, float slope_out,
-                    float* y, int mode, float div, hipStream_t stream, long long xbs = 0) {
+                    float* y, int mode, float div, hipStream_t stream, long long xbs = 0, const int* lens = nullptr,
+                    int len_mul = 1) {
     if (B <= 0 || T <= 0) { set_error("amp_conv_forward: B=%d T=%d", B, T); return AMP_ERR_INVALID; }
     const int Tout = conv_out_len(c, T);
     if (Tout <= 0) { set_error("amp_conv_forward: input too short (T=%d)", T); return AMP_ERR_INVALID; }
@@ -286,6 +287,7 @@ static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope
     a.wd = NT + c->halo_left + c->halo_right;
     a.Cout = c->cout; a.Tout = Tout; a.up = c->up; a.up_pad = c->up_pad;
     a.slope_in = slope_in; a.slope_out = slope_out; a.mode = mode; a.div = div;
+    a.lens = lens; a.len_mul = len_mul;
     if (c->precision == PREC_F32) {
         a.acc_scale = a.inv_scale = 1.f;
         AMP_HIP(launch_conv(c->plan, a, stream));
@@ -310,7 +312,7 @@ static bool pair_supported(const amp_conv* c1, const amp_conv* c2) {
 }
 
 static int pair_run(const amp_conv* c1, const amp_conv* c2, const float* x, int B, int T, float slope, float* y,
-                    int mode, float div, hipStream_t stream) {
+                    int mode, float div, hipStream_t stream, const int* lens = nullptr, int len_mul = 1) {
     if (x == y) { set_error("pair_run: x and y must not alias"); return AMP_ERR_INVALID; }
     PairArgs a{};
     a.x = x; a.y = y;
@@ -323,6 +325,7 @@ static int pair_run(const amp_conv* c1, const amp_conv* c2, const float* x, int 
     a.sc1 = 16.f * c1->wscale; a.isc1 = 1.f / a.sc1;
     a.sc2 = 16.f * c2->wscale; a.isc2 = 1.f / a.sc2;
     a.mode = mode; a.div = div;
+    a.lens = lens; a.len_mul = len_mul;
     AMP_HIP(launch_pair(c1->k, a, stream));
     return AMP_OK;
 }
@@ -733,8 +736,9 @@ int amp_gen_last_timing_ms(amp_gen* g, int which, float* ms_out) {
 #define AMP_RC(expr) do { int rc__ = (expr); if (rc__ != AMP_OK) return rc__; } while (0)
 
 // One group of `B` items through the whole generator (buffers sized for `be` elements each).
-static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond_dev, int B, int T, float* wav_dev,
-                             float* base, size_t be, hipStream_t st, hipEvent_t* ev_mrf /* 2 per stage, or null */) {
+static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond_dev, const int* lens, int B, int T,
+                             float* wav_dev, float* base, size_t be, hipStream_t st,
+                             hipEvent_t* ev_mrf /* 2 per stage, or null */) {
     const amp_gen_desc& d = g->d;
     const bool big = d.arch == AMP_ARCH_BIGVGAN;
     float* X = base;            // stage input / MRF accumulator (ping-pong with XS)
@@ -746,18 +750,20 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
     float* CB = base + (size_t)gen_num_bufs(g) * be;  // cond(g): [B, C0]
     const float slope = 0.1f;  // LRELU_SLOPE hifigan.py:14
 
-    AMP_RC(conv_run(g->conv_pre.get(), mel_dev, B, T, 1.f, nullptr, 1.f, X, 0, 1.f, st));
+    AMP_RC(conv_run(g->conv_pre.get(), mel_dev, B, T, 1.f, nullptr, 1.f, X, 0, 1.f, st, 0, lens, 1));
     if (cond_dev) {  // x = x + self.cond(g), hifigan.py:426-427 (g has length 1 -> per-channel bias)
         AMP_RC(conv_run(g->cond.get(), cond_dev, B, 1, 1.f, nullptr, 1.f, CB, 0, 1.f, st));
         AMP_HIP(launch_add_channel_bias(X, CB, B, d.upsample_initial_channel, T, st));
     }
     int t = T;
+    int lm = 1;  // samples per mel frame at the current stage (ragged batches: valid length = lens[b] * lm)
     const int nk = d.n_kernels;
     for (int i = 0; i < d.n_stages; ++i) {
         const int C = g->ch[i];
         // HiFiGAN: leaky_relu(0.1) before the transposed conv (hifigan.py:206); BigVGAN: none (bigvgan.py:316-318)
-        AMP_RC(conv_run(g->ups[i].get(), X, B, t, big ? 1.f : slope, nullptr, 1.f, U, 0, 1.f, st));
+        AMP_RC(conv_run(g->ups[i].get(), X, B, t, big ? 1.f : slope, nullptr, 1.f, U, 0, 1.f, st, 0, lens, lm));
         t *= d.upsample_rates[i];
+        lm *= d.upsample_rates[i];
         if (ev_mrf) AMP_HIP(hipEventRecord(ev_mrf[2 * i], st));
         for (int j = 0; j < nk; ++j) {
             const ResBlock& rb = g->rbs[(size_t)i * nk + j];
@@ -771,7 +777,7 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
                         // the whole pair in one kernel; the output ping-pongs R <-> TMP (never in place:
                         // other tiles still read the input's halo)
                         float* dst = last ? XS : (cur == R ? TMP : R);
-                        AMP_RC(pair_run(rb.c1[p].get(), rb.c2[p].get(), cur, B, t, slope, dst, last ? mode_last : 0, (float)nk, st));
+                        AMP_RC(pair_run(rb.c1[p].get(), rb.c2[p].get(), cur, B, t, slope, dst, last ? mode_last : 0, (float)nk, st, lens, lm));
                         cur = dst;
                     } else if (!big) {
                         // xt = lrelu(c1(lrelu(x))) ; x = c2(xt) + x        hifigan.py:93-100
@@ -779,18 +785,18 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
                             AMP_HIP(hipMemcpyAsync(R, TMP, (size_t)B * C * t * sizeof(float), hipMemcpyDeviceToDevice, st));
                             cur = R;
                         }
-                        AMP_RC(conv_run(rb.c1[p].get(), cur, B, t, slope, nullptr, slope, TMP, 0, 1.f, st));
-                        if (!last) { AMP_RC(conv_run(rb.c2[p].get(), TMP, B, t, 1.f, cur, 1.f, R, 0, 1.f, st)); cur = R; }
-                        else AMP_RC(conv_run(rb.c2[p].get(), TMP, B, t, 1.f, cur, 1.f, XS, mode_last, (float)nk, st));
+                        AMP_RC(conv_run(rb.c1[p].get(), cur, B, t, slope, nullptr, slope, TMP, 0, 1.f, st, 0, lens, lm));
+                        if (!last) { AMP_RC(conv_run(rb.c2[p].get(), TMP, B, t, 1.f, cur, 1.f, R, 0, 1.f, st, 0, lens, lm)); cur = R; }
+                        else AMP_RC(conv_run(rb.c2[p].get(), TMP, B, t, 1.f, cur, 1.f, XS, mode_last, (float)nk, st, 0, lens, lm));
                     } else {
                         // xt = c2(a2(c1(a1(x)))) ; x = xt + x              bigvgan.py:137-146
                         const ActParams& a1 = rb.acts[2 * p];
                         const ActParams& a2 = rb.acts[2 * p + 1];
-                        AMP_HIP(launch_act1d(cur, ACT, B, C, t, a1.a_dev, a1.invb_dev, a1.fu_dev, a1.fd_dev, st));
-                        AMP_RC(conv_run(rb.c1[p].get(), ACT, B, t, 1.f, nullptr, 1.f, TMP, 0, 1.f, st));
-                        AMP_HIP(launch_act1d(TMP, ACT, B, C, t, a2.a_dev, a2.invb_dev, a2.fu_dev, a2.fd_dev, st));
-                        if (!last) { AMP_RC(conv_run(rb.c2[p].get(), ACT, B, t, 1.f, cur, 1.f, R, 0, 1.f, st)); cur = R; }
-                        else AMP_RC(conv_run(rb.c2[p].get(), ACT, B, t, 1.f, cur, 1.f, XS, mode_last, (float)nk, st));
+                        AMP_HIP(launch_act1d(cur, ACT, B, C, t, a1.a_dev, a1.invb_dev, a1.fu_dev, a1.fd_dev, lens, lm, st));
+                        AMP_RC(conv_run(rb.c1[p].get(), ACT, B, t, 1.f, nullptr, 1.f, TMP, 0, 1.f, st, 0, lens, lm));
+                        AMP_HIP(launch_act1d(TMP, ACT, B, C, t, a2.a_dev, a2.invb_dev, a2.fu_dev, a2.fd_dev, lens, lm, st));
+                        if (!last) { AMP_RC(conv_run(rb.c2[p].get(), ACT, B, t, 1.f, cur, 1.f, R, 0, 1.f, st, 0, lens, lm)); cur = R; }
+                        else AMP_RC(conv_run(rb.c2[p].get(), ACT, B, t, 1.f, cur, 1.f, XS, mode_last, (float)nk, st, 0, lens, lm));
                     }
                 } else {
                     // x = c(act(x)) + x                                    hifigan.py:140-145, bigvgan.py:218-224
@@ -798,17 +804,17 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
                     float sl = slope;
                     if (big) {
                         const ActParams& a1 = rb.acts[p];
-                        AMP_HIP(launch_act1d(cur, ACT, B, C, t, a1.a_dev, a1.invb_dev, a1.fu_dev, a1.fd_dev, st));
+                        AMP_HIP(launch_act1d(cur, ACT, B, C, t, a1.a_dev, a1.invb_dev, a1.fu_dev, a1.fd_dev, lens, lm, st));
                         in = ACT;
                         sl = 1.f;
                     }
                     if (!last) {
                         // the conv reads a halo of `in`; never write the tensor it is reading
                         float* dst = (in == cur && cur == R) ? TMP : R;
-                        AMP_RC(conv_run(rb.c1[p].get(), in, B, t, sl, cur, 1.f, dst, 0, 1.f, st));
+                        AMP_RC(conv_run(rb.c1[p].get(), in, B, t, sl, cur, 1.f, dst, 0, 1.f, st, 0, lens, lm));
                         cur = dst;
                     } else {
-                        AMP_RC(conv_run(rb.c1[p].get(), in, B, t, sl, cur, 1.f, XS, mode_last, (float)nk, st));
+                        AMP_RC(conv_run(rb.c1[p].get(), in, B, t, sl, cur, 1.f, XS, mode_last, (float)nk, st, 0, lens, lm));
                     }
                 }
             }
@@ -817,17 +823,22 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
         float* tmp = X; X = XS; XS = tmp;  // x = xs / num_kernels
     }
     if (big) {
-        AMP_HIP(launch_act1d(X, ACT, B, g->post_cin, t, g->act_post.a_dev, g->act_post.invb_dev, g->act_post.fu_dev, g->act_post.fd_dev, st));
-        AMP_HIP(launch_conv_post(ACT, g->post_w_dev, g->post_b_dev, wav_dev, B, g->post_cin, t, 7, 1.f, 1, st));
+        AMP_HIP(launch_act1d(X, ACT, B, g->post_cin, t, g->act_post.a_dev, g->act_post.invb_dev, g->act_post.fu_dev, g->act_post.fd_dev, lens, lm, st));
+        AMP_HIP(launch_conv_post(ACT, g->post_w_dev, g->post_b_dev, wav_dev, B, g->post_cin, t, 7, 1.f, 1, lens, lm, st));
     } else {
         // F.leaky_relu(x) with the DEFAULT slope 0.01 (hifigan.py:215,439), conv_post, tanh
-        AMP_HIP(launch_conv_post(X, g->post_w_dev, g->post_b_dev, wav_dev, B, g->post_cin, t, 7, 0.01f, 1, st));
+        AMP_HIP(launch_conv_post(X, g->post_w_dev, g->post_b_dev, wav_dev, B, g->post_cin, t, 7, 0.01f, 1, lens, lm, st));
     }
     return AMP_OK;
 }
 
 int amp_gen_forward(amp_gen* g, const float* mel_dev, const float* cond_dev, int B, int T, float* wav_dev,
                     void* workspace_dev, size_t workspace_bytes, void* stream_) {
+    return amp_gen_forward_ragged(g, mel_dev, cond_dev, nullptr, B, T, wav_dev, workspace_dev, workspace_bytes, stream_);
+}
+
+int amp_gen_forward_ragged(amp_gen* g, const float* mel_dev, const float* cond_dev, const int32_t* lens_dev, int B, int T,
+                           float* wav_dev, void* workspace_dev, size_t workspace_bytes, void* stream_) {
     if (!g || !mel_dev || !wav_dev || !workspace_dev) { set_error("amp_gen_forward: null argument"); return AMP_ERR_INVALID; }
     if (!g->finalized) { set_error("amp_gen_forward: call amp_gen_finalize first"); return AMP_ERR_STATE; }
     if (B <= 0 || T <= 0) { set_error("amp_gen_forward: B=%d T=%d", B, T); return AMP_ERR_INVALID; }
@@ -853,7 +864,8 @@ int amp_gen_forward(amp_gen* g, const float* mel_dev, const float* cond_dev, int
         const int b0 = gi * G;
         const int Bg = (B - b0) < G ? (B - b0) : G;
         AMP_RC(gen_forward_group(g, mel_dev + (size_t)b0 * d.n_in * T,
-                                 cond_dev ? cond_dev + (size_t)b0 * d.gin_channels : nullptr, Bg, T,
+                                 cond_dev ? cond_dev + (size_t)b0 * d.gin_channels : nullptr,
+                                 lens_dev ? lens_dev + b0 : nullptr, Bg, T,
                                  wav_dev + (size_t)b0 * L, (float*)workspace_dev, be, st,
                                  g->profiling ? g->ev_mrf.data() + 2 * (size_t)d.n_stages * gi : nullptr));
     }
@@ -969,7 +981,7 @@ int amp_antialias_snake(const float* x_dev, int B, int C, int T, const float* al
     if (e == hipSuccess) e = hipMemcpy(scratch + C, ib.data(), C * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(scratch + 2 * C, filt_up_host, 12 * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(scratch + 2 * C + 12, filt_down_host, 12 * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = launch_act1d(x_dev, y_dev, B, C, T, scratch, scratch + C, scratch + 2 * C, scratch + 2 * C + 12, (hipStream_t)stream);
+    if (e == hipSuccess) e = launch_act1d(x_dev, y_dev, B, C, T, scratch, scratch + C, scratch + 2 * C, scratch + 2 * C + 12, nullptr, 1, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     (void)hipFree(scratch);
     if (e != hipSuccess) { set_error("amp_antialias_snake: %s", hipGetErrorString(e)); return AMP_ERR_HIP; }

@@ -64,6 +64,8 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairArgs a) {
     const int q0 = tile * NT;                 // first output column
     const int C = 32 * WM;
     const int T = a.T;
+    int Tv = T;                               // valid columns of this item (ragged batch)
+    if (a.lens) { const int l = a.lens[item] * a.len_mul; Tv = l < Tv ? l : Tv; }
     const int dil = a.dil;
     const int h1 = H2 * dil;
 
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairArgs a) {
             const int qd = ibase / SX;
             const int col = ibase - qd * SX + lane;
             const int t = tbase + col;
-            const bool tok = (t >= 0) && (t < T);
+            const bool tok = (t >= 0) && (t < Tv);
             union { uint2 u; _Float16 h[4]; } fh, fl;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairArgs a) {
         for (int t = 0; t < NI; ++t) {
             const int col = colw + 32 * t;                   // xt column (tile-local)
             const int q = q0 - H2 + col;                     // its global column
-            const bool qok = (q >= 0) && (q < T);            // conv2 zero-pads xt outside [0, T)
+            const bool qok = (q >= 0) && (q < Tv);           // conv2 zero-pads xt outside the utterance
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 union { uint2 u; _Float16 h[4]; } fh, fl;

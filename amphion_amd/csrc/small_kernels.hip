@@ -15,7 +15,8 @@ constexpr int CP_S = CP_TT + 16;
 
 __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y,
-                                                         int Cin, int T, int K, float slope_in, int apply_tanh) {
+                                                         int Cin, int T, int K, float slope_in, int apply_tanh,
+                                                         const int* __restrict__ lens, int len_mul) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xl = smem;                 // [8][CP_S]
     float* wl = smem + 8 * CP_S;      // [Cin*K]
@@ -23,6 +24,8 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict_
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * CP_TT;
     const int pad = (K - 1) / 2;
+    int Tv = T;  // valid columns of this item (ragged batch)
+    if (lens) { const int l = lens[b] * len_mul; Tv = l < Tv ? l : Tv; }
     for (int i = tid; i < Cin * K; i += 256) wl[i] = w[i];
     float acc[4];
     const float b0 = bias ? bias[0] : 0.f;
@@ -36,7 +39,7 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict_
             const int t = t0 - pad + col;
             const int ch = c0 + row;
             float v = 0.f;
-            if (ch < Cin && t >= 0 && t < T) v = xb[(size_t)ch * T + t];
+            if (ch < Cin && t >= 0 && t < Tv) v = xb[(size_t)ch * T + t];
             xl[idx] = v > 0.f ? v : v * slope_in;
         }
         __syncthreads();
@@ -67,13 +70,14 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict_
 }
 
 hipError_t launch_conv_post(const float* x, const float* w_dev, const float* bias_dev, float* y, int B, int Cin,
-                            int T, int K, float slope_in, int apply_tanh, hipStream_t stream) {
+                            int T, int K, float slope_in, int apply_tanh, const int* lens, int len_mul,
+                            hipStream_t stream) {
     if (K > 9 || K < 1 || (K & 1) == 0) return hipErrorInvalidValue;
     const size_t lds = (size_t)(8 * CP_S + Cin * K) * sizeof(float);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     dim3 grid((unsigned)((T + CP_TT - 1) / CP_TT), (unsigned)B);
     hipLaunchKernelGGL(conv_post_kernel, grid, dim3(256), lds, stream, x, w_dev, bias_dev, y, Cin, T, K, slope_in,
-                       apply_tanh);
+                       apply_tanh, lens, len_mul);
     return hipGetLastError();
 }
 
@@ -89,25 +93,31 @@ constexpr int A1_TT = 1024;
 __global__ __launch_bounds__(256) void act1d_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int T,
                                                     const float* __restrict__ a_dev,
                                                     const float* __restrict__ invb_dev, const float* __restrict__ fu,
-                                                    const float* __restrict__ fd) {
+                                                    const float* __restrict__ fd, const int* __restrict__ lens,
+                                                    int len_mul) {
     __shared__ float xl[A1_TT + 12];
     __shared__ float sl[2 * A1_TT + 12];
     __shared__ float ful[12], fdl[12];
     const int tid = threadIdx.x;
-    const int ntiles = (T + A1_TT - 1) / A1_TT;
+    const int ntiles = (T + A1_TT - 1) / A1_TT;   // T = row stride (padded length)
     const int bc = blockIdx.x / ntiles;
     const int c = bc % C;
     const int t0 = (blockIdx.x - bc * ntiles) * A1_TT;
+    // Tv = the utterance's own length: the replicate padding (resample.py:36-45, filter.py:92-99) clamps to
+    // ITS last sample, so a padded batch equals the per-utterance results
+    int Tv = T;
+    if (lens) { const int l = lens[bc / C] * len_mul; Tv = l < Tv ? l : Tv; }
+    if (t0 >= Tv) return;                          // nothing valid in this tile (block-uniform)
     const float a = a_dev[c], invb = invb_dev[c];
     const float* xr = x + (size_t)bc * T;
     if (tid < 12) { ful[tid] = fu[tid]; fdl[tid] = fd[tid]; }
     for (int i = tid; i < A1_TT + 12; i += 256) {
         int t = t0 - 6 + i;
-        t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+        t = t < 0 ? 0 : (t > Tv - 1 ? Tv - 1 : t);
         xl[i] = xr[t];
     }
     __syncthreads();
-    const int twoT = 2 * T;
+    const int twoT = 2 * Tv;
     for (int i = tid; i < 2 * A1_TT + 11; i += 256) {
         int n = 2 * t0 + i - 5;
         n = n < 0 ? 0 : (n > twoT - 1 ? twoT - 1 : n);
@@ -118,7 +128,7 @@ __global__ __launch_bounds__(256) void act1d_kernel(const float* __restrict__ x,
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             int xi = mmax - k - 5;  // index into x before clamping
-            xi = xi < 0 ? 0 : (xi > T - 1 ? T - 1 : xi);
+            xi = xi < 0 ? 0 : (xi > Tv - 1 ? Tv - 1 : xi);
             u = fmaf(xl[xi - (t0 - 6)], ful[par + 2 * k], u);
         }
         u *= 2.f;
@@ -129,7 +139,7 @@ __global__ __launch_bounds__(256) void act1d_kernel(const float* __restrict__ x,
     float* yr = y + (size_t)bc * T;
     for (int k = tid; k < A1_TT; k += 256) {
         const int t = t0 + k;
-        if (t < T) {
+        if (t < Tv) {
             float acc = 0.f;
 #pragma unroll
             for (int j = 0; j < 12; ++j) acc = fmaf(fdl[j], sl[2 * k + j], acc);
@@ -139,9 +149,11 @@ __global__ __launch_bounds__(256) void act1d_kernel(const float* __restrict__ x,
 }
 
 hipError_t launch_act1d(const float* x, float* y, int B, int C, int T, const float* a_dev, const float* invb_dev,
-                        const float* filt_up12, const float* filt_dn12, hipStream_t stream) {
+                        const float* filt_up12, const float* filt_dn12, const int* lens, int len_mul,
+                        hipStream_t stream) {
     dim3 grid((unsigned)(((T + A1_TT - 1) / A1_TT) * (size_t)(B * C)));
-    hipLaunchKernelGGL(act1d_kernel, grid, dim3(256), 0, stream, x, y, C, T, a_dev, invb_dev, filt_up12, filt_dn12);
+    hipLaunchKernelGGL(act1d_kernel, grid, dim3(256), 0, stream, x, y, C, T, a_dev, invb_dev, filt_up12, filt_dn12,
+                       lens, len_mul);
     return hipGetLastError();
 }
 

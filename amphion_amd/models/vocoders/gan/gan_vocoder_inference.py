@@ -2,11 +2,8 @@
 
 ``vocoder_inference`` is the reference's batched forward wrapper (:11-38).  ``synthesis_audios``
 keeps the reference contract (:41-96: list of [n_mel, T_i] mels -> list of [T_i * hop] audios) but
-runs each padded batch through the generator ONCE instead of one utterance at a time; the crop to
-``frame * hop`` is the reference's.  Because every conv zero-pads its own input, an utterance that
-sits in a zero-padded batch differs from its B=1 result only within the receptive field of the tail;
-``exact=True`` (default) therefore groups utterances of equal length and falls back to per-length
-batches so results are identical to the reference's per-utterance loop.
+runs each padded batch through the generator ONCE (``forward_ragged``: the kernels pad every layer at
+each utterance's own end) instead of one utterance at a time, with identical results.
 """
 import torch
 
@@ -30,25 +27,35 @@ def vocoder_inference(cfg, model, mels, f0s=None, device=None, fast_inference=Fa
 
 
 def synthesis_audios(cfg, model, mels, f0s=None, batch_size=None, fast_inference=False, exact=True):
-    """gan_vocoder_inference.py:41-96."""
+    """gan_vocoder_inference.py:41-96: list of [n_mel, T_i] mels -> list of [T_i * hop] audios.
+
+    ``exact=True`` (default): utterances are sorted by length, zero-padded into batches of ``batch_size``
+    and run through ``forward_ragged`` -- every kernel pads at each utterance's own end, so each audio is
+    bit-identical to the reference's one-utterance-at-a-time loop while the GPU sees true batches.
+    ``exact=False`` is the reference's *batched* behaviour (`pad_mels_to_tensors` + crop): utterances
+    shorter than their batch differ from their B=1 result inside the receptive field of the tail.
+    """
     device = next(model.parameters()).device
     if f0s is not None:
         raise NotImplementedError("f0-conditioned generators (NSF-HiFiGAN) are outside the HiFi-GAN/BigVGAN hot path")
     hop = model.cfg.preprocess.hop_size
     audios = [None] * len(mels)
     if exact:
-        # one true batch per distinct length: bit-identical to the reference's B=1 loop
-        by_len = {}
-        for i, m in enumerate(mels):
-            by_len.setdefault(int(m.shape[-1]), []).append(i)
-        for T, idxs in by_len.items():
-            step = len(idxs) if batch_size is None else batch_size
-            for s in range(0, len(idxs), step):
-                grp = idxs[s:s + step]
-                batch = torch.stack([torch.as_tensor(mels[i]) for i in grp])
-                out = vocoder_inference(cfg, model, batch, device=device, fast_inference=fast_inference)
+        order = sorted(range(len(mels)), key=lambda i: int(mels[i].shape[-1]), reverse=True)
+        step = len(order) if not batch_size else int(batch_size)
+        model.eval()
+        with torch.no_grad():
+            for s in range(0, len(order), step):
+                grp = order[s:s + step]
+                lens = [int(mels[i].shape[-1]) for i in grp]
+                Tmax = lens[0]
+                n_mel = int(mels[grp[0]].shape[0])
+                batch = torch.zeros((len(grp), n_mel, Tmax), dtype=torch.float32)
                 for r, i in enumerate(grp):
-                    audios[i] = out[r][: T * hop]
+                    batch[r, :, : lens[r]] = torch.as_tensor(mels[i], dtype=torch.float32)
+                out = model.forward_ragged(batch.to(device), lens).squeeze(1).cpu()
+                for r, i in enumerate(grp):
+                    audios[i] = out[r, : lens[r] * hop].clone()
         return audios
     mel_batches, mel_frames = pad_mels_to_tensors(mels, batch_size)
     k = 0

@@ -185,7 +185,7 @@ class HipGenerator(nn.Module):
         self._amp_handle, self._amp_finalizer, self._amp_sig, self._amp_device = h, fin, sig, device
         return h
 
-    def _amp_forward(self, x, g=None):
+    def _amp_forward(self, x, g=None, lengths=None):
         x = _lib.require_device_tensor(x, "generator input")
         if x.dim() != 3:
             raise ValueError(f"expected [B, C, T] input, got {tuple(x.shape)}")
@@ -204,6 +204,13 @@ class HipGenerator(nn.Module):
             if g.dim() != 3 or g.shape[0] != B or g.shape[2] != 1:
                 raise ValueError(f"g must be [B, gin_channels, 1], got {tuple(g.shape)}")
             cond_ptr = ctypes.c_void_p(g.data_ptr())
+        lens_ptr = None
+        if lengths is not None:
+            lengths = torch.as_tensor(lengths)
+            if lengths.numel() != B or int(lengths.max()) > T or int(lengths.min()) < 1:
+                raise ValueError(f"lengths must hold B={B} values in [1, {T}]")
+            lengths = lengths.to(device=dev, dtype=torch.int32).contiguous()
+            lens_ptr = ctypes.c_void_p(lengths.data_ptr())
         hop = L.amp_gen_hop(h)
         need = L.amp_gen_workspace_bytes(h, B, T)
         if self._amp_ws is None or self._amp_ws.numel() < need or self._amp_ws.device != dev:
@@ -211,10 +218,18 @@ class HipGenerator(nn.Module):
             self._amp_ws = torch.empty(need, dtype=torch.uint8, device=dev)
         out = torch.empty((B, 1, T * hop), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(L.amp_gen_forward(h, ctypes.c_void_p(x.data_ptr()), cond_ptr, B, T,
-                                         ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(self._amp_ws.data_ptr()),
-                                         self._amp_ws.numel(), _lib.current_stream_ptr(dev)))
+            _lib.check(L.amp_gen_forward_ragged(h, ctypes.c_void_p(x.data_ptr()), cond_ptr, lens_ptr, B, T,
+                                                ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(self._amp_ws.data_ptr()),
+                                                self._amp_ws.numel(), _lib.current_stream_ptr(dev)))
         return out
+
+    def forward_ragged(self, x, lengths, g=None):
+        """A zero-padded batch of utterances of different lengths in ONE forward: item b holds
+        ``lengths[b]`` valid frames; ``out[b, 0, : lengths[b] * hop]`` is bit-identical to running that
+        utterance alone (every layer pads at the utterance's own end), the tail beyond it is unspecified.
+        This is what lets ``synthesis_audios`` replace the reference's B=1 loop
+        (gan_vocoder_inference.py:74-96) by true batches without changing results."""
+        return self._amp_forward(x, g, lengths=lengths)
 
     # ---- profiling hooks used by bench.py ----
     def set_profiling(self, enabled=True):

@@ -39,33 +39,39 @@ PRECISIONS = {
 }
 
 
-def build_model(device):
-    from amphion_amd.models.vocoders.gan.generator.hifigan import HiFiGAN
-    from oracle import synth
-    from oracle import vocoder_oracle as vo
+# HiFi-GAN V1 hyper-parameters (reference config/vits.json:36-71)
+HIFIGAN_V1 = dict(resblock="1", upsample_rates=[8, 8, 2, 2], upsample_kernel_sizes=[16, 16, 4, 4],
+                  upsample_initial_channel=512, resblock_kernel_sizes=[3, 7, 11],
+                  resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]])
 
-    hp = vo.hifigan_v1_hp()
+
+def build_model(device):
+    """The product path only: amphion_amd module + seeded random-init weights (no checkpoints offline)."""
+    from amphion_amd.models.vocoders.gan.generator.hifigan import HiFiGAN
+    from amphion_amd.utils.synthetic import randomize_
+
+    hp = dict(HIFIGAN_V1)
     cfg = NS(preprocess=NS(n_mel=N_MEL, hop_size=256, sample_rate=SAMPLE_RATE), model=NS(hifigan=NS(**hp)))
-    model = HiFiGAN(cfg)
-    sd = synth.synth_state_dict(synth.hifigan_param_shapes(N_MEL, hp), 1234)
-    model.load_state_dict(sd)
+    model = randomize_(HiFiGAN(cfg), 1234)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}   # CPU copy for the cpu_baseline leg
     return model.to(device).eval(), sd, hp
 
 
 def cpu_baseline(sd, hp, budget_s=20.0):
-    """Reference CPU path (oracle = the reference's own torch ops) on the host cores, bounded sample."""
-    from oracle import synth
+    """Reference CPU path (oracle = the reference's own torch ops) on the host cores, bounded sample.
+    The ONLY place bench.py touches oracle/."""
+    from amphion_amd.utils.synthetic import synthetic_mel
     from oracle import vocoder_oracle as vo
 
     # torch's CPU convs collapse when oversubscribed on the 2 x EPYC 9575F GPU host (measured with
-    # tools/cpu_threads_sweep.py at B=4,T=256: 8 thr x5.3 RT, 16 thr x6.7, 32 thr x4.3, 64 thr x2.4,
+    # tests/experiments/cpu_threads_sweep.py at B=4,T=256: 8 thr x5.3 RT, 16 thr x6.7, 32 thr x4.3, 64 thr x2.4,
     # 128 thr x1.3, 256 thr x0.17); 16 threads is the best, so that is the baseline we report.
     cores = min(os.cpu_count() or 1, int(os.environ.get("AMP_CPU_BASELINE_THREADS", "16")))
     torch.set_num_threads(cores)
     with torch.no_grad():
-        vo.hifigan_forward(sd, hp, synth.synth_mel(1, N_MEL, 32, seed=1))  # warm-up
+        vo.hifigan_forward(sd, hp, synthetic_mel(1, N_MEL, 32, seed=1))  # warm-up
         B, T = 4, T_FRAMES
-        mel = synth.synth_mel(B, N_MEL, T, seed=2)
+        mel = synthetic_mel(B, N_MEL, T, seed=2)
         t0 = time.perf_counter()
         reps = 0
         while True:
@@ -111,13 +117,13 @@ def main():
 
     from amphion_amd import _lib
     from amphion_amd.distributed import gather_audio
-    from oracle import synth
+    from amphion_amd.utils.synthetic import synthetic_mel
 
     _lib.set_precision(args.precision)
     dtype_str, peak_tflops, peak_note = PRECISIONS[args.precision]
 
     model, sd, hp = build_model(device)
-    mel = synth.synth_mel(B_PER_GPU, N_MEL, T_FRAMES, seed=rank).to(device)  # resident in HBM before timing
+    mel = synthetic_mel(B_PER_GPU, N_MEL, T_FRAMES, seed=rank).to(device)  # resident in HBM before timing
     L = T_FRAMES * model.hop_factor
     total_items = B_PER_GPU * world
 

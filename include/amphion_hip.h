@@ -126,6 +126,14 @@ int amp_set_group_mb(int megabytes);
 int amp_gen_forward(amp_gen* g, const float* mel_dev, const float* cond_dev, int B, int T, float* wav_dev,
                     void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* Ragged batch: item b holds lens_dev[b] <= T valid mel frames (int32, device) inside the zero-padded
+ * [B, n_in, T] input.  Every layer then pads at the utterance's OWN end (zero padding of the convs,
+ * replicate padding of the anti-aliased activations), so wav[b, : lens[b] * hop] is bit-identical to
+ * running that utterance alone (the reference's per-utterance loop, gan_vocoder_inference.py:74-96);
+ * samples beyond it are unspecified.  lens_dev == NULL is amp_gen_forward. */
+int amp_gen_forward_ragged(amp_gen* g, const float* mel_dev, const float* cond_dev, const int32_t* lens_dev, int B,
+                           int T, float* wav_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* Duration [ms] of the kernels of the LAST amp_gen_forward on this handle, measured with HIP events
  * recorded on the launch stream when profiling is on.  which: 0 = whole forward, 1 = MRF conv stack
  * (all ResBlock/AMPBlock convs), 2 + i = the MRF convs of upsampling stage i.  Synchronises on the events.

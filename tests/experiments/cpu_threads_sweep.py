@@ -1,6 +1,6 @@
 """Times the CPU oracle (reference torch ops) at several thread counts on this host."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import synth, vocoder_oracle as vo
 

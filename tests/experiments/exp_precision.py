@@ -1,6 +1,6 @@
 """GPU experiment: where does the f16x3 conv's error come from? (single conv + fused pair, vs fp64)"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch, torch.nn.functional as F
 from amphion_amd import _lib

@@ -1,7 +1,7 @@
 """CPU emulation of the split-f16 (3 x f16 MFMA, f32 accumulate) operand rounding, end to end through
 HiFi-GAN V1, against an fp64 run of the oracle.  Design-time experiment for conv_f16x3.hip."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, torch.nn.functional as F
 from oracle import synth, vocoder_oracle as vo
 

@@ -51,3 +51,35 @@ def test_vocoder_inference_and_synthesis_audios(tmp_path):
     auds3 = vi.synthesis(cfg, str(tmp_path / "g.pt"), None, pred, batch_size=64)
     for a, b in zip(auds, auds3):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("arch", ["hifigan", "bigvgan"])
+def test_forward_ragged_is_bit_identical_to_per_utterance_forward(arch):
+    """amp_gen_forward_ragged: every kernel pads at each utterance's own end, so a zero-padded batch gives
+    exactly the audio of the reference's one-utterance-at-a-time loop (gan_vocoder_inference.py:74-96)."""
+    hp = vo.hifigan_v1_hp() if arch == "hifigan" else vo.bigvgan_base_hp()
+    if arch == "hifigan":
+        from amphion_amd.models.vocoders.gan.generator.hifigan import HiFiGAN as Net
+        n_mel = 80
+        sd = synth.synth_state_dict(synth.hifigan_param_shapes(n_mel, hp), 1234)
+        cfg = NS(preprocess=NS(n_mel=n_mel, hop_size=256), model=NS(hifigan=NS(**hp)))
+    else:
+        from amphion_amd.models.vocoders.gan.generator.bigvgan import BigVGAN as Net
+        n_mel = 100
+        sd = synth.synth_state_dict(synth.bigvgan_param_shapes(n_mel, hp), 1234, g_gain=0.75)
+        cfg = NS(preprocess=NS(n_mel=n_mel, hop_size=256), model=NS(bigvgan=NS(**hp)))
+    m = Net(cfg)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    lens = [23, 7, 1, 16, 23]
+    mels = [synth.synth_mel(1, n_mel, T, seed=40 + i)[0] for i, T in enumerate(lens)]
+    batch = torch.zeros(len(lens), n_mel, max(lens))
+    for i, (mel, T) in enumerate(zip(mels, lens)):
+        batch[i, :, :T] = mel
+    with torch.no_grad():
+        out = m.forward_ragged(batch.cuda(), lens).cpu()
+        for i, (mel, T) in enumerate(zip(mels, lens)):
+            solo = m(mel.unsqueeze(0).cuda()).cpu()
+            assert torch.equal(out[i, 0, : T * 256], solo[0, 0]), (arch, i, T)
+    with pytest.raises(ValueError):
+        m.forward_ragged(batch.cuda(), [23, 7, 0, 16, 24])

@@ -15,8 +15,11 @@ REPO=$PWD
 ( cd /tmp && timeout 600 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $REPO/$OUT/pmc_fetch -o pf -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $REPO/$OUT/pmc_fetch.err )
 ( cd /tmp && timeout 600 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $REPO/$OUT/pmc_write -o pw -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $REPO/$OUT/pmc_write.err )
 # keep only the small summaries
-find $OUT -name '*.db' -delete 2>/dev/null
-du -sh $OUT
+
+
 tail -12 $OUT/pytest_gpu.txt
 cat $OUT/conv_bench.csv; tail -3 $OUT/conv_bench.err
 cat $OUT/bench.json
+# SQ counter pass over one bench step (MFMA busy / stall split per kernel)
+( cd /tmp && timeout 600 rocprofv3 --output-format csv --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $REPO/$OUT/pmc_sq -o sq -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> $REPO/$OUT/pmc_sq.err )
+find $OUT -name "*.db" -delete 2>/dev/null; du -sh $OUT

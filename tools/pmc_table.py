@@ -5,10 +5,10 @@ rows = collections.OrderedDict()
 for path in sys.argv[1:]:
     with open(path) as f:
         for r in csv.DictReader(f):
-            if "conv" not in r["Kernel_Name"]:
+            if "conv" not in r["Kernel_Name"] and "pair" not in r["Kernel_Name"]:
                 continue
             key = (int(r["Dispatch_Id"]))
-            d = rows.setdefault(key, {"kernel": r["Kernel_Name"].replace("void amp::", "").replace("(amp::ConvArgs)", "").replace(", ", "."), "grid": r["Grid_Size"],
+            d = rows.setdefault(key, {"kernel": r["Kernel_Name"].replace("void amp::", "").replace("(amp::ConvArgs)", "").replace("(amp::PairArgs)", "").replace(", ", "."), "grid": r["Grid_Size"],
                                       "us": (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3, "vgpr": r["VGPR_Count"], "lds": r["LDS_Block_Size"]})
             d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
 names = []
