@@ -99,6 +99,102 @@ hipError_t launch_mel(const amp_mel_desc& d, const float* wav, int B, int L, int
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Inverse STFT (utils/stft.py:183-222, STFT.inverse): the reference runs conv_transpose1d with the
+// windowed pseudo-inverse Fourier basis [2*(n_fft/2+1), 1, n_fft], divides by the window-sum-square
+// envelope and crops n_fft/2 per side.  pinv of the stacked [Re; Im] real-DFT matrix is the inverse real
+// FFT (Im X_0 and Im X_{N/2} have all-zero basis rows and drop out), so:
+//   frame_f[n] = irfft(mag_f * e^{i phase_f})[n] * window[n] * hop/n_fft        (kernel 1, FFT in LDS)
+//   out[m]     = (n_fft/hop) * sum_f frame_f[m - f*hop] / wss[m]   where wss[m] > tiny      (kernel 2)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void istft_frames_kernel(const float* __restrict__ mag, const float* __restrict__ phase,
+                                                           int F, int n_fft, int log2n, float inv_scale,
+                                                           const float* __restrict__ window, float* __restrict__ frames) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float2* buf0 = reinterpret_cast<float2*>(smem);   // [n_fft]
+    float2* buf1 = buf0 + n_fft;                      // [n_fft]
+    float2* tw = buf1 + n_fft;                        // [n_fft/2]  exp(-2*pi*i*m/n_fft)
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / F;
+    const int f = blockIdx.x - b * F;
+    const int half = n_fft >> 1;
+    const int bins = half + 1;
+    // ifft(X) = conj(fft(conj(X))) / N with the Hermitian extension X[N-k] = conj(X[k])
+    for (int k = tid; k < bins; k += 256) {
+        const size_t o = ((size_t)b * bins + k) * F + f;
+        const float m = mag[o];
+        float sn, cs;
+        sincosf(phase[o], &sn, &cs);
+        const float re = m * cs;
+        const float im = (k == 0 || k == half) ? 0.f : m * sn;
+        buf0[k] = make_float2(re, -im);
+        if (k > 0 && k < half) buf0[n_fft - k] = make_float2(re, im);
+    }
+    for (int m = tid; m < half; m += 256) {
+        float sn, cs;
+        sincospif(-2.0f * (float)m / (float)n_fft, &sn, &cs);
+        tw[m] = make_float2(cs, sn);
+    }
+    __syncthreads();
+    float2* in = buf0;
+    float2* out = buf1;
+    for (int s = 0; s < log2n; ++s) {
+        const int Ns = 1 << s;
+        const int tstride = half >> s;
+        for (int j = tid; j < half; j += 256) {
+            const int k = j & (Ns - 1);
+            const float2 w = tw[k * tstride];
+            const float2 v0 = in[j];
+            const float2 x1 = in[j + half];
+            const float2 v1 = make_float2(x1.x * w.x - x1.y * w.y, x1.x * w.y + x1.y * w.x);
+            const int j0 = ((j - k) << 1) + k;
+            out[j0] = make_float2(v0.x + v1.x, v0.y + v1.y);
+            out[j0 + Ns] = make_float2(v0.x - v1.x, v0.y - v1.y);
+        }
+        __syncthreads();
+        float2* t = in; in = out; out = t;
+    }
+    const float sc = inv_scale / (float)n_fft;
+    float* fr = frames + ((size_t)b * F + f) * n_fft;
+    for (int n = tid; n < n_fft; n += 256) fr[n] = in[n].x * sc * window[n];
+}
+
+__global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict__ frames, const float* __restrict__ wss,
+                                                        int F, int n_fft, int hop, int Lout, float scale, float tiny,
+                                                        float* __restrict__ wav) {
+    const int b = blockIdx.y;
+    const int mo = blockIdx.x * 256 + threadIdx.x;
+    if (mo >= Lout) return;
+    const int m = mo + (n_fft >> 1);
+    int f0 = (m - n_fft + hop) / hop;          // ceil((m - n_fft + 1) / hop) for m - n_fft + 1 > 0
+    if (m - n_fft + 1 <= 0) f0 = 0;
+    int f1 = m / hop;
+    if (f1 > F - 1) f1 = F - 1;
+    const float* fb = frames + (size_t)b * F * n_fft;
+    float acc = 0.f;
+    for (int f = f0; f <= f1; ++f) acc += fb[(size_t)f * n_fft + (m - f * hop)];
+    const float w = wss[m];
+    if (w > tiny) acc /= w;
+    wav[(size_t)b * Lout + mo] = acc * scale;
+}
+
+hipError_t launch_istft(const amp_mel_desc& d, const float* mag, const float* phase, int B, int F, const float* window,
+                        const float* wss, float* frames, float* wav, hipStream_t stream) {
+    int log2n = 0;
+    while ((1 << log2n) < d.n_fft) ++log2n;
+    const size_t lds = (size_t)(2 * d.n_fft + d.n_fft / 2) * sizeof(float2);
+    const float scale = (float)d.n_fft / (float)d.hop_size;
+    hipLaunchKernelGGL(istft_frames_kernel, dim3((unsigned)((size_t)B * F)), dim3(256), lds, stream, mag, phase, F, d.n_fft,
+                       log2n, 1.0f / scale, window, frames);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int Lout = d.hop_size * (F - 1);
+    if (Lout <= 0) return hipSuccess;
+    hipLaunchKernelGGL(istft_ola_kernel, dim3((unsigned)((Lout + 255) / 256), (unsigned)B), dim3(256), 0, stream, frames, wss, F,
+                       d.n_fft, d.hop_size, Lout, scale, 1.17549435e-38f, wav);
+    return hipGetLastError();
+}
+
 }  // namespace amp
 
 using namespace amp;
@@ -129,6 +225,19 @@ int amp_mel_forward(const amp_mel_desc* d, const float* wav_dev, int B, int L, c
     if (F <= 0) { set_error("amp_mel_forward: no frames for L=%d", L); return AMP_ERR_INVALID; }
     hipError_t e = launch_mel(*d, wav_dev, B, L, F, window_dev, melbasis_dev, mel_dev, mag_dev, re_dev, im_dev, (hipStream_t)stream);
     if (e != hipSuccess) { set_error("amp_mel_forward: %s", hipGetErrorString(e)); return AMP_ERR_HIP; }
+    return AMP_OK;
+}
+
+int amp_istft_forward(const amp_mel_desc* d, const float* mag_dev, const float* phase_dev, int B, int F,
+                      const float* window_dev, const float* wss_dev, float* frames_ws_dev, float* wav_dev, void* stream) {
+    if (!d || !mag_dev || !phase_dev || !window_dev || !wss_dev || !frames_ws_dev || !wav_dev) { set_error("amp_istft_forward: null argument"); return AMP_ERR_INVALID; }
+    if (d->n_fft < 64 || d->n_fft > 4096 || (d->n_fft & (d->n_fft - 1)) != 0) {
+        set_error("amp_istft_forward: n_fft=%d must be a power of two in [64, 4096]", d->n_fft);
+        return AMP_ERR_UNSUPPORTED;
+    }
+    if (d->hop_size <= 0 || d->hop_size > d->n_fft || B <= 0 || F <= 1) { set_error("amp_istft_forward: hop=%d B=%d F=%d", d->hop_size, B, F); return AMP_ERR_INVALID; }
+    hipError_t e = launch_istft(*d, mag_dev, phase_dev, B, F, window_dev, wss_dev, frames_ws_dev, wav_dev, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("amp_istft_forward: %s", hipGetErrorString(e)); return AMP_ERR_HIP; }
     return AMP_OK;
 }
 

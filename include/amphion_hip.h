@@ -229,6 +229,14 @@ int amp_mel_forward(const amp_mel_desc* d, const float* wav_dev, int B, int L, c
                     const float* melbasis_dev, float* mel_dev, float* mag_dev, float* re_dev, float* im_dev,
                     void* stream);
 
+/* Replaces STFT.inverse (utils/stft.py:183-222; used by STFT.forward and griffin_lim :78-95): magnitude and
+ * phase [B, n_fft/2+1, F] -> waveform [B, hop*(F-1)] (overlap-add of the windowed inverse FFTs, divided by the
+ * window-sum-square envelope where it exceeds float32 tiny, times n_fft/hop, n_fft/2 cropped per side).
+ * window_dev [n_fft]; wss_dev [n_fft + hop*(F-1)] = window_sumsquare (stft.py:19-75) as float32;
+ * frames_ws_dev: scratch of B*F*n_fft floats. */
+int amp_istft_forward(const amp_mel_desc* d, const float* mag_dev, const float* phase_dev, int B, int F,
+                      const float* window_dev, const float* wss_dev, float* frames_ws_dev, float* wav_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

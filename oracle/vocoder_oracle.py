@@ -378,6 +378,45 @@ def taco_stft_transform(y, filter_length, hop_length, win_length, dtype=torch.fl
     return mag, phase
 
 
+def window_sumsquare(n_frames, hop_length, win_length, n_fft):
+    """utils/stft.py:19-75 with window="hann", norm=None, dtype=float32."""
+    n = n_fft + hop_length * (n_frames - 1)
+    x = np.zeros(n, dtype=np.float32)
+    win_sq = (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(win_length) / win_length)) ** 2   # scipy hann, fftbins=True
+    lp = (n_fft - win_length) // 2
+    win_sq = np.pad(win_sq, (lp, n_fft - win_length - lp))
+    for i in range(n_frames):
+        sample = i * hop_length
+        x[sample:min(n, sample + n_fft)] += win_sq[:max(0, min(n_fft, n - sample))]
+    return x
+
+
+def taco_stft_inverse(magnitude, phase, filter_length, hop_length, win_length, dtype=torch.float32):
+    """STFT.inverse utils/stft.py:183-217 with the bases of STFT.__init__ :122-147: conv_transpose1d with
+    pinv(scale * [Re F; Im F]).T * window, / window_sumsquare where > tiny, * filter_length / hop, crop."""
+    scale = filter_length / hop_length
+    fb = np.fft.fft(np.eye(filter_length))
+    cutoff = int(filter_length / 2 + 1)
+    fb = np.vstack([np.real(fb[:cutoff, :]), np.imag(fb[:cutoff, :])])
+    inv = torch.FloatTensor(np.linalg.pinv(scale * fb).T[:, None, :])
+    win = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(win_length) / win_length)
+    lp = (filter_length - win_length) // 2
+    win = torch.from_numpy(np.pad(win, (lp, filter_length - win_length - lp))).float()
+    inv = (inv * win).to(dtype)
+    magnitude = torch.as_tensor(magnitude).to(dtype)
+    phase = torch.as_tensor(phase).to(dtype)
+    rec = torch.cat([magnitude * torch.cos(phase), magnitude * torch.sin(phase)], dim=1)
+    out = F.conv_transpose1d(rec, inv, stride=hop_length, padding=0)
+    ws = window_sumsquare(magnitude.size(-1), hop_length, win_length, filter_length)
+    nz = torch.from_numpy(np.where(ws > np.finfo(np.float32).tiny)[0])
+    ws = torch.from_numpy(ws).to(dtype)
+    out[:, :, nz] /= ws[nz]
+    out *= float(filter_length) / hop_length
+    out = out[:, :, int(filter_length / 2):]
+    out = out[:, :, : -int(filter_length / 2)]
+    return out
+
+
 def taco_mel_spectrogram(y, filter_length, hop_length, win_length, n_mel, sr, fmin, fmax, dtype=torch.float32):
     """TacotronSTFT.mel_spectrogram utils/stft.py:259-278 -> (mel, energy)."""
     mag, _ = taco_stft_transform(y, filter_length, hop_length, win_length, dtype)
