@@ -372,6 +372,7 @@ struct amp_gen {
     bool profiling = false;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     std::vector<hipEvent_t> ev_mrf;  // begin/end per (batch group, stage)
+    std::vector<hipEvent_t> ev_rb;   // per (batch group, stage): n_kernels + 1 marks around the resblocks
     int ev_groups = 0;
     bool timing_valid = false;
     ~amp_gen() {
@@ -379,6 +380,7 @@ struct amp_gen {
         if (ev_begin) (void)hipEventDestroy(ev_begin);
         if (ev_end) (void)hipEventDestroy(ev_end);
         for (auto e : ev_mrf) (void)hipEventDestroy(e);
+        for (auto e : ev_rb) (void)hipEventDestroy(e);
     }
 };
 
@@ -726,6 +728,17 @@ int amp_gen_last_timing_ms(amp_gen* g, int which, float* ms_out) {
                 tot += ms;
             }
         *ms_out = tot;
+    } else if (which >= 100 && which < 100 + 16 * g->d.n_stages && (which - 100) % 16 < g->d.n_kernels) {
+        // one resblock: 100 + 16 * stage + j, summed over the batch groups
+        const int i = (which - 100) / 16, j = (which - 100) % 16, nk = g->d.n_kernels;
+        float tot = 0.f;
+        for (int gi = 0; gi < g->ev_groups; ++gi) {
+            float ms = 0.f;
+            const size_t e = (size_t)g->d.n_stages * (nk + 1) * gi + (size_t)i * (nk + 1) + j;
+            AMP_HIP(hipEventElapsedTime(&ms, g->ev_rb[e], g->ev_rb[e + 1]));
+            tot += ms;
+        }
+        *ms_out = tot;
     } else {
         set_error("amp_gen_last_timing_ms: which=%d", which);
         return AMP_ERR_INVALID;
@@ -738,7 +751,7 @@ int amp_gen_last_timing_ms(amp_gen* g, int which, float* ms_out) {
 // One group of `B` items through the whole generator (buffers sized for `be` elements each).
 static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond_dev, const int* lens, int B, int T,
                              float* wav_dev, float* base, size_t be, hipStream_t st,
-                             hipEvent_t* ev_mrf /* 2 per stage, or null */) {
+                             hipEvent_t* ev_mrf /* 2 per stage, or null */, hipEvent_t* ev_rb /* (n_kernels+1) per stage */) {
     const amp_gen_desc& d = g->d;
     const bool big = d.arch == AMP_ARCH_BIGVGAN;
     float* X = base;            // stage input / MRF accumulator (ping-pong with XS)
@@ -766,6 +779,7 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
         lm *= d.upsample_rates[i];
         if (ev_mrf) AMP_HIP(hipEventRecord(ev_mrf[2 * i], st));
         for (int j = 0; j < nk; ++j) {
+            if (ev_rb) AMP_HIP(hipEventRecord(ev_rb[(size_t)i * (nk + 1) + j], st));
             const ResBlock& rb = g->rbs[(size_t)i * nk + j];
             const int nd = (int)rb.dil.size();
             const int mode_last = (nk == 1) ? 0 : (j == 0 ? 0 : (j == nk - 1 ? 2 : 1));
@@ -819,6 +833,7 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
                 }
             }
         }
+        if (ev_rb) AMP_HIP(hipEventRecord(ev_rb[(size_t)i * (nk + 1) + nk], st));
         if (ev_mrf) AMP_HIP(hipEventRecord(ev_mrf[2 * i + 1], st));
         float* tmp = X; X = XS; XS = tmp;  // x = xs / num_kernels
     }
@@ -857,6 +872,12 @@ int amp_gen_forward_ragged(amp_gen* g, const float* mel_dev, const float* cond_d
             AMP_HIP(hipEventCreate(&e));
             g->ev_mrf.push_back(e);
         }
+        const size_t need_rb = (size_t)d.n_stages * (d.n_kernels + 1) * ngroups;
+        while (g->ev_rb.size() < need_rb) {
+            hipEvent_t e;
+            AMP_HIP(hipEventCreate(&e));
+            g->ev_rb.push_back(e);
+        }
         g->ev_groups = ngroups;
         AMP_HIP(hipEventRecord(g->ev_begin, st));
     }
@@ -867,7 +888,8 @@ int amp_gen_forward_ragged(amp_gen* g, const float* mel_dev, const float* cond_d
                                  cond_dev ? cond_dev + (size_t)b0 * d.gin_channels : nullptr,
                                  lens_dev ? lens_dev + b0 : nullptr, Bg, T,
                                  wav_dev + (size_t)b0 * L, (float*)workspace_dev, be, st,
-                                 g->profiling ? g->ev_mrf.data() + 2 * (size_t)d.n_stages * gi : nullptr));
+                                 g->profiling ? g->ev_mrf.data() + 2 * (size_t)d.n_stages * gi : nullptr,
+                                 g->profiling ? g->ev_rb.data() + (size_t)d.n_stages * (d.n_kernels + 1) * gi : nullptr));
     }
     if (g->profiling) { AMP_HIP(hipEventRecord(g->ev_end, st)); g->timing_valid = true; }
     return AMP_OK;

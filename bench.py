@@ -31,6 +31,11 @@ BYTES_PER_SAMPLE_MRF = 14_976        # layer-wise minimum fp32 HBM traffic of th
 PEAK_FP32_TFLOPS = 157.3             # MI355X_MICROARCH.md: fp32 MFMA == fp32 vector peak
 PEAK_F16_TFLOPS = 2516.6             # dense f16 MFMA (256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz)
 PEAK_HBM_GBS = 8000.0
+# Sustained f16 MFMA rate of a register-resident v_mfma_f32_32x32x16_f16 loop on RANDOM operands, measured
+# on MI355X (profiles/r1_mfma_peak_microbench.txt): the chip clocks down to ~1.6 GHz under MFMA load
+# (2192 TF on zeros, 1580-1630 TF on random data), so this -- not 2516.6 -- is what a perfect kernel gets.
+SUSTAINED_F16_TFLOPS = 1600.0
+PROFILE_TRAFFIC_CSV = os.path.join(ROOT, "profiles", "r1_v3_f16x3_fused_hbm_traffic.csv")
 # arithmetic of the conv contractions -> (dtype string, peak for ALGORITHMIC flops, note)
 PRECISIONS = {
     "f16x3": ("f32 (split-f16 MFMA: 3 x v_mfma_f32_32x32x16_f16 per term, f32 accumulate)", PEAK_F16_TFLOPS / 3.0,
@@ -156,12 +161,16 @@ def main():
     model.set_profiling(True)
     step()
     torch.cuda.synchronize()
-    fwd_ms, mrf_ms, stage_ms = [], [], []
+    # dominant kernel: the fused ResBlock pairs of stage 1 (C=128), kernel 11 -- resblock j=2 of stage i=1 is
+    # three back-to-back launches of pair_f16x3_kernel<11,4,1,3,192> (k=11 pairs with dilation 1, 3, 5)
+    DOM_STAGE, DOM_RB, DOM_LAUNCHES = 1, 2, 3
+    fwd_ms, mrf_ms, stage_ms, dom_ms = [], [], [], []
     for _ in range(max(3, min(args.steps, 10))):
         step()
         fwd_ms.append(model.last_timing_ms(0))
         mrf_ms.append(model.last_timing_ms(1))
         stage_ms.append([model.last_timing_ms(2 + i) for i in range(len(hp["upsample_rates"]))])
+        dom_ms.append(model.last_timing_ms(100 + 16 * DOM_STAGE + DOM_RB))
     model.set_profiling(False)
 
     if rank == 0:
@@ -172,6 +181,48 @@ def main():
         fwd_s = (sum(fwd_ms) / len(fwd_ms)) * 1e-3
         mrf_tflops = FLOP_PER_SAMPLE_MRF * n_local / mrf_s / 1e12
         mrf_gbs = BYTES_PER_SAMPLE_MRF * n_local / mrf_s / 1e9
+        # ---- roofline of the dominant kernel (per launch), plus the whole MRF stack beside it ----
+        C1 = hp["upsample_initial_channel"] // 4                      # channels of stage 1
+        T1 = T_FRAMES * hp["upsample_rates"][0] * hp["upsample_rates"][1]
+        k_dom = hp["resblock_kernel_sizes"][DOM_RB]
+        fused = args.precision == "f16x3"
+        dom_launches = DOM_LAUNCHES if fused else 2 * DOM_LAUNCHES     # unfused: conv1 and conv2 are separate launches
+        dom_flop = 2 * (2.0 * C1 * C1 * k_dom * B_PER_GPU * T1) / (1 if fused else 2)   # per launch
+        dom_bytes = (2 if fused else 2.5) * 4.0 * B_PER_GPU * C1 * T1  # read x + write y (+ residual when unfused)
+        dom_s = (sum(dom_ms) / len(dom_ms)) * 1e-3 / dom_launches
+        dom_tflops = dom_flop / dom_s / 1e12
+        traffic = None
+        kname = "pair_f16x3_kernel<11, 4, 1, 3, 192>" if fused else "conv_mfma_kernel<11, 4, 1, 8, 64>"
+        if fused and os.path.exists(PROFILE_TRAFFIC_CSV):              # PMC pass of an earlier run of this command
+            for line in open(PROFILE_TRAFFIC_CSV):
+                if kname in line:
+                    traffic = float(line.rsplit(",", 1)[1]) * 1e6      # FETCH_SIZE x2 (gfx950) + WRITE_SIZE, bytes/launch
+        roofline = {
+            "kernel": kname + (" (fused ResBlock pair, C=128, k=11: conv1 -> LDS -> conv2 + residual)" if fused else ""),
+            "bound": "mfma",
+            "achieved": dom_tflops,
+            "peak": peak_tflops,
+            "peak_note": peak_note,
+            "unit": "TFLOP/s",
+            "frac": dom_tflops / peak_tflops,
+            "traffic": traffic,
+            "traffic_note": "HBM-side bytes per launch from rocprofv3 FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, "
+                            + os.path.relpath(PROFILE_TRAFFIC_CSV, ROOT) if traffic else None,
+            "algorithmic_flop_per_launch": dom_flop,
+            "algorithmic_bytes_per_launch": dom_bytes,
+            "launch_us": dom_s * 1e6,
+            "hbm_term": {"achieved": dom_bytes / dom_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": dom_bytes / dom_s / 1e9 / PEAK_HBM_GBS},
+            "sustained_peak": (SUSTAINED_F16_TFLOPS / 3.0) if fused else None,
+            "frac_of_sustained": dom_tflops / (SUSTAINED_F16_TFLOPS / 3.0) if fused else None,
+            "sustained_note": "register-resident f16 MFMA loop on random data sustains 1.6 PF (power/clock wall), "
+                              "profiles/r1_mfma_peak_microbench.txt" if fused else None,
+            "mrf_stack": {"tflops": mrf_tflops, "frac": mrf_tflops / peak_tflops, "ms": mrf_s * 1e3,
+                          "ms_per_stage": [sum(v[i] for v in stage_ms) / len(stage_ms) for i in range(len(stage_ms[0]))],
+                          "hbm_gbs_layerwise_min": mrf_gbs},
+            "forward_ms": fwd_s * 1e3,
+            "whole_forward_tflops": FLOP_PER_SAMPLE_ALL * n_local / fwd_s / 1e12,
+        }
         result = {
             "metric": "audio samples/sec (HiFi-GAN V1 22.05 kHz generator, mel->wav)",
             "value": value,
@@ -195,22 +246,7 @@ def main():
                 "samples_per_step": samples_per_step,
                 "parallelism": f"batch-sharded x{world}, result gather on rank 0" if world > 1 else "single GPU",
             },
-            "roofline": {
-                "kernel": "MRF conv stack (72 fused dilated Conv1d, "
-                          + ("conv_f16x3_kernel" if args.precision == "f16x3" else "conv_mfma_kernel") + ")",
-                "bound": "mfma",
-                "achieved": mrf_tflops,
-                "peak": peak_tflops,
-                "peak_note": peak_note,
-                "unit": "TFLOP/s",
-                "frac": mrf_tflops / peak_tflops,
-                "traffic": None,
-                "hbm_term": {"achieved": mrf_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": mrf_gbs / PEAK_HBM_GBS},
-                "mrf_ms": mrf_s * 1e3,
-                "mrf_ms_per_stage": [sum(v[i] for v in stage_ms) / len(stage_ms) for i in range(len(stage_ms[0]))],
-                "forward_ms": fwd_s * 1e3,
-                "whole_forward_tflops": FLOP_PER_SAMPLE_ALL * n_local / fwd_s / 1e12,
-            },
+            "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(sd, hp)

@@ -136,7 +136,8 @@ int amp_gen_forward_ragged(amp_gen* g, const float* mel_dev, const float* cond_d
 
 /* Duration [ms] of the kernels of the LAST amp_gen_forward on this handle, measured with HIP events
  * recorded on the launch stream when profiling is on.  which: 0 = whole forward, 1 = MRF conv stack
- * (all ResBlock/AMPBlock convs), 2 + i = the MRF convs of upsampling stage i.  Synchronises on the events.
+ * (all ResBlock/AMPBlock convs), 2 + i = the MRF convs of upsampling stage i, 100 + 16*i + j = resblock j of
+ * stage i (its back-to-back conv / fused-pair launches).  Synchronises on the events.
  * Returns <0 on error. */
 int amp_gen_set_profiling(amp_gen* g, int enabled);
 int amp_gen_last_timing_ms(amp_gen* g, int which, float* ms_out);
