@@ -103,6 +103,15 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
                 for (int t = 0; t < NI; ++t) acc[t][r] += yr_[lane_off + 32 * t];
             }
         }
+    } else if (!a.res && a.mode == 0) {   // transposed convs / ragged tiles without residual: bias only
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int o = (up == 1) ? m : m / up;
+            const float bv = (m < a.M && a.bias) ? a.bias[o] : 0.f;
+#pragma unroll
+            for (int t = 0; t < NI; ++t) acc[t][r] = bv;
+        }
     } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -253,6 +262,67 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
                 if (exact_div) v = v / a.div;
                 v = v > 0.f ? v : v * slope_out;
                 yr_[lane_off + 32 * t] = v;
+            }
+        }
+    } else if (up > 1 && (up & 3) == 0 && (a.up_pad & 3) == 0 && (mb * 32 + 32 <= a.M) && a.mode == 0) {
+        // Polyphase scatter, stride % 4 == 0 (the 8x stages): a lane's 4 rows (r & 3) of one register quad
+        // are 4 CONSECUTIVE phases of one output channel = 4 consecutive samples n0..n0+3, 16-B aligned
+        // (n0 = q*up + phase0 - pad with up, phase0, pad all multiples of 4): one float4 store, and the two
+        // lane halves (hi) interleave to fully coalesced rows.  (Scalar stores at stride `up` touched one
+        // 32-B sector per lane.)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m0 = mb * 32 + 8 * j + 4 * hi;          // GEMM row of (r & 3) == 0
+            const int o = m0 / up;
+            const int ph = m0 - o * up;                       // phase of that row, multiple of 4
+            float* yrow = a.y + ((size_t)item * a.Cout + o) * a.Tout;
+#pragma unroll
+            for (int t = 0; t < NI; ++t) {
+                const int q = qw + 32 * t;
+                const int n0 = q * up + ph - a.up_pad;
+                if (q < a.Tq && n0 >= 0 && n0 + 3 < a.Tout) {
+                    float4 v;
+                    v.x = acc[t][4 * j + 0] * a.inv_scale;
+                    v.y = acc[t][4 * j + 1] * a.inv_scale;
+                    v.z = acc[t][4 * j + 2] * a.inv_scale;
+                    v.w = acc[t][4 * j + 3] * a.inv_scale;
+                    v.x = v.x > 0.f ? v.x : v.x * slope_out;
+                    v.y = v.y > 0.f ? v.y : v.y * slope_out;
+                    v.z = v.z > 0.f ? v.z : v.z * slope_out;
+                    v.w = v.w > 0.f ? v.w : v.w * slope_out;
+                    *reinterpret_cast<float4*>(yrow + n0) = v;
+                }
+            }
+        }
+    } else if (up == 2 && (mb * 32 + 32 <= a.M) && a.mode == 0) {
+        // stride 2: rows (r & 3) = {0,1} and {2,3} are the two phases of two consecutive output channels:
+        // two consecutive samples each -> 8-B stores (4-B aligned: pad is odd), lanes contiguous
+        struct __attribute__((packed, aligned(4))) F2 { float a, b; };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int m0 = mb * 32 + 8 * j + 4 * hi + 2 * h2;   // even row: phase 0
+                const int o = m0 >> 1;
+                float* yrow = a.y + ((size_t)item * a.Cout + o) * a.Tout;
+#pragma unroll
+                for (int t = 0; t < NI; ++t) {
+                    const int q = qw + 32 * t;
+                    const int n0 = 2 * q - a.up_pad;
+                    float v0 = acc[t][4 * j + 2 * h2] * a.inv_scale;
+                    float v1 = acc[t][4 * j + 2 * h2 + 1] * a.inv_scale;
+                    v0 = v0 > 0.f ? v0 : v0 * slope_out;
+                    v1 = v1 > 0.f ? v1 : v1 * slope_out;
+                    if (q < a.Tq) {
+                        if (n0 >= 0 && n0 + 1 < a.Tout) {
+                            F2 v{v0, v1};
+                            *reinterpret_cast<F2*>(yrow + n0) = v;
+                        } else {
+                            if (n0 >= 0 && n0 < a.Tout) yrow[n0] = v0;
+                            if (n0 + 1 >= 0 && n0 + 1 < a.Tout) yrow[n0 + 1] = v1;
+                        }
+                    }
+                }
             }
         }
     } else {

@@ -44,6 +44,11 @@ def gather_audio(local: torch.Tensor, total_items: int, dst: int = 0, group=None
         send[: local.shape[0]] = local
     send = send.contiguous()
     if rank == dst:
+        if min(counts) == mx:
+            # equal shards: receive straight into the row blocks of the result (no staging copies)
+            out = torch.empty((total_items,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+            dist.gather(send, list(out.split(mx, dim=0)), dst=dst, group=group)
+            return out
         bufs = [torch.empty_like(send) for _ in range(world)]
         dist.gather(send, bufs, dst=dst, group=group)
         return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
