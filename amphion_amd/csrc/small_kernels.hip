@@ -90,68 +90,175 @@ hipError_t launch_conv_post(const float* x, const float* w_dev, const float* bia
 // ---------------------------------------------------------------------------------------------
 constexpr int A1_TT = 1024;
 
+// sin(x)^2 for Snake (snake.py:56-61).  The activation evaluates two sines per output sample and was
+// sin-bound with the full-range libm sinf (Payne-Hanek branch + ~40 instructions): a 3-term Cody-Waite
+// reduction by pi (exact k * PI_A for |k| < 2^16) and the odd Taylor polynomial through r^13 on
+// [-pi/2, pi/2] costs 13 FMAs and stays within 1.1e-7 of the exact sine for |x| <= 1e5 (libm: 0.7e-7);
+// the sign lost by reducing modulo pi does not matter under the square.  Larger arguments take sinf.
+__device__ __forceinline__ float snake_sin2(float x) {
+    if (fabsf(x) > 1.0e5f) { const float s = sinf(x); return s * s; }
+    const float k = rintf(x * 0.31830988618379067f);
+    float r = fmaf(-k, 3.140625f, x);
+    r = fmaf(-k, 9.67502593994140625e-4f, r);
+    r = fmaf(-k, 1.509957990978376432e-07f, r);
+    const float r2 = r * r;
+    float p = 1.0f / 6227020800.0f;
+    p = fmaf(p, r2, -1.0f / 39916800.0f);
+    p = fmaf(p, r2, 1.0f / 362880.0f);
+    p = fmaf(p, r2, -1.0f / 5040.0f);
+    p = fmaf(p, r2, 1.0f / 120.0f);
+    p = fmaf(p, r2, -1.0f / 6.0f);
+    const float sn = fmaf(r * r2, p, r);
+    return sn * sn;
+}
+
+constexpr int A1_NTILE = 4;   // consecutive tiles per workgroup (next tile's inputs prefetched into registers)
+
 __global__ __launch_bounds__(256) void act1d_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int T,
                                                     const float* __restrict__ a_dev,
                                                     const float* __restrict__ invb_dev, const float* __restrict__ fu,
                                                     const float* __restrict__ fd, const int* __restrict__ lens,
                                                     int len_mul) {
-    __shared__ float xl[A1_TT + 12];
-    __shared__ float sl[2 * A1_TT + 12];
+    // staged window xl[i] = x[clamp(t0 - 8 + i)], i < A1_TT + 16 (starts 8 before the tile: 16-B aligned rows)
+    __shared__ __attribute__((aligned(16))) float xl[A1_TT + 16];
+    __shared__ __attribute__((aligned(16))) float sl[2 * A1_TT + 12];
     __shared__ float ful[12], fdl[12];
     const int tid = threadIdx.x;
     const int ntiles = (T + A1_TT - 1) / A1_TT;   // T = row stride (padded length)
-    const int bc = blockIdx.x / ntiles;
+    const int ngroups = (ntiles + A1_NTILE - 1) / A1_NTILE;
+    const int bc = blockIdx.x / ngroups;
     const int c = bc % C;
-    const int t0 = (blockIdx.x - bc * ntiles) * A1_TT;
+    const int tile_first = (blockIdx.x - bc * ngroups) * A1_NTILE;
     // Tv = the utterance's own length: the replicate padding (resample.py:36-45, filter.py:92-99) clamps to
     // ITS last sample, so a padded batch equals the per-utterance results
     int Tv = T;
     if (lens) { const int l = lens[bc / C] * len_mul; Tv = l < Tv ? l : Tv; }
-    if (t0 >= Tv) return;                          // nothing valid in this tile (block-uniform)
     const float a = a_dev[c], invb = invb_dev[c];
     const float* xr = x + (size_t)bc * T;
-    if (tid < 12) { ful[tid] = fu[tid]; fdl[tid] = fd[tid]; }
-    for (int i = tid; i < A1_TT + 12; i += 256) {
-        int t = t0 - 6 + i;
-        t = t < 0 ? 0 : (t > Tv - 1 ? Tv - 1 : t);
-        xl[i] = xr[t];
-    }
-    __syncthreads();
-    const int twoT = 2 * Tv;
-    for (int i = tid; i < 2 * A1_TT + 11; i += 256) {
-        int n = 2 * t0 + i - 5;
-        n = n < 0 ? 0 : (n > twoT - 1 ? twoT - 1 : n);
-        const int np = n + 15;
-        const int mmax = np >> 1;
-        const int par = np & 1;
-        float u = 0.f;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            int xi = mmax - k - 5;  // index into x before clamping
-            xi = xi < 0 ? 0 : (xi > Tv - 1 ? Tv - 1 : xi);
-            u = fmaf(xl[xi - (t0 - 6)], ful[par + 2 * k], u);
-        }
-        u *= 2.f;
-        const float sn = sinf(u * a);
-        sl[i] = u + invb * (sn * sn);
-    }
-    __syncthreads();
     float* yr = y + (size_t)bc * T;
-    for (int k = tid; k < A1_TT; k += 256) {
-        const int t = t0 + k;
-        if (t < Tv) {
-            float acc = 0.f;
+    if (tid < 12) { ful[tid] = fu[tid]; fdl[tid] = fd[tid]; }
+    const int twoT = 2 * Tv;
+    const bool vec_rows = (T & 3) == 0;            // rows start 16-B aligned (x and y come from the workspace)
+    // interior tile: no index is clamped anywhere in it, and its window can be loaded as aligned float4
+    auto is_interior = [&](int t0) { return vec_rows && (t0 >= 8) && (t0 + A1_TT + 8 <= Tv); };
+
+    float4 pre0, pre1;                             // prefetched window of the next interior tile
+    bool have_pre = false;
+    for (int tl = 0; tl < A1_NTILE; ++tl) {
+        const int t0 = (tile_first + tl) * A1_TT;
+        if (t0 >= Tv || tile_first + tl >= ntiles) break;      // nothing valid from here on (block-uniform)
+        if (is_interior(t0)) {
+            // ---- vector path: float4 global loads (next tile prefetched under this tile's arithmetic),
+            //      3 + 5 ds_read_b128 per thread instead of 96 scalar LDS reads ----
+            float4 v0, v1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (have_pre) { v0 = pre0; v1 = pre1; }
+            else {
+                v0 = *reinterpret_cast<const float4*>(xr + t0 - 8 + 4 * tid);
+                if (tid < 4) v1 = *reinterpret_cast<const float4*>(xr + t0 - 8 + A1_TT + 4 * tid);
+            }
+            *reinterpret_cast<float4*>(&xl[4 * tid]) = v0;
+            if (tid < 4) *reinterpret_cast<float4*>(&xl[A1_TT + 4 * tid]) = v1;
+            const int tn = t0 + A1_TT;
+            have_pre = (tl + 1 < A1_NTILE) && (tile_first + tl + 1 < ntiles) && is_interior(tn);
+            if (have_pre) {
+                pre0 = *reinterpret_cast<const float4*>(xr + tn - 8 + 4 * tid);
+                if (tid < 4) pre1 = *reinterpret_cast<const float4*>(xr + tn - 8 + A1_TT + 4 * tid);
+            }
+            __syncthreads();
+            for (int i0 = 8 * tid; i0 < 2 * A1_TT + 11; i0 += 8 * 256) {
+                // Snake value i = i0 + e (n = 2*t0 + i - 5) needs x[((n + 15) >> 1) - k - 5], k = 0..5
+                //   = xl[(i0 >> 1) + ((e + 10) >> 1) + 3 - k]: a 12-float window at xl[i0 >> 1]
+                const int xb = i0 >> 1;                           // multiple of 4
+                const float4 w0 = *reinterpret_cast<const float4*>(&xl[xb]);
+                const float4 w1 = *reinterpret_cast<const float4*>(&xl[xb + 4]);
+                const float4 w2 = *reinterpret_cast<const float4*>(&xl[xb + 8]);
+                const float xw[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+                float sv[8];
 #pragma unroll
-            for (int j = 0; j < 12; ++j) acc = fmaf(fdl[j], sl[2 * k + j], acc);
-            yr[t] = acc;
+                for (int e = 0; e < 8; ++e) {
+                    const int par = e & 1;                        // (n + 15) & 1, i0 even
+                    const int top = ((e + 10) >> 1) + 3;          // window index of k = 0
+                    float u = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) u = fmaf(xw[top - k], ful[par + 2 * k], u);
+                    u *= 2.f;
+                    sv[e] = u + invb * snake_sin2(u * a);
+                }
+                if (i0 + 8 <= 2 * A1_TT + 12) {
+                    *reinterpret_cast<float4*>(&sl[i0]) = make_float4(sv[0], sv[1], sv[2], sv[3]);
+                    *reinterpret_cast<float4*>(&sl[i0 + 4]) = make_float4(sv[4], sv[5], sv[6], sv[7]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (i0 + e < 2 * A1_TT + 12) sl[i0 + e] = sv[e];
+                }
+            }
+            __syncthreads();
+            {
+                const int k0 = 4 * tid;                           // outputs k0..k0+3 need sl[2*k0 .. 2*k0 + 17]
+                float sw[20];
+#pragma unroll
+                for (int v = 0; v < 5; ++v) {
+                    const float4 q = *reinterpret_cast<const float4*>(&sl[2 * k0 + 4 * v]);
+                    sw[4 * v] = q.x; sw[4 * v + 1] = q.y; sw[4 * v + 2] = q.z; sw[4 * v + 3] = q.w;
+                }
+                float4 o;
+                float* op = &o.x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 12; ++j) acc = fmaf(fdl[j], sw[2 * e + j], acc);
+                    op[e] = acc;
+                }
+                *reinterpret_cast<float4*>(yr + t0 + k0) = o;     // vec_rows: 16-B aligned
+            }
+        } else {
+            // ---- edge tiles (first / last of a row, ragged ends, unaligned rows): clamp every index ----
+            have_pre = false;
+            for (int i = tid; i < A1_TT + 16; i += 256) {
+                int t = t0 - 8 + i;
+                t = t < 0 ? 0 : (t > Tv - 1 ? Tv - 1 : t);
+                xl[i] = xr[t];
+            }
+            __syncthreads();
+            for (int i = tid; i < 2 * A1_TT + 11; i += 256) {
+                int n = 2 * t0 + i - 5;
+                n = n < 0 ? 0 : (n > twoT - 1 ? twoT - 1 : n);
+                const int np = n + 15;
+                const int mmax = np >> 1;
+                const int par = np & 1;
+                float u = 0.f;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    int xi = mmax - k - 5;  // index into x before clamping
+                    xi = xi < 0 ? 0 : (xi > Tv - 1 ? Tv - 1 : xi);
+                    u = fmaf(xl[xi - (t0 - 8)], ful[par + 2 * k], u);
+                }
+                u *= 2.f;
+                sl[i] = u + invb * snake_sin2(u * a);
+            }
+            __syncthreads();
+            for (int k = tid; k < A1_TT; k += 256) {
+                const int t = t0 + k;
+                if (t < Tv) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 12; ++j) acc = fmaf(fdl[j], sl[2 * k + j], acc);
+                    yr[t] = acc;
+                }
+            }
         }
+        __syncthreads();   // xl / sl are rewritten by the next tile
     }
 }
 
 hipError_t launch_act1d(const float* x, float* y, int B, int C, int T, const float* a_dev, const float* invb_dev,
                         const float* filt_up12, const float* filt_dn12, const int* lens, int len_mul,
                         hipStream_t stream) {
-    dim3 grid((unsigned)(((T + A1_TT - 1) / A1_TT) * (size_t)(B * C)));
+    const int ntiles = (T + A1_TT - 1) / A1_TT;
+    const int ngroups = (ntiles + A1_NTILE - 1) / A1_NTILE;
+    dim3 grid((unsigned)((size_t)ngroups * (size_t)(B * C)));
     hipLaunchKernelGGL(act1d_kernel, grid, dim3(256), 0, stream, x, y, C, T, a_dev, invb_dev, filt_up12, filt_dn12,
                        lens, len_mul);
     return hipGetLastError();

@@ -27,11 +27,14 @@ def timed(fn, reps):
 
 
 def main():
-    ap = argparse.ArgumentParser(); ap.add_argument("--reps", type=int, default=5); a = ap.parse_args()
+    ap = argparse.ArgumentParser(); ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--only", default="", help="c3 | c5 | mel | list (default: all)"); a = ap.parse_args()
     dev = "cuda:0"
     out = []
     with torch.no_grad():
         # ---- C3: BigVGAN-base 24 kHz, B=32, 100 mel x 256 frames
+        if a.only not in ("", "c3"):
+            raise SystemExit("--only supports c3 (or nothing)")
         from amphion_amd.models.vocoders.gan.generator.bigvgan import BigVGAN
         hp = dict(V1, activation="snakebeta", snake_logscale=True)
         m = randomize_(BigVGAN(NS(preprocess=NS(n_mel=100, hop_size=256), model=NS(bigvgan=NS(**hp)))), 1234, g_gain=0.75).to(dev).eval()
@@ -40,6 +43,8 @@ def main():
         n = 32 * 256 * 256
         out.append({"config": "C3 BigVGAN-base 24 kHz, B=32 x 100 mel x 256 frames", "ms_per_step": ms, "samples_per_s": n / ms * 1e3, "x_realtime": n / ms * 1e3 / 24000})
         del m, mel; torch.cuda.empty_cache()
+        if a.only == "c3":
+            print(json.dumps(out[0])); return
         # ---- C5: VITS posterior encoder + flow + reverse flow + HiFi-GAN decoder, B=16, T=256
         from amphion_amd.models.tts.vits.vits import SynthesizerTrnDecodePath
         net = SynthesizerTrnDecodePath(513, 192, 192, "1", V1["resblock_kernel_sizes"], V1["resblock_dilation_sizes"],
