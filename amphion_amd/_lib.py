@@ -19,6 +19,7 @@ AMP_MAX_DILATIONS = 8
 AMP_ARCH_HIFIGAN, AMP_ARCH_BIGVGAN, AMP_ARCH_HIFIGAN_VITS = 0, 1, 2
 AMP_ACT_LRELU, AMP_ACT_SNAKE, AMP_ACT_SNAKEBETA = 0, 1, 2
 AMP_PRECISION_F32, AMP_PRECISION_F16X3 = 0, 1
+AMP_CONV_OPT_PAD_REFLECT, AMP_CONV_OPT_TANH = 1, 2
 PRECISIONS = {"f32": AMP_PRECISION_F32, "fp32": AMP_PRECISION_F32, "f16x3": AMP_PRECISION_F16X3}
 
 
@@ -82,6 +83,7 @@ _SIGNATURES = {
     "amp_conv_out_len": (c_int, [c_void_p, c_int]),
     "amp_conv_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_float, c_void_p, c_void_p]),
     "amp_conv_forward_strided": (c_int, [c_void_p, c_void_p, ctypes.c_longlong, c_int, c_int, c_float, c_void_p, c_float, c_void_p, c_void_p]),
+    "amp_conv_set_option": (c_int, [c_void_p, c_int, c_int]),
     "amp_pair_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
     "amp_conv_destroy": (None, [c_void_p]),
     "amp_wn_gate": (c_int, [c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_int, c_int, c_int, c_void_p]),

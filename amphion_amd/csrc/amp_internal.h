@@ -46,6 +46,8 @@ struct ConvArgs {
     // layer zero-pads at the utterance's OWN end, so a padded batch equals the per-utterance results)
     const int* lens;            // [B] on the device, or nullptr (all items valid on [0, Tin))
     int len_mul;
+    int pad_reflect;            // 1: out-of-range columns mirror (nn.ReflectionPad1d + unpadded conv, melgan.py:39,56,92)
+    int tanh_out;               // 1: tanh on store (melgan.py:94)
 };
 
 // Arguments of the fused ResBlock-pair kernel (pair_f16x3.hip):

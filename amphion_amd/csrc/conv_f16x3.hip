@@ -159,6 +159,10 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
             const int qd = ibase / S;                        // channel quad 0..3
             const int col = ibase - qd * S + lane;
             int t = tbase + col;
+            if (a.pad_reflect) {                             // wave-uniform: mirror without repeating the edge
+                t = t < 0 ? -t : t;
+                t = t > Tv - 1 ? 2 * (Tv - 1) - t : t;
+            }
             t = t < 0 ? 0 : t;
             t = t > a.Tin - 1 ? a.Tin - 1 : t;
             const int ch0 = chunk * KC16 + 4 * qd;
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
             const int qd = ibase / S;
             const int col = ibase - qd * S + lane;
             const int t = tbase + col;
-            const bool tok = (col < a.wd) && (t >= 0) && (t < Tv);
+            const bool tok = (col < a.wd) && (a.pad_reflect || ((t >= 0) && (t < Tv)));
             const int ch0 = chunk * KC16 + 4 * qd;
             union { uint2 u; _Float16 h[4]; } fh, fl;
 #pragma unroll
@@ -261,6 +265,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
                 float v = acc[t][r] * a.inv_scale;
                 if (exact_div) v = v / a.div;
                 v = v > 0.f ? v : v * slope_out;
+                if (a.tanh_out) v = tanhf(v);
                 yr_[lane_off + 32 * t] = v;
             }
         }
@@ -342,6 +347,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
                         float v = acc[t][r] * a.inv_scale;
                         if (exact_div) v = v / a.div;
                         v = v > 0.f ? v : v * slope_out;
+                        if (a.tanh_out) v = tanhf(v);
                         a.y[rowoff + n] = v;
                     }
                 }

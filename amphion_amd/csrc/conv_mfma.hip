@@ -121,9 +121,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
             const int col = idx - row * S;
             const int ch = chunk * KC + row;
             const int t = tbase + col;
-            const bool ok = (idx < KC * S) && (col < a.wd) && (ch < a.Cin) && (t >= 0) && (t < Tv);
+            int tr = t;
+            if (a.pad_reflect) {
+                tr = tr < 0 ? -tr : tr;
+                tr = tr > Tv - 1 ? 2 * (Tv - 1) - tr : tr;
+            }
+            const bool ok = (idx < KC * S) && (col < a.wd) && (ch < a.Cin) && (tr >= 0) && (tr < Tv);
             float v = 0.f;
-            if (ok) v = xb[(size_t)ch * a.Tin + t];
+            if (ok) v = xb[(size_t)ch * a.Tin + tr];
             xs[it] = v;
         }
     };
@@ -190,6 +195,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
                 if (a.mode == 2) v = v / a.div;
                 (void)scale;
                 v = v > 0.f ? v : v * slope_out;
+                if (a.tanh_out) v = tanhf(v);
                 yr_[lane_off + 32 * t] = v;
             }
         }
@@ -210,6 +216,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
                         float v = acc[t][r];
                         if (a.mode == 2) v = v / a.div;
                         v = v > 0.f ? v : v * slope_out;
+                        if (a.tanh_out) v = tanhf(v);
                         a.y[rowoff + n] = v;
                     }
                 }

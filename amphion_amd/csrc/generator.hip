@@ -159,6 +159,7 @@ struct amp_conv {
     int M = 0, ntaps = 0, KT = 0, off0 = 0, dstep = 0, halo_left = 0, halo_right = 0, up = 1, up_pad = 0;
     int nchunks = 0;
     int precision = PREC_F32;  // arithmetic of the contraction, fixed at build time
+    int pad_reflect = 0, tanh_out = 0;  // amp_conv_set_option
     float wscale = 1.f;        // f16x3: power of two applied to the packed weights
     ConvPlan plan{};
     void* wp_dev = nullptr;
@@ -288,6 +289,11 @@ static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope
     a.Cout = c->cout; a.Tout = Tout; a.up = c->up; a.up_pad = c->up_pad;
     a.slope_in = slope_in; a.slope_out = slope_out; a.mode = mode; a.div = div;
     a.lens = lens; a.len_mul = len_mul;
+    a.pad_reflect = c->pad_reflect; a.tanh_out = c->tanh_out;
+    if (c->pad_reflect && (c->halo_left >= T || c->halo_right >= T)) {
+        set_error("amp_conv_forward: reflection padding %d needs more than %d input samples", c->halo_left > c->halo_right ? c->halo_left : c->halo_right, T);
+        return AMP_ERR_INVALID;
+    }
     if (c->precision == PREC_F32) {
         a.acc_scale = a.inv_scale = 1.f;
         AMP_HIP(launch_conv(c->plan, a, stream));
@@ -304,6 +310,7 @@ static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope
 static bool pair_supported(const amp_conv* c1, const amp_conv* c2) {
     if (!fuse_pairs_enabled()) return false;
     if (c1->precision != PREC_F16X3 || c2->precision != PREC_F16X3) return false;
+    if (c1->pad_reflect || c2->pad_reflect || c1->tanh_out || c2->tanh_out) return false;
     if (c1->transposed || c2->transposed || c1->cin != c1->cout || c2->cin != c2->cout || c1->cin != c2->cin) return false;
     if (c1->k != c2->k || c2->dilation != 1 || c1->k != c1->KT) return false;
     if (c1->padding != (c1->k - 1) / 2 * c1->dilation || c2->padding != (c2->k - 1) / 2) return false;
@@ -935,6 +942,20 @@ int amp_pair_forward(const amp_conv* c1, const amp_conv* c2, const float* x_dev,
         return AMP_ERR_UNSUPPORTED;
     }
     return pair_run(c1, c2, x_dev, B, T, slope, y_dev, 0, 1.f, (hipStream_t)stream);
+}
+
+int amp_conv_set_option(amp_conv* c, int option, int value) {
+    if (!c) { set_error("amp_conv_set_option: null handle"); return AMP_ERR_INVALID; }
+    if (option == AMP_CONV_OPT_PAD_REFLECT) {
+        if (value && c->transposed) { set_error("amp_conv_set_option: reflection padding on a transposed conv"); return AMP_ERR_UNSUPPORTED; }
+        c->pad_reflect = value != 0;
+    } else if (option == AMP_CONV_OPT_TANH) {
+        c->tanh_out = value != 0;
+    } else {
+        set_error("amp_conv_set_option: unknown option %d", option);
+        return AMP_ERR_INVALID;
+    }
+    return AMP_OK;
 }
 
 void amp_conv_destroy(amp_conv* c) { delete c; }

@@ -40,6 +40,21 @@ def synthesis_audios(cfg, model, mels, f0s=None, batch_size=None, fast_inference
         raise NotImplementedError("f0-conditioned generators (NSF-HiFiGAN) are outside the HiFi-GAN/BigVGAN hot path")
     hop = model.cfg.preprocess.hop_size
     audios = [None] * len(mels)
+    if exact and not hasattr(model, "forward_ragged"):
+        # generators without per-utterance lengths in their kernels (MelGAN): one true batch per distinct
+        # length -- still bit-identical to the reference's B=1 loop
+        by_len = {}
+        for i, m in enumerate(mels):
+            by_len.setdefault(int(m.shape[-1]), []).append(i)
+        for T, idxs in by_len.items():
+            step = len(idxs) if not batch_size else int(batch_size)
+            for s in range(0, len(idxs), step):
+                grp = idxs[s:s + step]
+                batch = torch.stack([torch.as_tensor(mels[i], dtype=torch.float32).cpu() for i in grp])
+                out = vocoder_inference(cfg, model, batch, device=device, fast_inference=fast_inference)
+                for r, i in enumerate(grp):
+                    audios[i] = out[r][: T * hop]
+        return audios
     if exact:
         order = sorted(range(len(mels)), key=lambda i: int(mels[i].shape[-1]), reverse=True)
         step = len(order) if not batch_size else int(batch_size)

@@ -2,7 +2,7 @@
 drivers dispatch through (:39-75), ``load_nnvocoder`` (:397-457), ``tensorize`` (:460-468) and
 ``synthesis`` (:471-515), bound to the MI355X generators.
 
-``install_into_reference(mod)`` overwrites the ``hifigan`` / ``bigvgan`` entries of the reference
+``install_into_reference(mod)`` overwrites the ``hifigan`` / ``bigvgan`` / ``melgan`` entries of the reference
 module's own dicts, which is how ``bins/vocoder/inference.py`` runs unchanged on the HIP path
 (see amphion_amd/integration and INTEGRATION.md).
 """
@@ -14,23 +14,26 @@ from pathlib import Path
 import torch
 
 from amphion_amd.models.vocoders.gan import gan_vocoder_inference
-from amphion_amd.models.vocoders.gan.generator import bigvgan, hifigan
+from amphion_amd.models.vocoders.gan.generator import bigvgan, hifigan, melgan
 
 _vocoders = {
     "bigvgan": bigvgan.BigVGAN,
     "hifigan": hifigan.HiFiGAN,
+    "melgan": melgan.MelGAN,
 }
 
 # Forward call for the generalized Inferencer (vocoder_inference.py:52-62)
 _vocoder_forward_funcs = {
     "bigvgan": gan_vocoder_inference.vocoder_inference,
     "hifigan": gan_vocoder_inference.vocoder_inference,
+    "melgan": gan_vocoder_inference.vocoder_inference,
 }
 
 # APIs for other tasks, e.g. SVC, TTS, TTA (vocoder_inference.py:65-75)
 _vocoder_infer_funcs = {
     "bigvgan": gan_vocoder_inference.synthesis_audios,
     "hifigan": gan_vocoder_inference.synthesis_audios,
+    "melgan": gan_vocoder_inference.synthesis_audios,
 }
 
 

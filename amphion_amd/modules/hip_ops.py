@@ -27,8 +27,11 @@ class HipConv1d(ConvParams):
     (``weight``/``bias`` or ``weight_g``/``weight_v`` under weight-norm); the packed device copy is
     rebuilt lazily when they change."""
 
-    def __init__(self, *a, **k):
+    def __init__(self, *a, pad_mode="zeros", tanh=False, **k):
         super().__init__(*a, **k)
+        if pad_mode not in ("zeros", "reflect"):
+            raise ValueError(f"pad_mode must be 'zeros' or 'reflect', got {pad_mode!r}")
+        self.pad_mode, self.tanh = pad_mode, bool(tanh)
         self._h = None
         self._fin = None
         self._sig = None
@@ -45,6 +48,10 @@ class HipConv1d(ConvParams):
         with torch.cuda.device(device):
             _lib.check(_lib.lib().amp_conv_create(int(self.transposed), self.cin, self.cout, self.k, self.stride,
                                                   self.dilation, self.padding, _ptr(w), _ptr(b), ctypes.byref(h)))
+            if self.pad_mode == "reflect":
+                _lib.check(_lib.lib().amp_conv_set_option(h, _lib.AMP_CONV_OPT_PAD_REFLECT, 1))
+            if self.tanh:
+                _lib.check(_lib.lib().amp_conv_set_option(h, _lib.AMP_CONV_OPT_TANH, 1))
         self._h, self._fin, self._sig = h, weakref.finalize(self, _destroy_conv, h.value), sig
         return h
 

@@ -162,6 +162,12 @@ int amp_conv_forward(const amp_conv* c, const float* x_dev, int B, int T, float 
  * (elements).  Used by ResidualCouplingLayer.pre on x0 = x[:, :half] (modules/flow/modules.py:380-381). */
 int amp_conv_forward_strided(const amp_conv* c, const float* x_dev, long long x_batch_stride, int B, int T,
                              float slope_in, const float* res_dev, float slope_out, float* y_dev, void* stream);
+/* Per-conv options (default 0).  PAD_REFLECT: columns outside the input mirror instead of reading zero, i.e.
+ * nn.ReflectionPad1d(p) followed by an unpadded conv == this conv created with padding = p (MelGAN,
+ * models/vocoders/gan/generator/melgan.py:39,56,92); needs p < T.  TANH: tanh on store (melgan.py:94). */
+typedef enum amp_conv_option { AMP_CONV_OPT_PAD_REFLECT = 1, AMP_CONV_OPT_TANH = 2 } amp_conv_option;
+int amp_conv_set_option(amp_conv* c, int option, int value);
+
 /* One ResBlock1 iteration fused in a single kernel (hifigan.py:93-100):
  *     y = x + c2( leaky_relu( c1( leaky_relu(x, slope) ), slope ) )
  * c1: Conv1d(C, C, k, dilation d, 'same' padding), c2: Conv1d(C, C, k, dilation 1), both with bias, built

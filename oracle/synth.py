@@ -95,6 +95,30 @@ def bigvgan_param_shapes(n_in, hp):
     return _generator_param_shapes(n_in, hp, ups_fmt="ups.{i}.0", act=act)
 
 
+def melgan_param_shapes(n_mel, hp):
+    """Parameter list of the reference MelGAN Sequential (melgan.py:51-97), in state_dict order."""
+    s = OrderedDict()
+    ratios, ngf, nres = list(hp["ratios"]), hp["ngf"], hp["n_residual_layers"]
+    mult = 2 ** len(ratios)
+    idx = 1
+    _wn_conv(s, f"model.{idx}", mult * ngf, n_mel, 7)
+    idx += 1
+    for r in ratios:
+        idx += 1
+        _wn_conv(s, f"model.{idx}", mult * ngf // 2, mult * ngf, 2 * r, transposed=True)
+        idx += 1
+        for _ in range(nres):
+            dim = mult * ngf // 2
+            _wn_conv(s, f"model.{idx}.block.2", dim, dim, 3)
+            _wn_conv(s, f"model.{idx}.block.4", dim, dim, 1)
+            _wn_conv(s, f"model.{idx}.shortcut", dim, dim, 1)
+            idx += 1
+        mult //= 2
+    idx += 2
+    _wn_conv(s, f"model.{idx}", 1, ngf, 7)
+    return s
+
+
 def synth_tensor(key, shape, seed=1234, g_gain=1.0):
     gen = torch.Generator().manual_seed((zlib.crc32(key.encode()) ^ seed) & 0x7FFFFFFF)
     leaf = key.rsplit(".", 1)[-1]

@@ -472,6 +472,47 @@ def preprocess_24k():
 
 
 # ----------------------------------------------------------------------------
+# MelGAN
+# ----------------------------------------------------------------------------
+def melgan_recipe_hp():
+    """egs/vocoder/gan/melgan/exp_config.json:14-17."""
+    return dict(ratios=[8, 8, 2, 2], ngf=32, n_residual_layers=3)
+
+
+def melgan_forward(sd, hp, mel, dtype=torch.float32):
+    """MelGAN.forward models/vocoders/gan/generator/melgan.py:51-100 over the reference's Sequential keys
+    (``model.<idx>...``): ReflectionPad1d(3) + WNConv1d(k7) ; per ratio r: LeakyReLU(0.2), WNConvTranspose1d(k=2r,
+    stride r, padding r//2 + r%2, output_padding r%2), n_residual_layers x ResnetBlock(dilation 3^j) ;
+    LeakyReLU(0.2), ReflectionPad1d(3), WNConv1d(ngf -> 1, k7), Tanh."""
+    x = torch.as_tensor(mel).to(dtype)
+    ratios = list(_cfg_get(hp, "ratios"))
+    nres = int(_cfg_get(hp, "n_residual_layers"))
+    idx = 0
+    idx += 1                                                   # ReflectionPad1d(3)                  :56
+    w, b = conv_params(sd, f"model.{idx}", dtype)
+    x = F.conv1d(F.pad(x, (3, 3), mode="reflect"), w, b)        # :57-62
+    idx += 1
+    for r in ratios:
+        idx += 1                                               # LeakyReLU(0.2)                      :69
+        w, b = conv_params(sd, f"model.{idx}", dtype)
+        x = F.conv_transpose1d(F.leaky_relu(x, 0.2), w, b, stride=r, padding=r // 2 + r % 2, output_padding=r % 2)  # :70-77
+        idx += 1
+        for j in range(nres):                                  # ResnetBlock :34-48,80-83
+            d = 3**j
+            w1, b1 = conv_params(sd, f"model.{idx}.block.2", dtype)
+            w2, b2 = conv_params(sd, f"model.{idx}.block.4", dtype)
+            ws, bs = conv_params(sd, f"model.{idx}.shortcut", dtype)
+            t = F.conv1d(F.pad(F.leaky_relu(x, 0.2), (d, d), mode="reflect"), w1, b1, dilation=d)
+            t = F.conv1d(F.leaky_relu(t, 0.2), w2, b2)
+            x = F.conv1d(x, ws, bs) + t
+            idx += 1
+    idx += 2                                                   # LeakyReLU(0.2), ReflectionPad1d(3)  :91-92
+    w, b = conv_params(sd, f"model.{idx}", dtype)
+    x = F.conv1d(F.pad(F.leaky_relu(x, 0.2), (3, 3), mode="reflect"), w, b)  # :93
+    return torch.tanh(x)                                        # :94
+
+
+# ----------------------------------------------------------------------------
 # VITS posterior encoder + flow (BASELINE.json config 5)
 # ----------------------------------------------------------------------------
 def _j(prefix, name):
