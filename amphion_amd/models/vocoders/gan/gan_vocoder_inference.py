@@ -1,9 +1,10 @@
 """Drop-in for models/vocoders/gan/gan_vocoder_inference.py: same two functions, same signatures.
 
 ``vocoder_inference`` is the reference's batched forward wrapper (:11-38).  ``synthesis_audios``
-keeps the reference contract (:41-96: list of [n_mel, T_i] mels -> list of [T_i * hop] audios) but
-runs each padded batch through the generator ONCE (``forward_ragged``: the kernels pad every layer at
-each utterance's own end) instead of one utterance at a time, with identical results.
+keeps the reference contract (:41-96: list of [n_mel, T_i] mels -> list of [T_i * hop] audios) and its
+arithmetic, but runs each padded batch through the generator ONCE instead of one item at a time; with
+``ragged=True`` it instead vocodes every utterance as if alone, in length-sorted true batches
+(``forward_ragged``: the kernels pad every layer at each utterance's own end).
 """
 import torch
 
@@ -26,36 +27,25 @@ def vocoder_inference(cfg, model, mels, f0s=None, device=None, fast_inference=Fa
         return output.squeeze(1).detach().cpu()
 
 
-def synthesis_audios(cfg, model, mels, f0s=None, batch_size=None, fast_inference=False, exact=True):
+def synthesis_audios(cfg, model, mels, f0s=None, batch_size=None, fast_inference=False, ragged=False):
     """gan_vocoder_inference.py:41-96: list of [n_mel, T_i] mels -> list of [T_i * hop] audios.
 
-    ``exact=True`` (default): utterances are sorted by length, zero-padded into batches of ``batch_size``
-    and run through ``forward_ragged`` -- every kernel pads at each utterance's own end, so each audio is
-    bit-identical to the reference's one-utterance-at-a-time loop while the GPU sees true batches.
-    ``exact=False`` is the reference's *batched* behaviour (`pad_mels_to_tensors` + crop): utterances
-    shorter than their batch differ from their B=1 result inside the receptive field of the tail.
+    Default (``ragged=False``) = the reference's arithmetic: ``pad_mels_to_tensors`` zero-pads the list, in order,
+    into batches of ``batch_size``; the reference then runs every (padded) item through the generator ONE AT A
+    TIME and crops to ``frames * hop`` -- here each padded batch is ONE forward, which gives bit-identical audio
+    because items of a batch never interact.  (Note what that arithmetic means: an utterance shorter than its
+    batch carries the zero mel frames behind it through the network, so the last receptive field of its audio
+    depends on the batch it was put in.)
+
+    ``ragged=True``: utterances are sorted by length and run through ``forward_ragged`` -- every kernel pads at
+    each utterance's own end, so each audio equals that utterance vocoded ALONE, independent of batching.
     """
     device = next(model.parameters()).device
-    if f0s is not None:
-        raise NotImplementedError("f0-conditioned generators (NSF-HiFiGAN) are outside the HiFi-GAN/BigVGAN hot path")
     hop = model.cfg.preprocess.hop_size
     audios = [None] * len(mels)
-    if exact and not hasattr(model, "forward_ragged"):
-        # generators without per-utterance lengths in their kernels (MelGAN): one true batch per distinct
-        # length -- still bit-identical to the reference's B=1 loop
-        by_len = {}
-        for i, m in enumerate(mels):
-            by_len.setdefault(int(m.shape[-1]), []).append(i)
-        for T, idxs in by_len.items():
-            step = len(idxs) if not batch_size else int(batch_size)
-            for s in range(0, len(idxs), step):
-                grp = idxs[s:s + step]
-                batch = torch.stack([torch.as_tensor(mels[i], dtype=torch.float32).cpu() for i in grp])
-                out = vocoder_inference(cfg, model, batch, device=device, fast_inference=fast_inference)
-                for r, i in enumerate(grp):
-                    audios[i] = out[r][: T * hop]
-        return audios
-    if exact:
+    if ragged:
+        if f0s is not None or not hasattr(model, "forward_ragged"):
+            raise NotImplementedError("ragged=True needs a generator with forward_ragged and no f0 input")
         order = sorted(range(len(mels)), key=lambda i: int(mels[i].shape[-1]), reverse=True)
         step = len(order) if not batch_size else int(batch_size)
         model.eval()
@@ -63,19 +53,25 @@ def synthesis_audios(cfg, model, mels, f0s=None, batch_size=None, fast_inference
             for s in range(0, len(order), step):
                 grp = order[s:s + step]
                 lens = [int(mels[i].shape[-1]) for i in grp]
-                Tmax = lens[0]
                 n_mel = int(mels[grp[0]].shape[0])
-                batch = torch.zeros((len(grp), n_mel, Tmax), dtype=torch.float32)
+                batch = torch.zeros((len(grp), n_mel, lens[0]), dtype=torch.float32)
                 for r, i in enumerate(grp):
                     batch[r, :, : lens[r]] = torch.as_tensor(mels[i], dtype=torch.float32)
                 out = model.forward_ragged(batch.to(device), lens).squeeze(1).cpu()
                 for r, i in enumerate(grp):
                     audios[i] = out[r, : lens[r] * hop].clone()
         return audios
+    mels = [torch.as_tensor(m, dtype=torch.float32).cpu() for m in mels]
     mel_batches, mel_frames = pad_mels_to_tensors(mels, batch_size)
     k = 0
     for mel_batch, mel_frame in zip(mel_batches, mel_frames):
-        out = vocoder_inference(cfg, model, mel_batch, device=device, fast_inference=fast_inference)
+        f0_batch = None
+        if f0s is not None:   # pad_f0_to_tensors (utils/util.py:83-111): zero-padded [B, T] per batch
+            f0_batch = torch.zeros((mel_batch.shape[0], mel_batch.shape[-1]), dtype=torch.float32)
+            for i in range(mel_batch.shape[0]):
+                f = torch.as_tensor(f0s[k + i], dtype=torch.float32).reshape(-1).cpu()
+                f0_batch[i, : f.shape[0]] = f[: mel_batch.shape[-1]]
+        out = vocoder_inference(cfg, model, mel_batch, f0s=f0_batch, device=device, fast_inference=fast_inference)
         for i in range(mel_batch.shape[0]):
             audios[k] = out[i][: int(mel_frame[i]) * hop]
             k += 1

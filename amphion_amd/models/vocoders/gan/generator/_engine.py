@@ -152,6 +152,10 @@ class HipGenerator(nn.Module):
             h *= d.upsample_rates[i]
         return h
 
+    def _amp_weights(self):
+        """(reference key, tensor) pairs handed to ``amp_gen_set_weight``; subclasses may filter / transform."""
+        return self.state_dict().items()
+
     def _amp_signature(self):
         return tuple((k, v.data_ptr(), v._version, tuple(v.shape)) for k, v in self.state_dict(keep_vars=True).items())
 
@@ -171,7 +175,7 @@ class HipGenerator(nn.Module):
         _lib.check(L.amp_gen_create(ctypes.byref(desc), ctypes.byref(h)))
         fin = weakref.finalize(self, _destroy_handle, h.value)
         try:
-            for key, t in self.state_dict().items():
+            for key, t in self._amp_weights():
                 c = t.detach().to("cpu", torch.float32).contiguous()
                 shape = (ctypes.c_int64 * c.dim())(*c.shape)
                 _lib.check(L.amp_gen_set_weight(h, key.encode(), ctypes.c_void_p(c.data_ptr()), shape, c.dim()))

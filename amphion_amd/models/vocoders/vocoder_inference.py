@@ -14,12 +14,13 @@ from pathlib import Path
 import torch
 
 from amphion_amd.models.vocoders.gan import gan_vocoder_inference
-from amphion_amd.models.vocoders.gan.generator import bigvgan, hifigan, melgan
+from amphion_amd.models.vocoders.gan.generator import bigvgan, hifigan, melgan, nsfhifigan
 
 _vocoders = {
     "bigvgan": bigvgan.BigVGAN,
     "hifigan": hifigan.HiFiGAN,
     "melgan": melgan.MelGAN,
+    "nsfhifigan": nsfhifigan.NSFHiFiGAN,
 }
 
 # Forward call for the generalized Inferencer (vocoder_inference.py:52-62)
@@ -27,6 +28,7 @@ _vocoder_forward_funcs = {
     "bigvgan": gan_vocoder_inference.vocoder_inference,
     "hifigan": gan_vocoder_inference.vocoder_inference,
     "melgan": gan_vocoder_inference.vocoder_inference,
+    "nsfhifigan": gan_vocoder_inference.vocoder_inference,
 }
 
 # APIs for other tasks, e.g. SVC, TTS, TTA (vocoder_inference.py:65-75)
@@ -34,6 +36,7 @@ _vocoder_infer_funcs = {
     "bigvgan": gan_vocoder_inference.synthesis_audios,
     "hifigan": gan_vocoder_inference.synthesis_audios,
     "melgan": gan_vocoder_inference.synthesis_audios,
+    "nsfhifigan": gan_vocoder_inference.synthesis_audios,
 }
 
 

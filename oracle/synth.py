@@ -95,6 +95,29 @@ def bigvgan_param_shapes(n_in, hp):
     return _generator_param_shapes(n_in, hp, ups_fmt="ups.{i}.0", act=act)
 
 
+def nsfhifigan_param_shapes(n_mel, hp):
+    """Parameter list of the reference NSFHiFiGAN (nsfhifigan.py:181-256) in state_dict order:
+    m_source.l_linear, noise_convs (plain Conv1d: weight then bias), conv_pre, ups, resblocks, conv_post."""
+    s = OrderedDict()
+    c0 = hp["upsample_initial_channel"]
+    rates = list(hp["upsample_rates"])
+    s["m_source.l_linear.weight"] = (1, hp["harmonic_num"] + 1)
+    s["m_source.l_linear.bias"] = (1,)
+    for i in range(len(rates)):
+        c_cur = c0 // 2 ** (i + 1)
+        if i + 1 < len(rates):
+            st = 1
+            for r in rates[i + 1:]:
+                st *= r
+            s[f"noise_convs.{i}.weight"] = (c_cur, 1, 2 * st)
+        else:
+            s[f"noise_convs.{i}.weight"] = (c_cur, 1, 1)
+        s[f"noise_convs.{i}.bias"] = (c_cur,)
+    g = _generator_param_shapes(n_mel, hp)
+    s.update(g)
+    return s
+
+
 def melgan_param_shapes(n_mel, hp):
     """Parameter list of the reference MelGAN Sequential (melgan.py:51-97), in state_dict order."""
     s = OrderedDict()

@@ -472,6 +472,41 @@ def preprocess_24k():
 
 
 # ----------------------------------------------------------------------------
+# NSF-HiFiGAN
+# ----------------------------------------------------------------------------
+def nsfhifigan_forward(sd, hp, mel, f0=None, dtype=torch.float32):
+    """NSFHiFiGAN.forward models/vocoders/gan/generator/nsfhifigan.py:258-283.
+
+    The harmonic source and ``noise_convs`` outputs are computed by the reference and then DISCARDED:
+    ``x_source = x[:, :, :length]`` (:269) replaces them, so ``x = x + x_source`` doubles x and the result is
+    independent of ``f0`` (and of SineGen's random draws).  ``length`` equals both lengths (T * prod(rates so
+    far)), so the crops are no-ops.  The restatement therefore never touches m_source / noise_convs.
+    """
+    x = torch.as_tensor(mel).to(dtype)
+    rates = list(_cfg_get(hp, "upsample_rates"))
+    uks = list(_cfg_get(hp, "upsample_kernel_sizes"))
+    rks = list(_cfg_get(hp, "resblock_kernel_sizes"))
+    rds = [list(d) for d in _cfg_get(hp, "resblock_dilation_sizes")]
+    rb = resblock1 if str(_cfg_get(hp, "resblock")) == "1" else resblock2
+    nk = len(rks)
+    w, b = conv_params(sd, "conv_pre", dtype)
+    x = F.conv1d(x, w, b, padding=3)                                   # :260
+    for i, (u, k) in enumerate(zip(rates, uks)):
+        x = F.leaky_relu(x, LRELU_SLOPE)                               # :262
+        w, b = conv_params(sd, f"ups.{i}", dtype)
+        x = F.conv_transpose1d(x, w, b, stride=u, padding=(k - u) // 2)  # :263
+        x = x + x                                                      # :266-271 (x_source := x)
+        xs = None
+        for j in range(nk):                                            # :272-277
+            r = rb(sd, f"resblocks.{i * nk + j}", x, rks[j], rds[j], dtype)
+            xs = r if xs is None else xs + r
+        x = xs / nk                                                    # :278
+    x = F.leaky_relu(x)                                                # :279
+    w, b = conv_params(sd, "conv_post", dtype)
+    return torch.tanh(F.conv1d(x, w, b, padding=3))                    # :280-281
+
+
+# ----------------------------------------------------------------------------
 # MelGAN (SURVEY.md §8 f.2)
 # ----------------------------------------------------------------------------
 def melgan_recipe_hp():

@@ -34,21 +34,30 @@ def test_vocoder_inference_and_synthesis_audios(tmp_path):
         ref = vo.hifigan_forward(sd, hp, mel).squeeze(1)
     assert (out - ref).abs().max().item() <= 1e-4
 
-    # ragged list API: results equal the reference's per-utterance (B=1) loop
-    mels = [synth.synth_mel(1, 80, T, seed=10 + T)[0] for T in (5, 9, 5, 14)]
+    # list API, default = the reference's arithmetic (gan_vocoder_inference.py:41-96): every utterance is
+    # zero-padded to the longest of ITS batch (list order, batch_size 2), vocoded, cropped
+    Ts = (5, 9, 5, 14)
+    mels = [synth.synth_mel(1, 80, T, seed=10 + T)[0] for T in Ts]
     auds = synthesis_audios(cfg, model, [m.cuda() for m in mels], batch_size=2)
-    assert [a.shape[0] for a in auds] == [T * 256 for T in (5, 9, 5, 14)]
+    assert [a.shape[0] for a in auds] == [T * 256 for T in Ts]
     with torch.no_grad():
-        for m, a in zip(mels, auds):
+        for i, (m, a) in enumerate(zip(mels, auds)):
+            Tpad = max(Ts[2 * (i // 2)], Ts[2 * (i // 2) + 1])
+            padded = torch.zeros(1, 80, Tpad)
+            padded[0, :, : m.shape[-1]] = m
+            r = vo.hifigan_forward(sd, hp, padded)[0, 0, : m.shape[-1] * 256]
+            assert (a - r).abs().max().item() <= 1e-4
+    # ragged=True: every utterance as if vocoded alone, whatever the batching
+    auds2 = synthesis_audios(cfg, model, [m.cuda() for m in mels], batch_size=4, ragged=True)
+    assert [a.shape[0] for a in auds2] == [T * 256 for T in Ts]
+    with torch.no_grad():
+        for m, a in zip(mels, auds2):
             r = vo.hifigan_forward(sd, hp, m.unsqueeze(0))[0, 0]
             assert (a - r).abs().max().item() <= 1e-4
-    # padded-batch mode keeps shapes; interior samples agree, only the tail receptive field may differ
-    auds2 = synthesis_audios(cfg, model, [m.cuda() for m in mels], batch_size=4, exact=False)
-    assert [a.shape[0] for a in auds2] == [T * 256 for T in (5, 9, 5, 14)]
-    assert (auds2[3] - auds[3]).abs().max().item() <= 1e-4          # longest item is never padded
+    assert (auds2[3] - auds[3]).abs().max().item() <= 1e-4          # the longest item of a batch is never padded
 
     pred = [m.numpy().T for m in mels]                               # synthesis() takes [T, n_mel] arrays
-    auds3 = vi.synthesis(cfg, str(tmp_path / "g.pt"), None, pred, batch_size=64)
+    auds3 = vi.synthesis(cfg, str(tmp_path / "g.pt"), None, pred, batch_size=2)   # same batching => same audio
     for a, b in zip(auds, auds3):
         assert torch.equal(a, b)
 
