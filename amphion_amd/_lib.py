@@ -83,6 +83,9 @@ _SIGNATURES = {
     "amp_conv_out_len": (c_int, [c_void_p, c_int]),
     "amp_conv_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_float, c_void_p, c_void_p]),
     "amp_conv_forward_strided": (c_int, [c_void_p, c_void_p, ctypes.c_longlong, c_int, c_int, c_float, c_void_p, c_float, c_void_p, c_void_p]),
+    "amp_conv_forward_mrf": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_float, c_void_p]),
+    "amp_apnet_polar": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "amp_istft_same": (c_int, [POINTER(amp_mel_desc), c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "amp_conv_set_option": (c_int, [c_void_p, c_int, c_int]),
     "amp_pair_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
     "amp_conv_destroy": (None, [c_void_p]),

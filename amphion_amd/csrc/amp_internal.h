@@ -113,6 +113,9 @@ hipError_t launch_flip_channels(const float* x, float* y, int B, int C, int T, h
 hipError_t launch_posterior_sample(const float* stats, const float* eps, const int* lens, float* z, int B, int C, int T,
                                    hipStream_t stream);
 
+hipError_t launch_apnet_polar(const float* logamp, const float* R, const float* I, size_t n, float* pha, float* rea,
+                              float* imag, hipStream_t stream);
+
 // mel front end (mel.hip)
 hipError_t launch_mel(const amp_mel_desc& d, const float* wav, int B, int L, int F, const float* window,
                       const float* melbasis, float* mel, float* mag, float* re, float* im, hipStream_t stream);

@@ -944,6 +944,21 @@ int amp_pair_forward(const amp_conv* c1, const amp_conv* c2, const float* x_dev,
     return pair_run(c1, c2, x_dev, B, T, slope, y_dev, 0, 1.f, (hipStream_t)stream);
 }
 
+int amp_conv_forward_mrf(const amp_conv* c, const float* x_dev, int B, int T, float slope_in, const float* res_dev,
+                         float* y_dev, int mode, float div, void* stream) {
+    if (!c || !x_dev || !y_dev) { set_error("amp_conv_forward_mrf: null argument"); return AMP_ERR_INVALID; }
+    if (x_dev == y_dev) { set_error("amp_conv_forward_mrf: x and y must not alias (the conv reads a halo)"); return AMP_ERR_INVALID; }
+    if (mode < 0 || mode > 2 || (mode == 2 && !(div > 0.f))) { set_error("amp_conv_forward_mrf: mode=%d div=%g", mode, (double)div); return AMP_ERR_INVALID; }
+    return conv_run(c, x_dev, B, T, slope_in, res_dev, 1.f, y_dev, mode, div, (hipStream_t)stream);
+}
+
+int amp_apnet_polar(const float* logamp_dev, const float* r_dev, const float* i_dev, size_t n, float* pha_dev,
+                    float* rea_dev, float* imag_dev, void* stream) {
+    if (!logamp_dev || !r_dev || !i_dev || !pha_dev || !rea_dev || !imag_dev || n == 0) { set_error("amp_apnet_polar: bad argument"); return AMP_ERR_INVALID; }
+    AMP_HIP(launch_apnet_polar(logamp_dev, r_dev, i_dev, n, pha_dev, rea_dev, imag_dev, (hipStream_t)stream));
+    return AMP_OK;
+}
+
 int amp_conv_set_option(amp_conv* c, int option, int value) {
     if (!c) { set_error("amp_conv_set_option: null handle"); return AMP_ERR_INVALID; }
     if (option == AMP_CONV_OPT_PAD_REFLECT) {

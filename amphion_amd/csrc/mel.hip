@@ -108,7 +108,7 @@ hipError_t launch_mel(const amp_mel_desc& d, const float* wav, int B, int L, int
 //   out[m]     = (n_fft/hop) * sum_f frame_f[m - f*hop] / wss[m]   where wss[m] > tiny      (kernel 2)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void istft_frames_kernel(const float* __restrict__ mag, const float* __restrict__ phase,
-                                                           int F, int n_fft, int log2n, float inv_scale,
+                                                           int polar, int F, int n_fft, int log2n, float inv_scale,
                                                            const float* __restrict__ window, float* __restrict__ frames) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float2* buf0 = reinterpret_cast<float2*>(smem);   // [n_fft]
@@ -122,11 +122,18 @@ __global__ __launch_bounds__(256) void istft_frames_kernel(const float* __restri
     // ifft(X) = conj(fft(conj(X))) / N with the Hermitian extension X[N-k] = conj(X[k])
     for (int k = tid; k < bins; k += 256) {
         const size_t o = ((size_t)b * bins + k) * F + f;
-        const float m = mag[o];
-        float sn, cs;
-        sincosf(phase[o], &sn, &cs);
-        const float re = m * cs;
-        const float im = (k == 0 || k == half) ? 0.f : m * sn;
+        float re, im;
+        if (polar) {          // (magnitude, phase)
+            const float m = mag[o];
+            float sn, cs;
+            sincosf(phase[o], &sn, &cs);
+            re = m * cs;
+            im = m * sn;
+        } else {              // (real, imaginary) -- APNet's ISTFT head (apnet.py:385-393)
+            re = mag[o];
+            im = phase[o];
+        }
+        if (k == 0 || k == half) im = 0.f;   // irfft ignores them (zero rows of the pseudo-inverse basis)
         buf0[k] = make_float2(re, -im);
         if (k > 0 && k < half) buf0[n_fft - k] = make_float2(re, im);
     }
@@ -160,12 +167,12 @@ __global__ __launch_bounds__(256) void istft_frames_kernel(const float* __restri
 }
 
 __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict__ frames, const float* __restrict__ wss,
-                                                        int F, int n_fft, int hop, int Lout, float scale, float tiny,
-                                                        float* __restrict__ wav) {
+                                                        int F, int n_fft, int hop, int crop, int Lout, float scale,
+                                                        float tiny, float* __restrict__ wav) {
     const int b = blockIdx.y;
     const int mo = blockIdx.x * 256 + threadIdx.x;
     if (mo >= Lout) return;
-    const int m = mo + (n_fft >> 1);
+    const int m = mo + crop;
     int f0 = (m - n_fft + hop) / hop;          // ceil((m - n_fft + 1) / hop) for m - n_fft + 1 > 0
     if (m - n_fft + 1 <= 0) f0 = 0;
     int f1 = m / hop;
@@ -178,20 +185,23 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
     wav[(size_t)b * Lout + mo] = acc * scale;
 }
 
-hipError_t launch_istft(const amp_mel_desc& d, const float* mag, const float* phase, int B, int F, const float* window,
+// mode 0: STFT.inverse (stft.py:183-222): polar input, crop n_fft/2, out = scale * sum / wss where wss > tiny
+// mode 1: APNet ISTFT "same" (apnet.py:46-101): re/im input, crop (win - hop)/2, out = sum / envelope, L = F * hop
+hipError_t launch_istft(const amp_mel_desc& d, int mode, const float* a, const float* b, int B, int F, const float* window,
                         const float* wss, float* frames, float* wav, hipStream_t stream) {
     int log2n = 0;
     while ((1 << log2n) < d.n_fft) ++log2n;
     const size_t lds = (size_t)(2 * d.n_fft + d.n_fft / 2) * sizeof(float2);
-    const float scale = (float)d.n_fft / (float)d.hop_size;
-    hipLaunchKernelGGL(istft_frames_kernel, dim3((unsigned)((size_t)B * F)), dim3(256), lds, stream, mag, phase, F, d.n_fft,
-                       log2n, 1.0f / scale, window, frames);
+    const float scale = mode == 0 ? (float)d.n_fft / (float)d.hop_size : 1.0f;
+    hipLaunchKernelGGL(istft_frames_kernel, dim3((unsigned)((size_t)B * F)), dim3(256), lds, stream, a, b, mode == 0 ? 1 : 0, F,
+                       d.n_fft, log2n, 1.0f / scale, window, frames);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const int Lout = d.hop_size * (F - 1);
+    const int crop = mode == 0 ? d.n_fft / 2 : (d.win_size - d.hop_size) / 2;
+    const int Lout = mode == 0 ? d.hop_size * (F - 1) : d.hop_size * (F - 1) + d.win_size - 2 * crop;
     if (Lout <= 0) return hipSuccess;
     hipLaunchKernelGGL(istft_ola_kernel, dim3((unsigned)((Lout + 255) / 256), (unsigned)B), dim3(256), 0, stream, frames, wss, F,
-                       d.n_fft, d.hop_size, Lout, scale, 1.17549435e-38f, wav);
+                       d.n_fft, d.hop_size, crop, Lout, scale, mode == 0 ? 1.17549435e-38f : -1.0f, wav);
     return hipGetLastError();
 }
 
@@ -236,8 +246,21 @@ int amp_istft_forward(const amp_mel_desc* d, const float* mag_dev, const float* 
         return AMP_ERR_UNSUPPORTED;
     }
     if (d->hop_size <= 0 || d->hop_size > d->n_fft || B <= 0 || F <= 1) { set_error("amp_istft_forward: hop=%d B=%d F=%d", d->hop_size, B, F); return AMP_ERR_INVALID; }
-    hipError_t e = launch_istft(*d, mag_dev, phase_dev, B, F, window_dev, wss_dev, frames_ws_dev, wav_dev, (hipStream_t)stream);
+    hipError_t e = launch_istft(*d, 0, mag_dev, phase_dev, B, F, window_dev, wss_dev, frames_ws_dev, wav_dev, (hipStream_t)stream);
     if (e != hipSuccess) { set_error("amp_istft_forward: %s", hipGetErrorString(e)); return AMP_ERR_HIP; }
+    return AMP_OK;
+}
+
+int amp_istft_same(const amp_mel_desc* d, const float* re_dev, const float* im_dev, int B, int F, const float* window_dev,
+                   const float* envelope_dev, float* frames_ws_dev, float* wav_dev, void* stream) {
+    if (!d || !re_dev || !im_dev || !window_dev || !envelope_dev || !frames_ws_dev || !wav_dev) { set_error("amp_istft_same: null argument"); return AMP_ERR_INVALID; }
+    if (d->n_fft < 64 || d->n_fft > 4096 || (d->n_fft & (d->n_fft - 1)) != 0 || d->win_size != d->n_fft) {
+        set_error("amp_istft_same: n_fft=%d must be a power of two in [64, 4096] and equal win_size=%d", d->n_fft, d->win_size);
+        return AMP_ERR_UNSUPPORTED;
+    }
+    if (d->hop_size <= 0 || d->hop_size > d->n_fft || ((d->win_size - d->hop_size) & 1) || B <= 0 || F <= 0) { set_error("amp_istft_same: hop=%d B=%d F=%d", d->hop_size, B, F); return AMP_ERR_INVALID; }
+    hipError_t e = launch_istft(*d, 1, re_dev, im_dev, B, F, window_dev, envelope_dev, frames_ws_dev, wav_dev, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("amp_istft_same: %s", hipGetErrorString(e)); return AMP_ERR_HIP; }
     return AMP_OK;
 }
 

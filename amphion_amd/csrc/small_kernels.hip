@@ -264,6 +264,29 @@ hipError_t launch_act1d(const float* x, float* y, int B, int C, int T, const flo
     return hipGetLastError();
 }
 
+// APNet head (apnet.py:379-383): pha = atan2(I, R); rea = exp(logamp) * cos(pha); imag = exp(logamp) * sin(pha)
+__global__ __launch_bounds__(256) void apnet_polar_kernel(const float* __restrict__ logamp, const float* __restrict__ R,
+                                                          const float* __restrict__ I, size_t n, float* __restrict__ pha,
+                                                          float* __restrict__ rea, float* __restrict__ imag) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float p = atan2f(I[i], R[i]);
+        const float m = expf(logamp[i]);
+        float sn, cs;
+        sincosf(p, &sn, &cs);
+        pha[i] = p;
+        rea[i] = m * cs;
+        imag[i] = m * sn;
+    }
+}
+
+hipError_t launch_apnet_polar(const float* logamp, const float* R, const float* I, size_t n, float* pha, float* rea,
+                              float* imag, hipStream_t stream) {
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 65535u * 16u) blocks = 65535u * 16u;
+    hipLaunchKernelGGL(apnet_polar_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, logamp, R, I, n, pha, rea, imag);
+    return hipGetLastError();
+}
+
 __global__ void add_channel_bias_kernel(float* __restrict__ y, const float* __restrict__ cb, int T) {
     const int bc = blockIdx.x;
     const float v = cb[bc];

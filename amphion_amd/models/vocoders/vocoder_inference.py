@@ -14,9 +14,10 @@ from pathlib import Path
 import torch
 
 from amphion_amd.models.vocoders.gan import gan_vocoder_inference
-from amphion_amd.models.vocoders.gan.generator import bigvgan, hifigan, melgan, nsfhifigan
+from amphion_amd.models.vocoders.gan.generator import apnet, bigvgan, hifigan, melgan, nsfhifigan
 
 _vocoders = {
+    "apnet": apnet.APNet,
     "bigvgan": bigvgan.BigVGAN,
     "hifigan": hifigan.HiFiGAN,
     "melgan": melgan.MelGAN,
@@ -25,6 +26,7 @@ _vocoders = {
 
 # Forward call for the generalized Inferencer (vocoder_inference.py:52-62)
 _vocoder_forward_funcs = {
+    "apnet": gan_vocoder_inference.vocoder_inference,
     "bigvgan": gan_vocoder_inference.vocoder_inference,
     "hifigan": gan_vocoder_inference.vocoder_inference,
     "melgan": gan_vocoder_inference.vocoder_inference,
@@ -33,6 +35,7 @@ _vocoder_forward_funcs = {
 
 # APIs for other tasks, e.g. SVC, TTS, TTA (vocoder_inference.py:65-75)
 _vocoder_infer_funcs = {
+    "apnet": gan_vocoder_inference.synthesis_audios,
     "bigvgan": gan_vocoder_inference.synthesis_audios,
     "hifigan": gan_vocoder_inference.synthesis_audios,
     "melgan": gan_vocoder_inference.synthesis_audios,

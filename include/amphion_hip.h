@@ -162,6 +162,16 @@ int amp_conv_forward(const amp_conv* c, const float* x_dev, int B, int T, float 
  * (elements).  Used by ResidualCouplingLayer.pre on x0 = x[:, :half] (modules/flow/modules.py:380-381). */
 int amp_conv_forward_strided(const amp_conv* c, const float* x_dev, long long x_batch_stride, int B, int T,
                              float slope_in, const float* res_dev, float slope_out, float* y_dev, void* stream);
+/* amp_conv_forward with the MRF accumulation of hifigan.py:208-214 / apnet.py:355-363 exposed:
+ *   v = conv(lrelu_in(x)) + bias (+ res);   mode 0: y = v   1: y = y + v   2: y = (y + v) / div. */
+int amp_conv_forward_mrf(const amp_conv* c, const float* x_dev, int B, int T, float slope_in, const float* res_dev,
+                         float* y_dev, int mode, float div, void* stream);
+
+/* APNet head, element-wise over n values (models/vocoders/gan/generator/apnet.py:379-383):
+ * pha = atan2(I, R); rea = exp(logamp) * cos(pha); imag = exp(logamp) * sin(pha). */
+int amp_apnet_polar(const float* logamp_dev, const float* r_dev, const float* i_dev, size_t n, float* pha_dev,
+                    float* rea_dev, float* imag_dev, void* stream);
+
 /* Per-conv options (default 0).  PAD_REFLECT: columns outside the input mirror instead of reading zero, i.e.
  * nn.ReflectionPad1d(p) followed by an unpadded conv == this conv created with padding = p (MelGAN,
  * models/vocoders/gan/generator/melgan.py:39,56,92); needs p < T.  TANH: tanh on store (melgan.py:94). */
@@ -243,6 +253,12 @@ int amp_mel_forward(const amp_mel_desc* d, const float* wav_dev, int B, int L, c
  * frames_ws_dev: scratch of B*F*n_fft floats. */
 int amp_istft_forward(const amp_mel_desc* d, const float* mag_dev, const float* phase_dev, int B, int F,
                       const float* window_dev, const float* wss_dev, float* frames_ws_dev, float* wav_dev, void* stream);
+
+/* APNet's ISTFT with "same" padding (apnet.py:16-101): complex spectrogram (re, im) [B, n_fft/2+1, F] ->
+ * waveform [B, F * hop]: overlap-add of irfft(spec) * window, cropped by (win - hop)/2 per side, divided by the
+ * window envelope.  envelope_dev [hop*(F-1) + win] = overlap-added window^2 (uncropped); needs win_size == n_fft. */
+int amp_istft_same(const amp_mel_desc* d, const float* re_dev, const float* im_dev, int B, int F, const float* window_dev,
+                   const float* envelope_dev, float* frames_ws_dev, float* wav_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -95,6 +95,25 @@ def bigvgan_param_shapes(n_in, hp):
     return _generator_param_shapes(n_in, hp, ups_fmt="ups.{i}.0", act=act)
 
 
+def apnet_param_shapes(n_mel, n_fft, hp):
+    """Parameter list of the reference APNet (apnet.py:280-352) in state_dict order."""
+    s = OrderedDict()
+    bins = n_fft // 2 + 1
+    _wn_conv(s, "ASP_input_conv", hp["ASP_channel"], n_mel, hp["ASP_input_conv_kernel_size"])
+    _wn_conv(s, "PSP_input_conv", hp["PSP_channel"], n_mel, hp["PSP_input_conv_kernel_size"])
+    for pre in ("ASP", "PSP"):
+        ch = hp[f"{pre}_channel"]
+        for j, (k, d) in enumerate(zip(hp[f"{pre}_resblock_kernel_sizes"], hp[f"{pre}_resblock_dilation_sizes"])):
+            for p in range(len(d)):
+                _wn_conv(s, f"{pre}_ResNet.{j}.convs1.{p}", ch, ch, k)
+            for p in range(len(d)):
+                _wn_conv(s, f"{pre}_ResNet.{j}.convs2.{p}", ch, ch, k)
+    _wn_conv(s, "ASP_output_conv", bins, hp["ASP_channel"], hp["ASP_output_conv_kernel_size"])
+    _wn_conv(s, "PSP_output_R_conv", bins, hp["PSP_channel"], hp["PSP_output_R_conv_kernel_size"])
+    _wn_conv(s, "PSP_output_I_conv", bins, hp["PSP_channel"], hp["PSP_output_I_conv_kernel_size"])
+    return s
+
+
 def nsfhifigan_param_shapes(n_mel, hp):
     """Parameter list of the reference NSFHiFiGAN (nsfhifigan.py:181-256) in state_dict order:
     m_source.l_linear, noise_convs (plain Conv1d: weight then bias), conv_pre, ups, resblocks, conv_post."""

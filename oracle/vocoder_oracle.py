@@ -472,6 +472,62 @@ def preprocess_24k():
 
 
 # ----------------------------------------------------------------------------
+# APNet
+# ----------------------------------------------------------------------------
+def apnet_recipe_hp():
+    """egs/vocoder/gan/apnet/exp_config.json:16-29."""
+    return dict(ASP_channel=512, ASP_resblock_kernel_sizes=[3, 7, 11], ASP_resblock_dilation_sizes=[[1, 3, 5]] * 3,
+                ASP_input_conv_kernel_size=7, ASP_output_conv_kernel_size=7, PSP_channel=512,
+                PSP_resblock_kernel_sizes=[3, 7, 11], PSP_resblock_dilation_sizes=[[1, 3, 5]] * 3,
+                PSP_input_conv_kernel_size=7, PSP_output_R_conv_kernel_size=7, PSP_output_I_conv_kernel_size=7)
+
+
+def apnet_istft_same(spec, n_fft, hop, win, window):
+    """ISTFT.forward apnet.py:46-101, padding="same"."""
+    pad = (win - hop) // 2
+    B, N, T = spec.shape
+    ifft = torch.fft.irfft(spec, n_fft, dim=1, norm="backward") * window[None, :, None]
+    output_size = (T - 1) * hop + win
+    y = F.fold(ifft, output_size=(1, output_size), kernel_size=(1, win), stride=(1, hop))[:, 0, 0, pad:-pad]
+    wsq = window.square().expand(1, T, -1).transpose(1, 2)
+    env = F.fold(wsq, output_size=(1, output_size), kernel_size=(1, win), stride=(1, hop)).squeeze()[pad:-pad]
+    return y / env
+
+
+def apnet_forward(sd, hp, pp, mel, dtype=torch.float32):
+    """APNet.forward apnet.py:354-399 -> (logamp, pha, rea, imag, audio[B, 1, L])."""
+    mel = torch.as_tensor(mel).to(dtype)
+
+    def branch(prefix, nk_key):
+        ks = list(_cfg_get(hp, f"{prefix}_resblock_kernel_sizes"))
+        ds = [list(d) for d in _cfg_get(hp, f"{prefix}_resblock_dilation_sizes")]
+        w, b = conv_params(sd, f"{prefix}_input_conv", dtype)
+        k_in = int(_cfg_get(hp, f"{prefix}_input_conv_kernel_size"))
+        x = F.conv1d(mel, w, b, padding=get_padding(k_in, 1))
+        xs = None
+        for j in range(len(ks)):
+            r = resblock1(sd, f"{prefix}_ResNet.{j}", x, ks[j], ds[j], dtype)
+            xs = r if xs is None else xs + r
+        return F.leaky_relu(xs / len(ks))
+
+    a = branch("ASP", None)
+    w, b = conv_params(sd, "ASP_output_conv", dtype)
+    logamp = F.conv1d(a, w, b, padding=get_padding(int(_cfg_get(hp, "ASP_output_conv_kernel_size")), 1))
+    p = branch("PSP", None)
+    w, b = conv_params(sd, "PSP_output_R_conv", dtype)
+    R = F.conv1d(p, w, b, padding=get_padding(int(_cfg_get(hp, "PSP_output_R_conv_kernel_size")), 1))
+    w, b = conv_params(sd, "PSP_output_I_conv", dtype)
+    I = F.conv1d(p, w, b, padding=get_padding(int(_cfg_get(hp, "PSP_output_I_conv_kernel_size")), 1))
+    pha = torch.atan2(I, R)
+    rea = torch.exp(logamp) * torch.cos(pha)
+    imag = torch.exp(logamp) * torch.sin(pha)
+    spec = torch.view_as_complex(torch.cat((rea.unsqueeze(-1), imag.unsqueeze(-1)), -1))
+    n_fft, hop, win = int(_cfg_get(pp, "n_fft")), int(_cfg_get(pp, "hop_size")), int(_cfg_get(pp, "win_size"))
+    audio = apnet_istft_same(spec, n_fft, hop, win, torch.hann_window(win).to(dtype))
+    return logamp, pha, rea, imag, audio.unsqueeze(1)
+
+
+# ----------------------------------------------------------------------------
 # NSF-HiFiGAN (SURVEY.md §8 f.2)
 # ----------------------------------------------------------------------------
 def nsfhifigan_forward(sd, hp, mel, f0=None, dtype=torch.float32):

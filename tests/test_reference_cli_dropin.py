@@ -68,7 +68,8 @@ def test_hook_patches_reference_registries():
         "assert m._vocoder_forward_funcs['hifigan'].__module__.startswith('amphion_amd');"
         "assert m._vocoder_infer_funcs['bigvgan'].__module__.startswith('amphion_amd');"
         "assert m._vocoders['melgan'].__module__.startswith('amphion_amd');"
-            "assert m._vocoders['apnet'].__module__.startswith('models.');"
+            "assert m._vocoders['apnet'].__module__.startswith('amphion_amd');"
+            "assert m._vocoders['diffwave'].__module__.startswith('models.');"
         "print('PATCHED', m.__amphion_amd_patched__)"
     )
     env = dict(os.environ)
