@@ -98,6 +98,7 @@ _SIGNATURES = {
     "amp_antialias_snake": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "amp_istft_forward": (c_int, [POINTER(amp_mel_desc), c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "amp_mel_num_frames": (c_int, [POINTER(amp_mel_desc), c_int]),
+    "amp_mel_forward_ragged": (c_int, [POINTER(amp_mel_desc), c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "amp_mel_forward": (c_int, [POINTER(amp_mel_desc), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 

@@ -117,7 +117,7 @@ hipError_t launch_apnet_polar(const float* logamp, const float* R, const float* 
                               float* imag, hipStream_t stream);
 
 // mel front end (mel.hip)
-hipError_t launch_mel(const amp_mel_desc& d, const float* wav, int B, int L, int F, const float* window,
+hipError_t launch_mel(const amp_mel_desc& d, const float* wav, const int* lens, int B, int L, int F, const float* window,
                       const float* melbasis, float* mel, float* mag, float* re, float* im, hipStream_t stream);
 
 void set_error(const char* fmt, ...);

@@ -14,8 +14,9 @@ __device__ __forceinline__ int reflect_index(int s, int L) {
     return s;
 }
 
-__global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ wav, int L, int F, int n_fft, int log2n,
-                                                  int hop, int pad, int n_mel, float mag_eps, float log_clip,
+__global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ wav, const int* __restrict__ lens, int L, int F,
+                                                  int n_fft, int log2n, int hop, int pad, int n_mel, float mag_eps,
+                                                  float log_clip,
                                                   const float* __restrict__ window, const float* __restrict__ melbasis,
                                                   float* __restrict__ mel, float* __restrict__ mag,
                                                   float* __restrict__ re_out, float* __restrict__ im_out) {
@@ -30,9 +31,13 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ wav,
     const int half = n_fft >> 1;
     const int bins = half + 1;
     const float* wb = wav + (size_t)b * L;
+    // ragged batch: item b holds lens[b] samples of the zero-padded row; its reflection padding mirrors at ITS
+    // end and it has (lens[b] + 2*pad - n_fft) / hop + 1 frames -- later frames of the row are left untouched
+    int Li = L;
+    if (lens) { Li = lens[b] < L ? lens[b] : L; if (f > (Li + 2 * pad - n_fft) / hop || Li <= pad) return; }
 
     for (int n = tid; n < n_fft; n += 256) {
-        const int s = reflect_index(f * hop + n - pad, L);
+        const int s = reflect_index(f * hop + n - pad, Li);
         buf0[n] = make_float2(wb[s] * window[n], 0.f);
     }
     for (int m = tid; m < half; m += 256) {
@@ -87,14 +92,14 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ wav,
     }
 }
 
-hipError_t launch_mel(const amp_mel_desc& d, const float* wav, int B, int L, int F, const float* window,
+hipError_t launch_mel(const amp_mel_desc& d, const float* wav, const int* lens, int B, int L, int F, const float* window,
                       const float* melbasis, float* mel, float* mag, float* re, float* im, hipStream_t stream) {
     int log2n = 0;
     while ((1 << log2n) < d.n_fft) ++log2n;
     const int pad = d.pad_mode == 0 ? (d.n_fft - d.hop_size) / 2 : d.n_fft / 2;
     const size_t lds = (size_t)(2 * d.n_fft + d.n_fft / 2) * sizeof(float2) + (size_t)(d.n_fft / 2 + 1) * sizeof(float);
     dim3 grid((unsigned)((size_t)B * F));
-    hipLaunchKernelGGL(mel_kernel, grid, dim3(256), lds, stream, wav, L, F, d.n_fft, log2n, d.hop_size, pad,
+    hipLaunchKernelGGL(mel_kernel, grid, dim3(256), lds, stream, wav, lens, L, F, d.n_fft, log2n, d.hop_size, pad,
                        mel ? d.n_mel : 0, d.mag_eps, d.log_clip, window, melbasis, mel, mag, re, im);
     return hipGetLastError();
 }
@@ -222,6 +227,12 @@ int amp_mel_num_frames(const amp_mel_desc* d, int L) {
 int amp_mel_forward(const amp_mel_desc* d, const float* wav_dev, int B, int L, const float* window_dev,
                     const float* melbasis_dev, float* mel_dev, float* mag_dev, float* re_dev, float* im_dev,
                     void* stream) {
+    return amp_mel_forward_ragged(d, wav_dev, nullptr, B, L, window_dev, melbasis_dev, mel_dev, mag_dev, re_dev, im_dev, stream);
+}
+
+int amp_mel_forward_ragged(const amp_mel_desc* d, const float* wav_dev, const int32_t* lens_dev, int B, int L,
+                           const float* window_dev, const float* melbasis_dev, float* mel_dev, float* mag_dev,
+                           float* re_dev, float* im_dev, void* stream) {
     if (!d || !wav_dev || !window_dev) { set_error("amp_mel_forward: null argument"); return AMP_ERR_INVALID; }
     if (d->n_fft < 64 || d->n_fft > 4096 || (d->n_fft & (d->n_fft - 1)) != 0) {
         set_error("amp_mel_forward: n_fft=%d must be a power of two in [64, 4096]", d->n_fft);
@@ -233,7 +244,7 @@ int amp_mel_forward(const amp_mel_desc* d, const float* wav_dev, int B, int L, c
     if (mel_dev && (d->n_mel <= 0 || !melbasis_dev)) { set_error("amp_mel_forward: mel output needs n_mel > 0 and a mel basis"); return AMP_ERR_INVALID; }
     const int F = amp_mel_num_frames(d, L);
     if (F <= 0) { set_error("amp_mel_forward: no frames for L=%d", L); return AMP_ERR_INVALID; }
-    hipError_t e = launch_mel(*d, wav_dev, B, L, F, window_dev, melbasis_dev, mel_dev, mag_dev, re_dev, im_dev, (hipStream_t)stream);
+    hipError_t e = launch_mel(*d, wav_dev, lens_dev, B, L, F, window_dev, melbasis_dev, mel_dev, mag_dev, re_dev, im_dev, (hipStream_t)stream);
     if (e != hipSuccess) { set_error("amp_mel_forward: %s", hipGetErrorString(e)); return AMP_ERR_HIP; }
     return AMP_OK;
 }

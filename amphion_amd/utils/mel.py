@@ -83,7 +83,7 @@ def _range_warning(y):
         print("max value is ", mx)
 
 
-def _run(y, cfg, *, n_mel, pad_mode, mag_eps, log_clip, want=("mel",), basis=None, window=None):
+def _run(y, cfg, *, n_mel, pad_mode, mag_eps, log_clip, want=("mel",), basis=None, window=None, lengths=None):
     y = _lib.require_device_tensor(y, "audio")
     if y.dim() == 1:
         y = y.unsqueeze(0)
@@ -102,11 +102,43 @@ def _run(y, cfg, *, n_mel, pad_mode, mag_eps, log_clip, want=("mel",), basis=Non
         if k in want:
             outs[k] = torch.empty((B, bins, F), device=dev)
     ptr = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+    lens = None
+    if lengths is not None:
+        lens = torch.as_tensor(lengths).to(device=dev, dtype=torch.int32).contiguous()
+        if lens.numel() != B:
+            raise ValueError(f"lengths must hold B={B} values")
+        for t in outs.values():
+            t.zero_()                      # frames beyond an utterance's own count are not written by the kernel
     with torch.cuda.device(dev):
-        _lib.check(L.amp_mel_forward(ctypes.byref(d), ptr(y), B, Lh, ptr(window), ptr(basis), ptr(outs.get("mel")),
-                                     ptr(outs.get("mag")), ptr(outs.get("re")), ptr(outs.get("im")),
-                                     _lib.current_stream_ptr(dev)))
+        _lib.check(L.amp_mel_forward_ragged(ctypes.byref(d), ptr(y), ptr(lens), B, Lh, ptr(window), ptr(basis),
+                                            ptr(outs.get("mel")), ptr(outs.get("mag")), ptr(outs.get("re")),
+                                            ptr(outs.get("im")), _lib.current_stream_ptr(dev)))
     return outs
+
+
+def num_frames(n_samples, cfg):
+    """Frames ``extract_mel_features`` yields for ``n_samples`` (reflect pad (n_fft-hop)/2, center=False)."""
+    pad = (cfg.n_fft - cfg.hop_size) // 2
+    return (n_samples + 2 * pad - cfg.n_fft) // cfg.hop_size + 1
+
+
+def extract_mel_features_batch(wavs, cfg, device=None):
+    """``extract_mel_features`` (utils/mel.py:111-170) over a LIST of waveforms of different lengths in ONE kernel
+    launch: the batch is zero-padded, every utterance is reflect-padded at its own end
+    (``amp_mel_forward_ragged``), and each returned ``[n_mel, F_i]`` equals the one-file-at-a-time result of the
+    reference's feature extraction (processors/acoustic_extractor.py:394-401)."""
+    if len(wavs) == 0:
+        return []
+    device = device or (wavs[0].device if isinstance(wavs[0], torch.Tensor) and wavs[0].is_cuda else "cuda")
+    lens = [int(w.shape[-1]) for w in wavs]
+    batch = torch.zeros((len(wavs), max(lens)), dtype=torch.float32)
+    for i, w in enumerate(wavs):
+        batch[i, : lens[i]] = torch.as_tensor(w, dtype=torch.float32).reshape(-1).cpu()
+    batch = batch.to(device)
+    basis, window = _basis_and_window(cfg, batch.device)
+    mel = _run(batch, cfg, n_mel=cfg.n_mel, pad_mode=0, mag_eps=1e-9, log_clip=1e-5, basis=basis, window=window,
+               lengths=lens)["mel"]
+    return [mel[i, :, : num_frames(lens[i], cfg)] for i in range(len(wavs))]
 
 
 def dynamic_range_compression_torch(x, C=1, clip_val=1e-5):

@@ -246,6 +246,14 @@ int amp_mel_forward(const amp_mel_desc* d, const float* wav_dev, int B, int L, c
                     const float* melbasis_dev, float* mel_dev, float* mag_dev, float* re_dev, float* im_dev,
                     void* stream);
 
+/* Ragged batch of the same: row b of wav_dev [B, L] holds lens_dev[b] <= L samples (int32, device), zero-padded.
+ * Every utterance is reflect-padded at ITS OWN end and fills frames [0, amp_mel_num_frames(d, lens[b])) of its
+ * output rows -- identical to running it alone (what the reference's one-file-at-a-time feature extraction,
+ * processors/acoustic_extractor.py:376-403, computes); later frames of a row are left unwritten. */
+int amp_mel_forward_ragged(const amp_mel_desc* d, const float* wav_dev, const int32_t* lens_dev, int B, int L,
+                           const float* window_dev, const float* melbasis_dev, float* mel_dev, float* mag_dev,
+                           float* re_dev, float* im_dev, void* stream);
+
 /* Replaces STFT.inverse (utils/stft.py:183-222; used by STFT.forward and griffin_lim :78-95): magnitude and
  * phase [B, n_fft/2+1, F] -> waveform [B, hop*(F-1)] (overlap-add of the windowed inverse FFTs, divided by the
  * window-sum-square envelope where it exceeds float32 tiny, times n_fft/hop, n_fft/2 cropped per side).

@@ -132,3 +132,36 @@ def test_stft_forward_round_trip_and_griffin_lim():
     assert (m2 - mag).abs().mean().item() < 0.5 * mag.abs().mean().item()
     with pytest.raises(RuntimeError):
         st.inverse(mag.cpu(), mag.cpu())
+
+
+# ---- feature extraction pipeline (processors/acoustic_extractor.py:376-449, utils/io.py:12-30) ---------------
+def test_ragged_mel_batch_equals_per_utterance(tmp_path):
+    """One ragged kernel launch == the reference's one-file-at-a-time extraction, bit for bit; .npy layout."""
+    from types import SimpleNamespace as NS
+
+    from amphion_amd.processors.acoustic_extractor import extract_mel_features_dataset, extract_utt_acoustic_features_vocoder
+    from amphion_amd.utils.mel import extract_mel_features, extract_mel_features_batch
+
+    pp = vo.preprocess_22k()
+    g = torch.Generator().manual_seed(3)
+    lens = [22016, 5000, 700, 12345]
+    wavs = [(torch.rand(L, generator=g) * 2 - 1) * 0.8 for L in lens]
+    mels = extract_mel_features_batch(wavs, pp)
+    for w, m in zip(wavs, mels):
+        solo = extract_mel_features(w.cuda().unsqueeze(0), pp)
+        assert m.shape == solo.shape and torch.equal(m, solo)
+        ref = vo.extract_mel_features(w.unsqueeze(0), pp)
+        assert (m.cpu() - ref).abs().max().item() <= 1e-3
+
+    pp2 = NS(**vars(pp), extract_mel=True, extract_audio=True, extract_energy=True, energy_extract_mode="from_mel",
+             extract_amplitude_phase=False, mel_dir="mels", audio_dir="audios", energy_dir="energys")
+    cfg = NS(preprocess=pp2)
+    utts = [{"Uid": f"u{i}", "Path": ""} for i in range(len(wavs))]
+    extract_mel_features_dataset(str(tmp_path / "a"), cfg, utts, wavs=wavs, batch_size=3)
+    for u, w in zip(utts, wavs):
+        extract_utt_acoustic_features_vocoder(str(tmp_path / "b"), cfg, u, wav_torch=w)
+        ma = np.load(tmp_path / "a" / "mels" / (u["Uid"] + ".npy"))
+        mb = np.load(tmp_path / "b" / "mels" / (u["Uid"] + ".npy"))
+        assert ma.dtype == np.float32 and ma.ndim == 2 and ma.shape[0] == 80 and np.array_equal(ma, mb)
+        assert np.array_equal(np.load(tmp_path / "a" / "audios" / (u["Uid"] + ".npy")), w.numpy())
+        assert np.load(tmp_path / "b" / "energys" / (u["Uid"] + ".npy")).shape == (ma.shape[1],)

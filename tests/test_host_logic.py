@@ -164,3 +164,28 @@ def test_registry_surface():
 
     assert list(inspect.signature(gi.vocoder_inference).parameters)[:6] == ["cfg", "model", "mels", "f0s", "device", "fast_inference"]
     assert list(inspect.signature(vi.synthesis).parameters) == ["cfg", "vocoder_weight_file", "n_samples", "pred", "f0s", "batch_size", "fast_inference"]
+
+
+def test_load_audio_torch_and_save_feature(tmp_path):
+    """processors drop-in, host side only: PCM16 wav -> float32 [-1, 1] at the config rate; .npy layout of utils/io.py."""
+    import wave
+
+    import numpy as np
+
+    from amphion_amd.processors.acoustic_extractor import load_audio_torch, save_feature
+
+    sr = 24000
+    t = np.arange(sr // 2) / sr
+    pcm = (0.5 * np.sin(2 * np.pi * 440 * t) * 32767).astype(np.int16)
+    p = tmp_path / "a.wav"
+    with wave.open(str(p), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(sr); w.writeframes(pcm.tobytes())
+    x, fs = load_audio_torch(str(p), 24000)
+    assert fs == 24000 and x.dtype.is_floating_point and x.shape[0] == pcm.shape[0]
+    assert abs(float(x.abs().max()) - 0.5) < 1e-3
+    y, fs2 = load_audio_torch(str(p), 22050)
+    assert fs2 == 22050 and abs(y.shape[0] - round(pcm.shape[0] * 22050 / 24000)) <= 1
+    save_feature(str(tmp_path / "out"), "mels", "uid0", np.zeros((80, 7), np.float32))
+    assert np.load(tmp_path / "out" / "mels" / "uid0.npy").shape == (80, 7)
+    save_feature(str(tmp_path / "out"), "mels", "uid0", np.ones((80, 7), np.float32), overrides=False)
+    assert np.load(tmp_path / "out" / "mels" / "uid0.npy").sum() == 0

@@ -77,6 +77,12 @@ def main():
         n = sum(lens) * 256
         out.append({"config": "synthesis_audios: 64 ragged utterances (60..400 frames), HiFi-GAN V1, host list API incl. D2H", "ms_total": (t1 - t0) * 1e3,
                     "samples_per_s": n / (t1 - t0), "x_realtime": n / (t1 - t0) / 22050})
+        # ---- single-utterance latency (the reference recipe's inference.batch_size = 1)
+        for T in (256, 860):
+            mel1 = synthetic_mel(1, 80, T, seed=5).to(dev)
+            ms = timed(lambda: m(mel1), 20)
+            out.append({"config": f"latency: HiFi-GAN V1, ONE utterance of {T} frames ({T * 256 / 22050:.1f} s of audio)", "ms": ms,
+                        "x_realtime": T * 256 / 22050 / (ms * 1e-3)})
     for o in out:
         print(json.dumps(o))
 
