@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """Throughput of the other BASELINE.json configs on one MI355X (reported in DESIGN.md; bench.py stays the
-configs[1] headline):  C3 BigVGAN-base 24 kHz B=32,  C5 VITS enc_q -> flow -> flow^-1 -> dec B=16,  the
-mel front end at B=64 x 65 536 samples,  and the list API (`synthesis_audios`) on ragged utterances.
+configs[1] headline):  c3 BigVGAN-base 24 kHz B=32,  c5 VITS enc_q -> flow -> flow^-1 -> dec B=16,  mel = the
+front end at B=64 x 65 536 samples,  list = the list API on ragged utterances,  lat = single-utterance latency.
 
-    python tools/bench_configs.py [--reps 5]
+    python tools/bench_configs.py [--reps 5] [--only c3|c5|mel|list|lat]
 Product path only (amphion_amd modules + seeded random-init weights); one JSON line per config."""
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,6 +14,7 @@ from amphion_amd.utils.synthetic import randomize_, synthetic_mel
 
 V1 = dict(resblock="1", upsample_rates=[8, 8, 2, 2], upsample_kernel_sizes=[16, 16, 4, 4], upsample_initial_channel=512,
           resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5]] * 3)
+DEV = "cuda:0"
 
 
 def timed(fn, reps):
@@ -26,65 +27,83 @@ def timed(fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
-def main():
-    ap = argparse.ArgumentParser(); ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--only", default="", help="c3 | c5 | mel | list (default: all)"); a = ap.parse_args()
-    dev = "cuda:0"
+def hifigan():
+    from amphion_amd.models.vocoders.gan.generator.hifigan import HiFiGAN
+    cfg = NS(preprocess=NS(n_mel=80, hop_size=256, sample_rate=22050, extract_amplitude_phase=False),
+             model=NS(hifigan=NS(**V1), generator="hifigan"))
+    return cfg, randomize_(HiFiGAN(cfg), 1234).to(DEV).eval()
+
+
+def c3(reps):
+    from amphion_amd.models.vocoders.gan.generator.bigvgan import BigVGAN
+    hp = dict(V1, activation="snakebeta", snake_logscale=True)
+    m = randomize_(BigVGAN(NS(preprocess=NS(n_mel=100, hop_size=256), model=NS(bigvgan=NS(**hp)))), 1234, g_gain=0.75).to(DEV).eval()
+    mel = torch.randn(32, 100, 256, generator=torch.Generator().manual_seed(0)).to(DEV)
+    ms = timed(lambda: m(mel), reps)
+    n = 32 * 256 * 256
+    return [{"config": "C3 BigVGAN-base 24 kHz, B=32 x 100 mel x 256 frames", "ms_per_step": ms, "samples_per_s": n / ms * 1e3, "x_realtime": n / ms * 1e3 / 24000}]
+
+
+def c5(reps):
+    from amphion_amd.models.tts.vits.vits import SynthesizerTrnDecodePath
+    net = SynthesizerTrnDecodePath(513, 192, 192, "1", V1["resblock_kernel_sizes"], V1["resblock_dilation_sizes"],
+                                   V1["upsample_rates"], V1["upsample_initial_channel"], V1["upsample_kernel_sizes"])
+    net = randomize_(net, 4321, g_gain=0.5).to(DEV).eval()
+    g = torch.Generator().manual_seed(7)
+    y = torch.rand(16, 513, 256, generator=g).to(DEV); lens = torch.full((16,), 256); noise = torch.randn(16, 192, 256, generator=g).to(DEV)
+    ms = timed(lambda: net.reconstruct(y, lens, noise=noise), reps)
+    n = 16 * 256 * 256
+    return [{"config": "C5 VITS enc_q -> flow -> flow(reverse) -> HiFi-GAN decoder, B=16, T=256", "ms_per_step": ms, "samples_per_s": n / ms * 1e3, "x_realtime": n / ms * 1e3 / 22050}]
+
+
+def mel(reps):
+    from amphion_amd.utils.mel import mel_spectrogram_torch
+    pp = NS(sample_rate=22050, n_fft=1024, win_size=1024, hop_size=256, n_mel=80, fmin=0, fmax=8000)
+    wav = (torch.rand(64, 65536, generator=torch.Generator().manual_seed(1)) * 2 - 1).to(DEV)
+    ms = timed(lambda: mel_spectrogram_torch(wav, pp), reps)
+    byts = 64 * 65536 * 4 + 64 * 80 * 256 * 4
+    return [{"config": "mel front end (reflect pad + STFT 1024/256 + mel 80 + log), B=64 x 65536 samples", "ms_per_step": ms,
+             "samples_per_s": 64 * 65536 / ms * 1e3, "algorithmic_GBps": byts / ms / 1e6}]
+
+
+def lst(reps):
+    from amphion_amd.models.vocoders.gan.gan_vocoder_inference import synthesis_audios
+    cfg, m = hifigan()
+    lens = torch.randint(60, 400, (64,), generator=torch.Generator().manual_seed(3)).tolist()
+    mels = [synthetic_mel(1, 80, L, seed=i)[0] for i, L in enumerate(lens)]
     out = []
-    with torch.no_grad():
-        # ---- C3: BigVGAN-base 24 kHz, B=32, 100 mel x 256 frames
-        if a.only not in ("", "c3"):
-            raise SystemExit("--only supports c3 (or nothing)")
-        from amphion_amd.models.vocoders.gan.generator.bigvgan import BigVGAN
-        hp = dict(V1, activation="snakebeta", snake_logscale=True)
-        m = randomize_(BigVGAN(NS(preprocess=NS(n_mel=100, hop_size=256), model=NS(bigvgan=NS(**hp)))), 1234, g_gain=0.75).to(dev).eval()
-        mel = torch.randn(32, 100, 256, generator=torch.Generator().manual_seed(0)).to(dev)
-        ms = timed(lambda: m(mel), a.reps)
-        n = 32 * 256 * 256
-        out.append({"config": "C3 BigVGAN-base 24 kHz, B=32 x 100 mel x 256 frames", "ms_per_step": ms, "samples_per_s": n / ms * 1e3, "x_realtime": n / ms * 1e3 / 24000})
-        del m, mel; torch.cuda.empty_cache()
-        if a.only == "c3":
-            print(json.dumps(out[0])); return
-        # ---- C5: VITS posterior encoder + flow + reverse flow + HiFi-GAN decoder, B=16, T=256
-        from amphion_amd.models.tts.vits.vits import SynthesizerTrnDecodePath
-        net = SynthesizerTrnDecodePath(513, 192, 192, "1", V1["resblock_kernel_sizes"], V1["resblock_dilation_sizes"],
-                                       V1["upsample_rates"], V1["upsample_initial_channel"], V1["upsample_kernel_sizes"])
-        net = randomize_(net, 4321, g_gain=0.5).to(dev).eval()
-        g = torch.Generator().manual_seed(7)
-        y = torch.rand(16, 513, 256, generator=g).to(dev); lens = torch.full((16,), 256); noise = torch.randn(16, 192, 256, generator=g).to(dev)
-        ms = timed(lambda: net.reconstruct(y, lens, noise=noise), a.reps)
-        n = 16 * 256 * 256
-        out.append({"config": "C5 VITS enc_q -> flow -> flow(reverse) -> HiFi-GAN decoder, B=16, T=256", "ms_per_step": ms, "samples_per_s": n / ms * 1e3, "x_realtime": n / ms * 1e3 / 22050})
-        del net; torch.cuda.empty_cache()
-        # ---- mel front end: B=64 x 65 536 samples -> [64, 80, 256]
-        from amphion_amd.utils.mel import mel_spectrogram_torch
-        pp = NS(sample_rate=22050, n_fft=1024, win_size=1024, hop_size=256, n_mel=80, fmin=0, fmax=8000)
-        wav = (torch.rand(64, 65536, generator=torch.Generator().manual_seed(1)) * 2 - 1).to(dev)
-        ms = timed(lambda: mel_spectrogram_torch(wav, pp), a.reps)
-        byts = 64 * 65536 * 4 + 64 * 80 * 256 * 4
-        out.append({"config": "mel front end (reflect pad + STFT 1024/256 + mel 80 + log), B=64 x 65536 samples", "ms_per_step": ms,
-                    "samples_per_s": 64 * 65536 / ms * 1e3, "algorithmic_GBps": byts / ms / 1e6})
-        # ---- list API: 64 ragged utterances through synthesis_audios (HiFi-GAN V1)
-        from amphion_amd.models.vocoders.gan.generator.hifigan import HiFiGAN
-        from amphion_amd.models.vocoders.gan.gan_vocoder_inference import synthesis_audios
-        cfg = NS(preprocess=NS(n_mel=80, hop_size=256, sample_rate=22050), model=NS(hifigan=NS(**V1), generator="hifigan"))
-        m = randomize_(HiFiGAN(cfg), 1234).to(dev).eval()
-        gl = torch.Generator().manual_seed(3)
-        lens = torch.randint(60, 400, (64,), generator=gl).tolist()
-        mels = [synthetic_mel(1, 80, L, seed=i)[0] for i, L in enumerate(lens)]
-        t0 = time.perf_counter(); auds = synthesis_audios(cfg, m, mels, batch_size=64, ragged=True); torch.cuda.synchronize(); t1 = time.perf_counter()
-        t0 = time.perf_counter(); auds = synthesis_audios(cfg, m, mels, batch_size=64, ragged=True); torch.cuda.synchronize(); t1 = time.perf_counter()
+    for ragged in (True, False):
+        synthesis_audios(cfg, m, mels, batch_size=64, ragged=ragged); torch.cuda.synchronize()
+        t0 = time.perf_counter(); synthesis_audios(cfg, m, mels, batch_size=64, ragged=ragged); torch.cuda.synchronize(); t1 = time.perf_counter()
         n = sum(lens) * 256
-        out.append({"config": "synthesis_audios: 64 ragged utterances (60..400 frames), HiFi-GAN V1, host list API incl. D2H", "ms_total": (t1 - t0) * 1e3,
-                    "samples_per_s": n / (t1 - t0), "x_realtime": n / (t1 - t0) / 22050})
-        # ---- single-utterance latency (the reference recipe's inference.batch_size = 1)
-        for T in (256, 860):
-            mel1 = synthetic_mel(1, 80, T, seed=5).to(dev)
-            ms = timed(lambda: m(mel1), 20)
-            out.append({"config": f"latency: HiFi-GAN V1, ONE utterance of {T} frames ({T * 256 / 22050:.1f} s of audio)", "ms": ms,
-                        "x_realtime": T * 256 / 22050 / (ms * 1e-3)})
-    for o in out:
-        print(json.dumps(o))
+        out.append({"config": f"synthesis_audios(ragged={ragged}): 64 utterances of 60..400 frames, HiFi-GAN V1, host list API incl. H2D/D2H",
+                    "ms_total": (t1 - t0) * 1e3, "samples_per_s": n / (t1 - t0), "x_realtime": n / (t1 - t0) / 22050})
+    return out
+
+
+def lat(reps):
+    cfg, m = hifigan()
+    out = []
+    for T in (256, 860):
+        mel1 = synthetic_mel(1, 80, T, seed=5).to(DEV)
+        ms = timed(lambda: m(mel1), 20)
+        out.append({"config": f"latency: HiFi-GAN V1, ONE utterance of {T} frames ({T * 256 / 22050:.1f} s of audio)", "ms": ms,
+                    "x_realtime": T * 256 / 22050 / (ms * 1e-3)})
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--only", default="", choices=["", "c3", "c5", "mel", "list", "lat"])
+    a = ap.parse_args()
+    runs = {"c3": c3, "c5": c5, "mel": mel, "list": lst, "lat": lat}
+    with torch.no_grad():
+        for name, fn in runs.items():
+            if a.only in ("", name):
+                for o in fn(a.reps):
+                    print(json.dumps(o), flush=True)
+                torch.cuda.empty_cache()
 
 
 if __name__ == "__main__":
