@@ -112,32 +112,42 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     if (a.lens) { const int l = a.lens[item] * a.len_mul; Tv = l < Tv ? l : Tv; }
     const float slope_in = a.slope_in;
 
+    // stage_load issues UNCONDITIONAL loads from clamped addresses (a predicated load makes hipcc branch
+    // around it and lose its vmcnt bookkeeping: the loads of chunk c+1 were then drained before the MFMAs of
+    // chunk c instead of flying under them); the zero padding is applied as a select in stage_store.
     float xs[NST];
+    auto stage_index = [&](int it, int chunk, int& ch, int& tr, bool& ok) {
+        const int idx = tid + 256 * it;
+        const int row = idx / S;
+        const int col = idx - row * S;
+        ch = chunk * KC + row;
+        tr = tbase + col;
+        if (a.pad_reflect) {
+            tr = tr < 0 ? -tr : tr;
+            tr = tr > Tv - 1 ? 2 * (Tv - 1) - tr : tr;
+        }
+        ok = (idx < KC * S) && (col < a.wd) && (ch < a.Cin) && (tr >= 0) && (tr < Tv);
+    };
     auto stage_load = [&](int chunk) {
 #pragma unroll
         for (int it = 0; it < NST; ++it) {
-            const int idx = tid + 256 * it;
-            const int row = idx / S;
-            const int col = idx - row * S;
-            const int ch = chunk * KC + row;
-            const int t = tbase + col;
-            int tr = t;
-            if (a.pad_reflect) {
-                tr = tr < 0 ? -tr : tr;
-                tr = tr > Tv - 1 ? 2 * (Tv - 1) - tr : tr;
-            }
-            const bool ok = (idx < KC * S) && (col < a.wd) && (ch < a.Cin) && (tr >= 0) && (tr < Tv);
-            float v = 0.f;
-            if (ok) v = xb[(size_t)ch * a.Tin + tr];
-            xs[it] = v;
+            int ch, tr;
+            bool ok;
+            stage_index(it, chunk, ch, tr, ok);
+            ch = ch > a.Cin - 1 ? a.Cin - 1 : ch;
+            tr = tr < 0 ? 0 : (tr > a.Tin - 1 ? a.Tin - 1 : tr);
+            xs[it] = xb[(size_t)ch * a.Tin + tr];
         }
     };
-    auto stage_store = [&](int buf) {
+    auto stage_store = [&](int chunk, int buf) {
         float* dst = smem + buf * (KC * S);
 #pragma unroll
         for (int it = 0; it < NST; ++it) {
             const int idx = tid + 256 * it;
-            float v = xs[it];
+            int ch, tr;
+            bool ok;
+            stage_index(it, chunk, ch, tr, ok);
+            float v = ok ? xs[it] : 0.f;
             v = v > 0.f ? v : v * slope_in;
             if (idx < KC * S) dst[idx] = v;
         }
@@ -154,20 +164,20 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     stage_load(0);
 #pragma unroll
     for (int g = 0; g < KT; ++g) a_cur[g] = wa[(size_t)g * 64];
-    stage_store(0);
+    stage_store(0, 0);
     __syncthreads();
 
     const int nchunks = a.nchunks;
     for (int c = 0; c < nchunks; ++c) {
         const bool more = (c + 1) < nchunks;
-        if (more) stage_load(c + 1);
+        stage_load(more ? c + 1 : c);   // unconditional (a branch around loads would blur the vmcnt counts)
         const float4* wan = wa + (size_t)(c + 1) * (KT * 64);
         const float* base = smem + (c & 1) * (KC * S) + rd0;
 #pragma unroll
         for (int g = 0; g < KT; ++g) {
             const float* bg = base + g * dstep;
             const float av[4] = {a_cur[g].x, a_cur[g].y, a_cur[g].z, a_cur[g].w};
-            if (more) a_cur[g] = wan[(size_t)g * 64];
+            a_cur[g] = wan[(size_t)g * 64];   // past the last chunk: next mb block / allocation pad
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
 #pragma unroll
@@ -177,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
                 }
             }
         }
-        if (more) stage_store((c + 1) & 1);
+        if (more) stage_store(c + 1, (c + 1) & 1);
         __syncthreads();
     }
 

@@ -219,7 +219,7 @@ static int conv_build(amp_conv* c, const float* w, const float* bias) {
     if (c->precision == PREC_F32) {
         // ---- f32 MFMA A-fragment order: [mb][chunk8][tap][lane][p] ----
         c->nchunks = (c->cin + KC - 1) / KC;
-        const size_t n = (size_t)nmb * c->nchunks * c->KT * 64 * 4;
+        const size_t n = ((size_t)nmb * c->nchunks + 1) * c->KT * 64 * 4;   // +1 chunk: the kernel's A reload runs one chunk ahead
         std::vector<float> wp(n, 0.f);
         for (int mb = 0; mb < nmb; ++mb)
             for (int ch = 0; ch < c->nchunks; ++ch)
