@@ -26,11 +26,14 @@ def shard_batch(mels: torch.Tensor, world_size: int = None, rank: int = None) ->
     return mels[s:e]
 
 
-def gather_audio(local: torch.Tensor, total_items: int, dst: int = 0, group=None):
+def gather_audio(local: torch.Tensor, total_items: int, dst: int = 0, group=None, async_op: bool = False):
     """Gather per-rank [b_r, L] audio on ``dst`` in rank order -> [total_items, L] (None elsewhere).
 
     Shards may be ragged by one item: every rank pads to the largest shard so the collective is a
     fixed-size gather (each peer sends over its own xGMI link to the root; no ring, no reduction).
+
+    ``async_op=True`` (equal shards only) returns ``(result, work)`` without making the compute stream wait:
+    the transfer then overlaps the vocoding of the NEXT batch; call ``work.wait()`` before reading ``result``.
     """
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -47,13 +50,15 @@ def gather_audio(local: torch.Tensor, total_items: int, dst: int = 0, group=None
         if min(counts) == mx:
             # equal shards: receive straight into the row blocks of the result (no staging copies)
             out = torch.empty((total_items,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-            dist.gather(send, list(out.split(mx, dim=0)), dst=dst, group=group)
-            return out
+            work = dist.gather(send, list(out.split(mx, dim=0)), dst=dst, group=group, async_op=async_op)
+            return (out, work) if async_op else out
+        if async_op:
+            raise ValueError("async gather needs equal shards")
         bufs = [torch.empty_like(send) for _ in range(world)]
         dist.gather(send, bufs, dst=dst, group=group)
         return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
-    dist.gather(send, None, dst=dst, group=group)
-    return None
+    work = dist.gather(send, None, dst=dst, group=group, async_op=async_op)
+    return (None, work) if async_op else None
 
 
 def sharded_vocoder_forward(model, mels: torch.Tensor, gather: bool = True, dst: int = 0):

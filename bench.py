@@ -132,14 +132,23 @@ def main():
     L = T_FRAMES * model.hop_factor
     total_items = B_PER_GPU * world
 
+    pending = []   # N > 1: (gathered audio, work) of the steps in flight
+
     def step():
+        """One batch per rank through the generator; for N > 1 the audio is then gathered on rank 0 WITHOUT
+        stalling the compute stream (the transfer overlaps the next batch, as in a serving loop); every gather
+        is waited for inside the timed region (fence())."""
         with torch.no_grad():
             wav = model(mel)
             if world > 1:
-                return gather_audio(wav.squeeze(1), total_items, dst=0)
+                pending.append(gather_audio(wav.squeeze(1), total_items, dst=0, async_op=True) + (wav,))
+                return pending[-1][0]
             return wav
 
     def fence():
+        for _, work, _ in pending:
+            work.wait()
+        pending.clear()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

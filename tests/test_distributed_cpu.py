@@ -63,6 +63,17 @@ def _worker(rank, world, port, n_items, q):
         g = gather_audio(torch.full((e - s, 2), float(rank)), n_items)
         if rank == 0:
             q.put(g[:, 0].tolist())
+        # asynchronous gather of equal shards (what bench.py does for N > 1): several in flight, waited later
+        if n_items % world == 0:
+            per = n_items // world
+            inflight = [gather_audio(torch.full((per, 3), float(10 * k + rank)), n_items, async_op=True) for k in range(3)]
+            for k, (res, work) in enumerate(inflight):
+                work.wait()
+                if rank == 0:
+                    want = torch.cat([torch.full((per, 3), float(10 * k + r)) for r in range(world)])
+                    assert torch.equal(res, want)
+                else:
+                    assert res is None
     finally:
         dist.destroy_process_group()
 
