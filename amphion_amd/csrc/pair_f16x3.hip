@@ -73,6 +73,30 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairArgs a) {
     const int tbase = q0 - H2 - h1;           // global column of staged column 0
     const float kpos = 16.f, kneg = 16.f * a.slope;
 
+    // Residual x at this lane's OUTPUT positions.  For C <= 64 (HBM-bound pairs) it is fetched here, next to the
+    // staging loads of the same cache lines, and carried in registers: fetched again after phase 2 those lines
+    // have left L2 and the residual costs a second HBM read of the tensor.  (C = 128 has no registers to spare
+    // and is MFMA-bound; it re-reads in the epilogue.)
+    constexpr bool RES_EARLY = WM < 4;
+    const int colw0 = wn * (32 * NI) + l31;
+    int qc[NI];
+    bool okc[NI];
+#pragma unroll
+    for (int t = 0; t < NI; ++t) {
+        const int col = colw0 + 32 * t;
+        const int q = q0 + col;
+        okc[t] = (col < NT) && (q < T);
+        qc[t] = q < T ? q : T - 1;
+    }
+    const float* xres = a.x + (size_t)item * C * T + (size_t)(32 * wm + 4 * hi) * T;
+    f32x16 rv[NI];
+    if (RES_EARLY) {
+#pragma unroll
+        for (int t = 0; t < NI; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[t][r] = xres[(size_t)((r & 3) + 8 * (r >> 2)) * T + qc[t]];
+    }
+
     // ---------------- phase 1: conv1 ----------------
     f32x16 acc[NI];
     {
@@ -247,22 +271,13 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairArgs a) {
     {
         const float i2 = a.isc2;
         const int mode = a.mode;
-        const float* xr = a.x + (size_t)item * C * T + (size_t)(32 * wm + 4 * hi) * T;
         float* yr = a.y + (size_t)item * C * T + (size_t)(32 * wm + 4 * hi) * T;
-        int qc[NI];
-        bool ok[NI];
+        if (!RES_EARLY) {
 #pragma unroll
-        for (int t = 0; t < NI; ++t) {
-            const int col = colw + 32 * t;
-            const int q = q0 + col;
-            ok[t] = (col < NT) && (q < T);
-            qc[t] = q < T ? q : T - 1;
+            for (int t = 0; t < NI; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[t][r] = xres[(size_t)((r & 3) + 8 * (r >> 2)) * T + qc[t]];
         }
-        f32x16 rv[NI];
-#pragma unroll
-        for (int t = 0; t < NI; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) rv[t][r] = xr[(size_t)((r & 3) + 8 * (r >> 2)) * T + qc[t]];
 #pragma unroll
         for (int t = 0; t < NI; ++t) acc[t] = acc[t] * i2 + rv[t];
         if (mode != 0) {   // wave-uniform
@@ -281,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairArgs a) {
         }
 #pragma unroll
         for (int t = 0; t < NI; ++t)
-            if (ok[t]) {
+            if (okc[t]) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) yr[(size_t)((r & 3) + 8 * (r >> 2)) * T + qc[t]] = acc[t][r];
             }
