@@ -235,6 +235,42 @@ class HipGenerator(nn.Module):
         (gan_vocoder_inference.py:74-96) by true batches without changing results."""
         return self._amp_forward(x, g, lengths=lengths)
 
+    # ---- hipGraph capture (launch-bound small batches) ----
+    def capture(self, B, T, g_shape=None):
+        """Capture one forward at a fixed shape into a hipGraph and return ``(replay, static_in, static_out)``.
+
+        A forward is 51 (HiFi-GAN V1) dependent kernel launches; for a single utterance each of them runs a few
+        tens of microseconds, so host launch cost and inter-launch gaps are a visible share of the latency.
+        ``replay()`` re-runs the captured launches with one ``hipGraphLaunch``: copy the new mel into
+        ``static_in`` (same shape), call ``replay()``, read ``static_out``.  The kernels launch on the caller's
+        stream and neither allocate nor synchronise, so plain stream capture works; one eager warm-up forward
+        runs first (it builds the handle and sets the >64 KiB dynamic-LDS attributes outside the capture).
+        """
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("capture() needs the generator on a ROCm device")
+        static_in = torch.zeros((B, self._amp_n_in, T), dtype=torch.float32, device=dev)
+        static_g = torch.zeros(g_shape, dtype=torch.float32, device=dev) if g_shape is not None else None
+        was_profiling = self._amp_profiling
+        self.set_profiling(False)                       # event records are not part of the product graph
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():
+            self._amp_forward(static_in, static_g)      # warm-up: handle, workspace, function attributes
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph), torch.no_grad():
+            static_out = self._amp_forward(static_in, static_g)
+        self.set_profiling(was_profiling)
+
+        def replay():
+            graph.replay()
+            return static_out
+
+        replay.graph = graph
+        replay.static_g = static_g
+        return replay, static_in, static_out
+
     # ---- profiling hooks used by bench.py ----
     def set_profiling(self, enabled=True):
         self._amp_profiling = bool(enabled)

@@ -92,3 +92,22 @@ def test_forward_ragged_is_bit_identical_to_per_utterance_forward(arch):
             assert torch.equal(out[i, 0, : T * 256], solo[0, 0]), (arch, i, T)
     with pytest.raises(ValueError):
         m.forward_ragged(batch.cuda(), [23, 7, 0, 16, 24])
+
+
+def test_hipgraph_capture_replays_bit_identically():
+    """generator.capture(): one hipGraphLaunch instead of 51 kernel launches, same bits as the eager forward."""
+    from amphion_amd.models.vocoders.gan.generator.hifigan import HiFiGAN
+
+    hp = vo.hifigan_v1_hp()
+    m = HiFiGAN(NS(preprocess=NS(n_mel=80, hop_size=256), model=NS(hifigan=NS(**hp))))
+    m.load_state_dict(synth.synth_state_dict(synth.hifigan_param_shapes(80, hp), 1234))
+    m = m.cuda().eval()
+    replay, static_in, static_out = m.capture(1, 40)
+    for seed in (1, 2):
+        mel = synth.synth_mel(1, 80, 40, seed=seed).cuda()
+        with torch.no_grad():
+            eager = m(mel).clone()
+        static_in.copy_(mel)
+        out = replay()
+        torch.cuda.synchronize()
+        assert out is static_out and torch.equal(out, eager)

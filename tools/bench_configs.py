@@ -89,6 +89,11 @@ def lat(reps):
         ms = timed(lambda: m(mel1), 20)
         out.append({"config": f"latency: HiFi-GAN V1, ONE utterance of {T} frames ({T * 256 / 22050:.1f} s of audio)", "ms": ms,
                     "x_realtime": T * 256 / 22050 / (ms * 1e-3)})
+        replay, static_in, _ = m.capture(1, T)
+        static_in.copy_(mel1)
+        ms = timed(replay, 20)
+        out.append({"config": f"latency, hipGraph replay: ONE utterance of {T} frames", "ms": ms,
+                    "x_realtime": T * 256 / 22050 / (ms * 1e-3)})
     return out
 
 
