@@ -375,19 +375,25 @@ struct amp_gen {
     float* post_b_dev = nullptr;
     int post_cin = 0;
     std::vector<float*> dev_allocs;
-    // profiling
-    bool profiling = false;
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-    std::vector<hipEvent_t> ev_mrf;  // begin/end per (batch group, stage)
-    std::vector<hipEvent_t> ev_rb;   // per (batch group, stage): n_kernels + 1 marks around the resblocks
-    int ev_groups = 0;
-    bool timing_valid = false;
+    // profiling: a ring of event sets, one per forward, so that a caller can time EVERY forward of a region
+    // without synchronising in between (bench.py reads them after its closing fence)
+    struct ProfSlot {
+        hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+        std::vector<hipEvent_t> ev_mrf;  // begin/end per (batch group, stage)
+        std::vector<hipEvent_t> ev_rb;   // per (batch group, stage): n_kernels + 1 marks around the resblocks
+        int ev_groups = 0;
+        bool valid = false;
+    };
+    std::vector<ProfSlot> prof;          // empty = profiling off
+    size_t prof_count = 0;               // forwards recorded so far
     ~amp_gen() {
         for (float* p : dev_allocs) (void)hipFree(p);
-        if (ev_begin) (void)hipEventDestroy(ev_begin);
-        if (ev_end) (void)hipEventDestroy(ev_end);
-        for (auto e : ev_mrf) (void)hipEventDestroy(e);
-        for (auto e : ev_rb) (void)hipEventDestroy(e);
+        for (auto& p : prof) {
+            if (p.ev_begin) (void)hipEventDestroy(p.ev_begin);
+            if (p.ev_end) (void)hipEventDestroy(p.ev_end);
+            for (auto e : p.ev_mrf) (void)hipEventDestroy(e);
+            for (auto e : p.ev_rb) (void)hipEventDestroy(e);
+        }
     }
 };
 
@@ -706,32 +712,44 @@ int amp_set_group_mb(int megabytes) {
     return AMP_OK;
 }
 
-int amp_gen_set_profiling(amp_gen* g, int enabled) {
-    if (!g) { set_error("amp_gen_set_profiling: null handle"); return AMP_ERR_INVALID; }
-    g->profiling = enabled != 0;
-    if (g->profiling && !g->ev_begin) {
-        AMP_HIP(hipEventCreate(&g->ev_begin));
-        AMP_HIP(hipEventCreate(&g->ev_end));
+int amp_gen_set_profiling(amp_gen* g, int slots) {
+    if (!g || slots < 0 || slots > 4096) { set_error("amp_gen_set_profiling: bad argument"); return AMP_ERR_INVALID; }
+    for (auto& p : g->prof) {
+        if (p.ev_begin) (void)hipEventDestroy(p.ev_begin);
+        if (p.ev_end) (void)hipEventDestroy(p.ev_end);
+        for (auto e : p.ev_mrf) (void)hipEventDestroy(e);
+        for (auto e : p.ev_rb) (void)hipEventDestroy(e);
     }
-    g->timing_valid = false;
+    g->prof.clear();
+    g->prof.resize((size_t)slots);
+    g->prof_count = 0;
+    for (auto& p : g->prof) {
+        AMP_HIP(hipEventCreate(&p.ev_begin));
+        AMP_HIP(hipEventCreate(&p.ev_end));
+    }
     return AMP_OK;
 }
 
-int amp_gen_last_timing_ms(amp_gen* g, int which, float* ms_out) {
-    if (!g || !ms_out) { set_error("amp_gen_last_timing_ms: null argument"); return AMP_ERR_INVALID; }
-    if (!g->profiling || !g->timing_valid) { set_error("amp_gen_last_timing_ms: no profiled forward recorded"); return AMP_ERR_STATE; }
-    AMP_HIP(hipEventSynchronize(g->ev_end));
+int amp_gen_timing_ms(amp_gen* g, int back, int which, float* ms_out) {
+    if (!g || !ms_out) { set_error("amp_gen_timing_ms: null argument"); return AMP_ERR_INVALID; }
+    if (g->prof.empty() || back < 0 || (size_t)back >= g->prof.size() || (size_t)back >= g->prof_count) {
+        set_error("amp_gen_timing_ms: no profiled forward %d back (slots=%zu, recorded=%zu)", back, g->prof.size(), g->prof_count);
+        return AMP_ERR_STATE;
+    }
+    const amp_gen::ProfSlot& p = g->prof[(g->prof_count - 1 - (size_t)back) % g->prof.size()];
+    if (!p.valid) { set_error("amp_gen_timing_ms: slot not recorded"); return AMP_ERR_STATE; }
+    AMP_HIP(hipEventSynchronize(p.ev_end));
     if (which == 0) {
-        AMP_HIP(hipEventElapsedTime(ms_out, g->ev_begin, g->ev_end));
+        AMP_HIP(hipEventElapsedTime(ms_out, p.ev_begin, p.ev_end));
     } else if (which >= 1 && which < 2 + g->d.n_stages) {
         // sum over the batch groups (and, for which == 1, over the stages)
         float tot = 0.f;
-        for (int gi = 0; gi < g->ev_groups; ++gi)
+        for (int gi = 0; gi < p.ev_groups; ++gi)
             for (int i = 0; i < g->d.n_stages; ++i) {
                 if (which >= 2 && i != which - 2) continue;
                 float ms = 0.f;
                 const size_t e = 2 * ((size_t)g->d.n_stages * gi + i);
-                AMP_HIP(hipEventElapsedTime(&ms, g->ev_mrf[e], g->ev_mrf[e + 1]));
+                AMP_HIP(hipEventElapsedTime(&ms, p.ev_mrf[e], p.ev_mrf[e + 1]));
                 tot += ms;
             }
         *ms_out = tot;
@@ -739,19 +757,21 @@ int amp_gen_last_timing_ms(amp_gen* g, int which, float* ms_out) {
         // one resblock: 100 + 16 * stage + j, summed over the batch groups
         const int i = (which - 100) / 16, j = (which - 100) % 16, nk = g->d.n_kernels;
         float tot = 0.f;
-        for (int gi = 0; gi < g->ev_groups; ++gi) {
+        for (int gi = 0; gi < p.ev_groups; ++gi) {
             float ms = 0.f;
             const size_t e = (size_t)g->d.n_stages * (nk + 1) * gi + (size_t)i * (nk + 1) + j;
-            AMP_HIP(hipEventElapsedTime(&ms, g->ev_rb[e], g->ev_rb[e + 1]));
+            AMP_HIP(hipEventElapsedTime(&ms, p.ev_rb[e], p.ev_rb[e + 1]));
             tot += ms;
         }
         *ms_out = tot;
     } else {
-        set_error("amp_gen_last_timing_ms: which=%d", which);
+        set_error("amp_gen_timing_ms: which=%d", which);
         return AMP_ERR_INVALID;
     }
     return AMP_OK;
 }
+
+int amp_gen_last_timing_ms(amp_gen* g, int which, float* ms_out) { return amp_gen_timing_ms(g, 0, which, ms_out); }
 
 #define AMP_RC(expr) do { int rc__ = (expr); if (rc__ != AMP_OK) return rc__; } while (0)
 
@@ -872,21 +892,22 @@ int amp_gen_forward_ragged(amp_gen* g, const float* mel_dev, const float* cond_d
     const int ngroups = (B + G - 1) / G;
     const size_t be = gen_buf_elems(g, G, T);
     const size_t L = (size_t)T * g->hop;
-    if (g->profiling) {
+    amp_gen::ProfSlot* ps = g->prof.empty() ? nullptr : &g->prof[g->prof_count % g->prof.size()];
+    if (ps) {
         const size_t need = 2 * (size_t)d.n_stages * ngroups;
-        while (g->ev_mrf.size() < need) {
+        while (ps->ev_mrf.size() < need) {
             hipEvent_t e;
             AMP_HIP(hipEventCreate(&e));
-            g->ev_mrf.push_back(e);
+            ps->ev_mrf.push_back(e);
         }
         const size_t need_rb = (size_t)d.n_stages * (d.n_kernels + 1) * ngroups;
-        while (g->ev_rb.size() < need_rb) {
+        while (ps->ev_rb.size() < need_rb) {
             hipEvent_t e;
             AMP_HIP(hipEventCreate(&e));
-            g->ev_rb.push_back(e);
+            ps->ev_rb.push_back(e);
         }
-        g->ev_groups = ngroups;
-        AMP_HIP(hipEventRecord(g->ev_begin, st));
+        ps->ev_groups = ngroups;
+        AMP_HIP(hipEventRecord(ps->ev_begin, st));
     }
     for (int gi = 0; gi < ngroups; ++gi) {
         const int b0 = gi * G;
@@ -895,10 +916,10 @@ int amp_gen_forward_ragged(amp_gen* g, const float* mel_dev, const float* cond_d
                                  cond_dev ? cond_dev + (size_t)b0 * d.gin_channels : nullptr,
                                  lens_dev ? lens_dev + b0 : nullptr, Bg, T,
                                  wav_dev + (size_t)b0 * L, (float*)workspace_dev, be, st,
-                                 g->profiling ? g->ev_mrf.data() + 2 * (size_t)d.n_stages * gi : nullptr,
-                                 g->profiling ? g->ev_rb.data() + (size_t)d.n_stages * (d.n_kernels + 1) * gi : nullptr));
+                                 ps ? ps->ev_mrf.data() + 2 * (size_t)d.n_stages * gi : nullptr,
+                                 ps ? ps->ev_rb.data() + (size_t)d.n_stages * (d.n_kernels + 1) * gi : nullptr));
     }
-    if (g->profiling) { AMP_HIP(hipEventRecord(g->ev_end, st)); g->timing_valid = true; }
+    if (ps) { AMP_HIP(hipEventRecord(ps->ev_end, st)); ps->valid = true; ++g->prof_count; }
     return AMP_OK;
 }
 

@@ -116,7 +116,7 @@ class HipGenerator(nn.Module):
         self._amp_sig = None
         self._amp_device = None
         self._amp_ws = None
-        self._amp_profiling = False
+        self._amp_profiling = 0
 
     # subclasses provide the architecture descriptor
     def _amp_desc(self) -> _lib.amp_gen_desc:  # pragma: no cover - abstract
@@ -182,7 +182,7 @@ class HipGenerator(nn.Module):
             with torch.cuda.device(device):
                 _lib.check(L.amp_gen_finalize(h))
                 if self._amp_profiling:
-                    _lib.check(L.amp_gen_set_profiling(h, 1))
+                    _lib.check(L.amp_gen_set_profiling(h, int(self._amp_profiling)))
         except Exception:
             fin()
             raise
@@ -272,13 +272,16 @@ class HipGenerator(nn.Module):
         return replay, static_in, static_out
 
     # ---- profiling hooks used by bench.py ----
-    def set_profiling(self, enabled=True):
-        self._amp_profiling = bool(enabled)
+    def set_profiling(self, slots=1):
+        """Record HIP events around the kernels of every forward into a ring of ``slots`` event sets
+        (True = 1, False / 0 = off); see ``amp_gen_set_profiling``."""
+        self._amp_profiling = int(slots)
         if self._amp_handle is not None:
-            _lib.check(_lib.lib().amp_gen_set_profiling(self._amp_handle, int(enabled)))
+            _lib.check(_lib.lib().amp_gen_set_profiling(self._amp_handle, int(slots)))
 
-    def last_timing_ms(self, which=0):
-        """HIP-event time of the last forward on its launch stream. which: 0 whole forward, 1 MRF conv stack."""
+    def last_timing_ms(self, which=0, back=0):
+        """HIP-event time of a recorded forward on its launch stream (``back`` = 0: the latest).  which: 0 whole
+        forward, 1 MRF conv stack, 2 + i stage i, 100 + 16*i + j resblock j of stage i."""
         ms = ctypes.c_float()
-        _lib.check(_lib.lib().amp_gen_last_timing_ms(self._amp_handle, which, ctypes.byref(ms)))
+        _lib.check(_lib.lib().amp_gen_timing_ms(self._amp_handle, back, which, ctypes.byref(ms)))
         return ms.value

@@ -156,6 +156,12 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    # HIP events around the kernel groups of EVERY timed forward, recorded on the launch stream without
+    # synchronising (a ring of `steps` event sets inside the handle); read back after the closing fence.
+    # dominant kernel: the fused ResBlock pairs of stage 1 (C=128), kernel 11 -- resblock j=2 of stage i=1 is
+    # three back-to-back launches of pair_f16x3_kernel<11,4,1,3,192> (k=11 pairs with dilation 1, 3, 5)
+    DOM_STAGE, DOM_RB, DOM_LAUNCHES = 1, 2, 3
+    model.set_profiling(args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -165,22 +171,13 @@ def main():
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
-
-    # per-kernel-group time of one more (untimed) step, HIP events on the launch stream
-    model.set_profiling(True)
-    step()
-    torch.cuda.synchronize()
-    # dominant kernel: the fused ResBlock pairs of stage 1 (C=128), kernel 11 -- resblock j=2 of stage i=1 is
-    # three back-to-back launches of pair_f16x3_kernel<11,4,1,3,192> (k=11 pairs with dilation 1, 3, 5)
-    DOM_STAGE, DOM_RB, DOM_LAUNCHES = 1, 2, 3
     fwd_ms, mrf_ms, stage_ms, dom_ms = [], [], [], []
-    for _ in range(max(3, min(args.steps, 10))):
-        step()
-        fwd_ms.append(model.last_timing_ms(0))
-        mrf_ms.append(model.last_timing_ms(1))
-        stage_ms.append([model.last_timing_ms(2 + i) for i in range(len(hp["upsample_rates"]))])
-        dom_ms.append(model.last_timing_ms(100 + 16 * DOM_STAGE + DOM_RB))
-    model.set_profiling(False)
+    for back in range(args.steps):
+        fwd_ms.append(model.last_timing_ms(0, back))
+        mrf_ms.append(model.last_timing_ms(1, back))
+        stage_ms.append([model.last_timing_ms(2 + i, back) for i in range(len(hp["upsample_rates"]))])
+        dom_ms.append(model.last_timing_ms(100 + 16 * DOM_STAGE + DOM_RB, back))
+    model.set_profiling(0)
 
     if rank == 0:
         samples_per_step = total_items * L

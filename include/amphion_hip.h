@@ -134,12 +134,15 @@ int amp_gen_forward(amp_gen* g, const float* mel_dev, const float* cond_dev, int
 int amp_gen_forward_ragged(amp_gen* g, const float* mel_dev, const float* cond_dev, const int32_t* lens_dev, int B,
                            int T, float* wav_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 
-/* Duration [ms] of the kernels of the LAST amp_gen_forward on this handle, measured with HIP events
- * recorded on the launch stream when profiling is on.  which: 0 = whole forward, 1 = MRF conv stack
- * (all ResBlock/AMPBlock convs), 2 + i = the MRF convs of upsampling stage i, 100 + 16*i + j = resblock j of
- * stage i (its back-to-back conv / fused-pair launches).  Synchronises on the events.
- * Returns <0 on error. */
-int amp_gen_set_profiling(amp_gen* g, int enabled);
+/* Kernel timing with HIP events recorded on the launch stream.  amp_gen_set_profiling(g, slots) keeps a ring of
+ * `slots` event sets (0 = off): every amp_gen_forward records into the next one without synchronising, so a whole
+ * timed region of `slots` forwards can be read back afterwards.  amp_gen_timing_ms(g, back, which, &ms): `back` = 0
+ * is the most recent forward, 1 the one before, ...; which: 0 = whole forward, 1 = MRF conv stack (all
+ * ResBlock/AMPBlock convs), 2 + i = the MRF convs of upsampling stage i, 100 + 16*i + j = resblock j of stage i
+ * (its back-to-back conv / fused-pair launches).  Synchronises on that forward's events.  Returns <0 on error.
+ * amp_gen_last_timing_ms(g, which, &ms) == amp_gen_timing_ms(g, 0, which, &ms). */
+int amp_gen_set_profiling(amp_gen* g, int slots);
+int amp_gen_timing_ms(amp_gen* g, int back, int which, float* ms_out);
 int amp_gen_last_timing_ms(amp_gen* g, int which, float* ms_out);
 
 void amp_gen_destroy(amp_gen* g);
