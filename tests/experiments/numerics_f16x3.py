@@ -27,8 +27,10 @@ def conv1d(x, w, b=None, **kw):
     S = wscale(w)
     xh, xl = split(x, XS); wh, wl = split(w, S)
     y = _c1(xh, wh, None, **kw)
-    if mode["terms"] >= 3:
-        y = y + _c1(xl, wh, None, **kw) + _c1(xh, wl, None, **kw)
+    if mode["terms"] in (3, "w11"):
+        y = y + _c1(xl, wh, None, **kw)      # Whi * Xlo
+    if mode["terms"] in (3, "x11"):
+        y = y + _c1(xh, wl, None, **kw)      # Wlo * Xhi
     y = (y / (S * XS)).float()
     if b is not None: y = y + b.view(1, -1, 1)
     return y
@@ -39,8 +41,10 @@ def convt(x, w, b=None, **kw):
     S = wscale(w)
     xh, xl = split(x, XS); wh, wl = split(w, S)
     y = _ct(xh, wh, None, **kw)
-    if mode["terms"] >= 3:
-        y = y + _ct(xl, wh, None, **kw) + _ct(xh, wl, None, **kw)
+    if mode["terms"] in (3, "w11"):
+        y = y + _ct(xl, wh, None, **kw)
+    if mode["terms"] in (3, "x11"):
+        y = y + _ct(xh, wl, None, **kw)
     y = (y / (S * XS)).float()
     if b is not None: y = y + b.view(1, -1, 1)
     return y
@@ -54,9 +58,15 @@ with torch.no_grad():
     ref32 = vo.hifigan_forward(sd, hp, mel)
     mode["on"] = True
     y3 = vo.hifigan_forward(sd, hp, mel)
+    mode["terms"] = "w11"      # weights rounded to f16 (11 bits), activations split: 2 MFMAs per term
+    yw = vo.hifigan_forward(sd, hp, mel)
+    mode["terms"] = "x11"      # activations rounded to f16, weights split: 2 MFMAs per term
+    yx = vo.hifigan_forward(sd, hp, mel)
     mode["terms"] = 1
     y1 = vo.hifigan_forward(sd, hp, mel)
 print("out absmax", ref64.abs().max().item())
 print("fp32 oracle vs fp64:", (ref32.double() - ref64).abs().max().item())
 print("f16x3       vs fp64:", (y3.double() - ref64).abs().max().item())
+print("f16x2 (W 11b) vs fp64:", (yw.double() - ref64).abs().max().item())
+print("f16x2 (X 11b) vs fp64:", (yx.double() - ref64).abs().max().item())
 print("f16x1       vs fp64:", (y1.double() - ref64).abs().max().item())
