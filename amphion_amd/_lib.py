@@ -87,6 +87,7 @@ _SIGNATURES = {
     "amp_conv_forward_mrf": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_float, c_void_p]),
     "amp_apnet_polar": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "amp_istft_same": (c_int, [POINTER(amp_mel_desc), c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "amp_wav_to_pcm16": (c_int, [c_void_p, c_int, c_int, ctypes.c_longlong, c_void_p, c_void_p, ctypes.c_longlong, c_void_p]),
     "amp_conv_set_option": (c_int, [c_void_p, c_int, c_int]),
     "amp_pair_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
     "amp_conv_destroy": (None, [c_void_p]),

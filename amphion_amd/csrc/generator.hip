@@ -980,6 +980,18 @@ int amp_apnet_polar(const float* logamp_dev, const float* r_dev, const float* i_
     return AMP_OK;
 }
 
+int amp_wav_to_pcm16(const float* wav_dev, int B, int L, long long wav_stride, const int* lens_dev, int16_t* pcm_dev,
+                     long long pcm_stride, void* stream) {
+    if (!wav_dev || !pcm_dev) { set_error("amp_wav_to_pcm16: null argument"); return AMP_ERR_INVALID; }
+    if (B <= 0 || L <= 0 || wav_stride < L || pcm_stride < L) {
+        set_error("amp_wav_to_pcm16: B=%d L=%d wav_stride=%lld pcm_stride=%lld", B, L, wav_stride, pcm_stride);
+        return AMP_ERR_INVALID;
+    }
+    if (B > 65535) { set_error("amp_wav_to_pcm16: B=%d exceeds 65535 rows per call", B); return AMP_ERR_UNSUPPORTED; }
+    AMP_HIP(launch_pcm16(wav_dev, (short*)pcm_dev, B, L, wav_stride, pcm_stride, lens_dev, (hipStream_t)stream));
+    return AMP_OK;
+}
+
 int amp_conv_set_option(amp_conv* c, int option, int value) {
     if (!c) { set_error("amp_conv_set_option: null handle"); return AMP_ERR_INVALID; }
     if (option == AMP_CONV_OPT_PAD_REFLECT) {

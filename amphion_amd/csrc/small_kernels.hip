@@ -3,6 +3,7 @@
 //   act1d       : Activation1d(Snake|SnakeBeta)         modules/anti_aliasing/act.py:31-36
 //   add_channel_bias : x + cond(g) for a length-1 g      hifigan.py:426-427
 #include "amp_internal.h"
+#include <stdlib.h>
 
 namespace amp {
 
@@ -112,8 +113,49 @@ __device__ __forceinline__ float snake_sin2(float x) {
     return sn * sn;
 }
 
-constexpr int A1_NTILE = 4;   // consecutive tiles per workgroup (next tile's inputs prefetched into registers)
+// Two fp32 lanes per instruction (v_pk_fma_f32 / v_pk_mul_f32: the 157 TFLOP/s vector rate needs them).  Every
+// half goes through exactly the scalar operation sequence, so packed and scalar paths agree bit for bit.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 pk_splat(float v) { return (f32x2){v, v}; }
 
+// sin(x)^2 of snake_sin2's fast path on four pairs (x = a*u already formed by the caller).  Written step by step
+// across the four independent chains so that dependent packed ops are never back to back.
+__device__ __forceinline__ void snake_sin2_pk4(const f32x2 (&x)[4], f32x2 (&out)[4]) {
+    f32x2 k[4], r[4], r2[4], p[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) k[q] = __builtin_elementwise_rint(x[q] * 0.31830988618379067f);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = pk_fma(-k[q], pk_splat(3.140625f), x[q]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = pk_fma(-k[q], pk_splat(9.67502593994140625e-4f), r[q]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = pk_fma(-k[q], pk_splat(1.509957990978376432e-07f), r[q]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r2[q] = r[q] * r[q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p[q] = pk_fma(pk_splat(1.0f / 6227020800.0f), r2[q], pk_splat(-1.0f / 39916800.0f));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p[q] = pk_fma(p[q], r2[q], pk_splat(1.0f / 362880.0f));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p[q] = pk_fma(p[q], r2[q], pk_splat(-1.0f / 5040.0f));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p[q] = pk_fma(p[q], r2[q], pk_splat(1.0f / 120.0f));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p[q] = pk_fma(p[q], r2[q], pk_splat(-1.0f / 6.0f));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x2 sn = pk_fma(r[q] * r2[q], p[q], r[q]);
+        out[q] = sn * sn;
+    }
+}
+
+// NTILE consecutive tiles per workgroup.  When all of them lie inside the row, their windows are requested at
+// kernel entry by straight-line code (no register is renamed while its load is pending); otherwise a rolled loop
+// with the next tile's window in flight.  First / last / ragged tiles stage a clamped window and then run the same
+// packed arithmetic as interior tiles, with the out-of-range Snake values replicated afterwards.  NTILE = 2 keeps
+// the kernel at 64 VGPRs (8 workgroups per CU); measured on C3: NTILE 4 -> 29.0 ms, NTILE 2 -> 27.9 ms.
+template <int NTILE>
 __global__ __launch_bounds__(256) void act1d_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int T,
                                                     const float* __restrict__ a_dev,
                                                     const float* __restrict__ invb_dev, const float* __restrict__ fu,
@@ -122,13 +164,13 @@ __global__ __launch_bounds__(256) void act1d_kernel(const float* __restrict__ x,
     // staged window xl[i] = x[clamp(t0 - 8 + i)], i < A1_TT + 16 (starts 8 before the tile: 16-B aligned rows)
     __shared__ __attribute__((aligned(16))) float xl[A1_TT + 16];
     __shared__ __attribute__((aligned(16))) float sl[2 * A1_TT + 12];
-    __shared__ float ful[12], fdl[12];
+    __shared__ float ful[12];                      // up taps for the one-value-at-a-time paths: indexed by parity
     const int tid = threadIdx.x;
     const int ntiles = (T + A1_TT - 1) / A1_TT;   // T = row stride (padded length)
-    const int ngroups = (ntiles + A1_NTILE - 1) / A1_NTILE;
+    const int ngroups = (ntiles + NTILE - 1) / NTILE;
     const int bc = blockIdx.x / ngroups;
     const int c = bc % C;
-    const int tile_first = (blockIdx.x - bc * ngroups) * A1_NTILE;
+    const int tile_first = (blockIdx.x - bc * ngroups) * NTILE;
     // Tv = the utterance's own length: the replicate padding (resample.py:36-45, filter.py:92-99) clamps to
     // ITS last sample, so a padded batch equals the per-utterance results
     int Tv = T;
@@ -136,132 +178,187 @@ __global__ __launch_bounds__(256) void act1d_kernel(const float* __restrict__ x,
     const float a = a_dev[c], invb = invb_dev[c];
     const float* xr = x + (size_t)bc * T;
     float* yr = y + (size_t)bc * T;
-    if (tid < 12) { ful[tid] = fu[tid]; fdl[tid] = fd[tid]; }
+    // the 12 + 12 taps are wave-uniform: scalar loads, no LDS reads in the packed path.  The up filter carries
+    // the x2 gain of UpSample1d (resample.py:41; a power of two, so folding it is exact).
+    float fu2[12], fdr[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) { fu2[k] = 2.f * fu[k]; fdr[k] = fd[k]; }
+    if (tid < 12) ful[tid] = 2.f * fu[tid];
     const int twoT = 2 * Tv;
     const bool vec_rows = (T & 3) == 0;            // rows start 16-B aligned (x and y come from the workspace)
     // interior tile: no index is clamped anywhere in it, and its window can be loaded as aligned float4
     auto is_interior = [&](int t0) { return vec_rows && (t0 >= 8) && (t0 + A1_TT + 8 <= Tv); };
-
-    float4 pre0, pre1;                             // prefetched window of the next interior tile
-    bool have_pre = false;
-    for (int tl = 0; tl < A1_NTILE; ++tl) {
+    auto tile_live = [&](int tl) { return tl < NTILE && tile_first + tl < ntiles && (tile_first + tl) * A1_TT < Tv; };
+    // one Snake value from the staged window: s-index i of the tile has its k = 0 tap at xl[top], parity par
+    auto snake_scalar = [&](int i) {
+        const int top = ((i + 10) >> 1) + 3, par = i & 1;
+        float u = 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) u = fmaf(xl[top - k], ful[par + 2 * k], u);
+        return fmaf(invb, snake_sin2(u * a), u);
+    };
+    auto load_window = [&](int tl, float4& w0, float4& w1) {      // issue the global loads of an interior tile
         const int t0 = (tile_first + tl) * A1_TT;
-        if (t0 >= Tv || tile_first + tl >= ntiles) break;      // nothing valid from here on (block-uniform)
-        if (is_interior(t0)) {
-            // ---- vector path: float4 global loads (next tile prefetched under this tile's arithmetic),
-            //      3 + 5 ds_read_b128 per thread instead of 96 scalar LDS reads ----
-            float4 v0, v1 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (have_pre) { v0 = pre0; v1 = pre1; }
-            else {
-                v0 = *reinterpret_cast<const float4*>(xr + t0 - 8 + 4 * tid);
-                if (tid < 4) v1 = *reinterpret_cast<const float4*>(xr + t0 - 8 + A1_TT + 4 * tid);
-            }
+        if (tile_live(tl) && is_interior(t0)) {
+            w0 = *reinterpret_cast<const float4*>(xr + t0 - 8 + 4 * tid);
+            if (tid < 4) w1 = *reinterpret_cast<const float4*>(xr + t0 - 8 + A1_TT + 4 * tid);
+        }
+    };
+
+    // ---- one tile: v0 / v1 = its window when it is interior ----
+    auto process_tile = [&](const int t0, const bool interior, const float4 v0, const float4 v1) __attribute__((always_inline)) {
+        if (interior) {
             *reinterpret_cast<float4*>(&xl[4 * tid]) = v0;
             if (tid < 4) *reinterpret_cast<float4*>(&xl[A1_TT + 4 * tid]) = v1;
-            const int tn = t0 + A1_TT;
-            have_pre = (tl + 1 < A1_NTILE) && (tile_first + tl + 1 < ntiles) && is_interior(tn);
-            if (have_pre) {
-                pre0 = *reinterpret_cast<const float4*>(xr + tn - 8 + 4 * tid);
-                if (tid < 4) pre1 = *reinterpret_cast<const float4*>(xr + tn - 8 + A1_TT + 4 * tid);
-            }
-            __syncthreads();
-            for (int i0 = 8 * tid; i0 < 2 * A1_TT + 11; i0 += 8 * 256) {
-                // Snake value i = i0 + e (n = 2*t0 + i - 5) needs x[((n + 15) >> 1) - k - 5], k = 0..5
-                //   = xl[(i0 >> 1) + ((e + 10) >> 1) + 3 - k]: a 12-float window at xl[i0 >> 1]
-                const int xb = i0 >> 1;                           // multiple of 4
-                const float4 w0 = *reinterpret_cast<const float4*>(&xl[xb]);
-                const float4 w1 = *reinterpret_cast<const float4*>(&xl[xb + 4]);
-                const float4 w2 = *reinterpret_cast<const float4*>(&xl[xb + 8]);
-                const float xw[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
-                float sv[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int par = e & 1;                        // (n + 15) & 1, i0 even
-                    const int top = ((e + 10) >> 1) + 3;          // window index of k = 0
-                    float u = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) u = fmaf(xw[top - k], ful[par + 2 * k], u);
-                    u *= 2.f;
-                    sv[e] = u + invb * snake_sin2(u * a);
-                }
-                if (i0 + 8 <= 2 * A1_TT + 12) {
-                    *reinterpret_cast<float4*>(&sl[i0]) = make_float4(sv[0], sv[1], sv[2], sv[3]);
-                    *reinterpret_cast<float4*>(&sl[i0 + 4]) = make_float4(sv[4], sv[5], sv[6], sv[7]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (i0 + e < 2 * A1_TT + 12) sl[i0 + e] = sv[e];
-                }
-            }
-            __syncthreads();
-            {
-                const int k0 = 4 * tid;                           // outputs k0..k0+3 need sl[2*k0 .. 2*k0 + 17]
-                float sw[20];
-#pragma unroll
-                for (int v = 0; v < 5; ++v) {
-                    const float4 q = *reinterpret_cast<const float4*>(&sl[2 * k0 + 4 * v]);
-                    sw[4 * v] = q.x; sw[4 * v + 1] = q.y; sw[4 * v + 2] = q.z; sw[4 * v + 3] = q.w;
-                }
-                float4 o;
-                float* op = &o.x;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float acc = 0.f;
-#pragma unroll
-                    for (int j = 0; j < 12; ++j) acc = fmaf(fdl[j], sw[2 * e + j], acc);
-                    op[e] = acc;
-                }
-                *reinterpret_cast<float4*>(yr + t0 + k0) = o;     // vec_rows: 16-B aligned
-            }
         } else {
-            // ---- edge tiles (first / last of a row, ragged ends, unaligned rows): clamp every index ----
-            have_pre = false;
+            // the replicate-padded window itself: every tap below then reads x[clamp(.)] as resample.py:36 does
             for (int i = tid; i < A1_TT + 16; i += 256) {
                 int t = t0 - 8 + i;
                 t = t < 0 ? 0 : (t > Tv - 1 ? Tv - 1 : t);
                 xl[i] = xr[t];
             }
-            __syncthreads();
-            for (int i = tid; i < 2 * A1_TT + 11; i += 256) {
-                int n = 2 * t0 + i - 5;
-                n = n < 0 ? 0 : (n > twoT - 1 ? twoT - 1 : n);
-                const int np = n + 15;
-                const int mmax = np >> 1;
-                const int par = np & 1;
-                float u = 0.f;
+        }
+        __syncthreads();
+        {
+            // Snake values i = 8*tid + e, e < 8 (n = 2*t0 + i - 5) need x[((n + 15) >> 1) - k - 5], k = 0..5
+            //   = xl[4*tid + ((e + 10) >> 1) + 3 - k]: a 12-float window at xl[4*tid].  Values e = 2q, 2q+1
+            // share their six x taps and take the even / odd phase of the filter: one packed chain.
+            const int xb = 4 * tid;
+            const float4 w0 = *reinterpret_cast<const float4*>(&xl[xb]);
+            const float4 w1 = *reinterpret_cast<const float4*>(&xl[xb + 4]);
+            const float4 w2 = *reinterpret_cast<const float4*>(&xl[xb + 8]);
+            const float xw[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+            f32x2 uv[4], xa[4], sv[4];
+            float big = 0.f;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    int xi = mmax - k - 5;  // index into x before clamping
-                    xi = xi < 0 ? 0 : (xi > Tv - 1 ? Tv - 1 : xi);
-                    u = fmaf(xl[xi - (t0 - 8)], ful[par + 2 * k], u);
-                }
-                u *= 2.f;
-                sl[i] = u + invb * snake_sin2(u * a);
+            for (int q = 0; q < 4; ++q) {
+                const int top = q + 8;                        // ((2q + 10) >> 1) + 3
+                f32x2 u = pk_splat(0.f);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) u = pk_fma(pk_splat(xw[top - k]), (f32x2){fu2[2 * k], fu2[2 * k + 1]}, u);
+                uv[q] = u;
+                xa[q] = u * a;
+                big = fmaxf(big, fmaxf(fabsf(xa[q].x), fabsf(xa[q].y)));
             }
-            __syncthreads();
-            for (int k = tid; k < A1_TT; k += 256) {
-                const int t = t0 + k;
-                if (t < Tv) {
-                    float acc = 0.f;
+            snake_sin2_pk4(xa, sv);
 #pragma unroll
-                    for (int j = 0; j < 12; ++j) acc = fmaf(fdl[j], sl[2 * k + j], acc);
-                    yr[t] = acc;
-                }
+            for (int q = 0; q < 4; ++q) sv[q] = pk_fma(pk_splat(invb), sv[q], uv[q]);
+            *reinterpret_cast<float4*>(&sl[8 * tid]) = make_float4(sv[0].x, sv[0].y, sv[1].x, sv[1].y);
+            *reinterpret_cast<float4*>(&sl[8 * tid + 4]) = make_float4(sv[2].x, sv[2].y, sv[3].x, sv[3].y);
+            if (__builtin_expect(big > 1.0e5f, 0)) {
+                // beyond the fast range reduction: redo this lane's eight values one at a time through
+                // snake_sin2 (libm sine above 1e5, the identical operation sequence below it)
+#pragma nounroll
+                for (int e = 0; e < 8; ++e) sl[8 * tid + e] = snake_scalar(8 * tid + e);
+            }
+            // the 10 values past the 2048 (the down filter's right halo): one lane each in the last wave
+            if (tid >= 256 - 10) {
+                const int i = 2 * A1_TT + (tid - (256 - 10));
+                sl[i] = snake_scalar(i);
+            }
+        }
+        if (!interior) {
+            // DownSample1d pads the SNAKE OUTPUT by replication (filter.py:92-99): values whose n = 2*t0 + i - 5
+            // lies outside [0, 2*Tv - 1] are copies of the first / last valid one, not filter results
+            __syncthreads();
+            const int ilo = 5 - 2 * t0;                       // i of n = 0
+            const int ihi = twoT + 4 - 2 * t0;                // i of n = 2*Tv - 1  (>= 6: t0 < Tv)
+            const float slo = sl[ilo > 0 ? ilo : 0];
+            const float shi = sl[ihi < 2 * A1_TT + 9 ? ihi : 2 * A1_TT + 9];
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int i = 8 * tid + e;
+                if (i < ilo) sl[i] = slo;
+                else if (i > ihi) sl[i] = shi;
+            }
+            if (tid >= 256 - 10) {
+                const int i = 2 * A1_TT + (tid - (256 - 10));
+                if (i > ihi) sl[i] = shi;
+            }
+        }
+        __syncthreads();
+        {
+            const int k0 = 4 * tid;                           // outputs k0..k0+3 need sl[2*k0 .. 2*k0 + 17]
+            f32x2 sw[10];
+#pragma unroll
+            for (int v = 0; v < 5; ++v) {
+                const float4 q = *reinterpret_cast<const float4*>(&sl[2 * k0 + 4 * v]);
+                sw[2 * v] = (f32x2){q.x, q.y};
+                sw[2 * v + 1] = (f32x2){q.z, q.w};
+            }
+            float4 o;
+            float* op = &o.x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f32x2 acc = pk_splat(0.f);                    // (even taps, odd taps): two FMA chains, added below
+#pragma unroll
+                for (int m = 0; m < 6; ++m) acc = pk_fma((f32x2){fdr[2 * m], fdr[2 * m + 1]}, sw[e + m], acc);
+                op[e] = acc.x + acc.y;
+            }
+            if (interior || (vec_rows && t0 + k0 + 4 <= Tv)) {
+                *reinterpret_cast<float4*>(yr + t0 + k0) = o; // vec_rows: 16-B aligned
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (t0 + k0 + e < Tv) yr[t0 + k0 + e] = op[e];
             }
         }
         __syncthreads();   // xl / sl are rewritten by the next tile
+    };
+
+    // do all NTILE tiles of this workgroup exist and lie inside the row (block-uniform)?
+    const bool all_interior = tile_first + NTILE <= ntiles && is_interior(tile_first * A1_TT) &&
+                              is_interior((tile_first + NTILE - 1) * A1_TT);
+    if (all_interior) {
+        // straight-line path: every window requested now, by every lane (lanes >= 4 repeat the halo address of
+        // lane & 3, so no load is conditional and none has to be waited for before its tile comes up)
+        float4 w0[NTILE], w1[NTILE];
+#pragma unroll
+        for (int tl = 0; tl < NTILE; ++tl) {
+            const float* wp = xr + (tile_first + tl) * A1_TT - 8;
+            w0[tl] = *reinterpret_cast<const float4*>(wp + 4 * tid);
+            w1[tl] = *reinterpret_cast<const float4*>(wp + A1_TT + 4 * (tid & 3));
+            // keep the requests together at the top (the machine scheduler would otherwise interleave them with
+            // address arithmetic).  hipcc still sinks tile 0's pair below the others, to its first use: harmless,
+            // loads return in issue order and tile 0 has to wait one full latency either way.
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int tl = 0; tl < NTILE; ++tl) process_tile((tile_first + tl) * A1_TT, true, w0[tl], w1[tl]);
+    } else {
+        float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
+        load_window(0, p0, p1);
+        for (int tl = 0; tl < NTILE; ++tl) {
+            const int t0 = (tile_first + tl) * A1_TT;
+            if (!tile_live(tl)) break;             // nothing valid from here on (block-uniform)
+            const float4 v0 = p0, v1 = p1;
+            load_window(tl + 1, p0, p1);           // in flight under this tile's arithmetic
+            process_tile(t0, is_interior(t0), v0, v1);
+        }
     }
+}
+
+template <int NTILE>
+static hipError_t launch_act1d_n(const float* x, float* y, int B, int C, int T, const float* a_dev, const float* invb_dev,
+                                 const float* fu, const float* fd, const int* lens, int len_mul, hipStream_t stream) {
+    const int ntiles = (T + A1_TT - 1) / A1_TT;
+    const int ngroups = (ntiles + NTILE - 1) / NTILE;
+    dim3 grid((unsigned)((size_t)ngroups * (size_t)(B * C)));
+    hipLaunchKernelGGL(act1d_kernel<NTILE>, grid, dim3(256), 0, stream, x, y, C, T, a_dev, invb_dev, fu, fd, lens,
+                       len_mul);
+    return hipGetLastError();
 }
 
 hipError_t launch_act1d(const float* x, float* y, int B, int C, int T, const float* a_dev, const float* invb_dev,
                         const float* filt_up12, const float* filt_dn12, const int* lens, int len_mul,
                         hipStream_t stream) {
-    const int ntiles = (T + A1_TT - 1) / A1_TT;
-    const int ngroups = (ntiles + A1_NTILE - 1) / A1_NTILE;
-    dim3 grid((unsigned)((size_t)ngroups * (size_t)(B * C)));
-    hipLaunchKernelGGL(act1d_kernel, grid, dim3(256), 0, stream, x, y, C, T, a_dev, invb_dev, filt_up12, filt_dn12,
-                       lens, len_mul);
-    return hipGetLastError();
+    // tiles per workgroup: 2 unless AMP_ACT1D_TILES says 1 or 4 (tuning knob for tools/bench_configs.py)
+    static const int ntile = [] { const char* e = getenv("AMP_ACT1D_TILES"); return e ? atoi(e) : 2; }();
+    if (ntile == 1) return launch_act1d_n<1>(x, y, B, C, T, a_dev, invb_dev, filt_up12, filt_dn12, lens, len_mul, stream);
+    if (ntile == 4) return launch_act1d_n<4>(x, y, B, C, T, a_dev, invb_dev, filt_up12, filt_dn12, lens, len_mul, stream);
+    return launch_act1d_n<2>(x, y, B, C, T, a_dev, invb_dev, filt_up12, filt_dn12, lens, len_mul, stream);
 }
 
 // APNet head (apnet.py:379-383): pha = atan2(I, R); rea = exp(logamp) * cos(pha); imag = exp(logamp) * sin(pha)
@@ -284,6 +381,56 @@ hipError_t launch_apnet_polar(const float* logamp, const float* R, const float* 
     size_t blocks = (n + 255) / 256;
     if (blocks > 65535u * 16u) blocks = 65535u * 16u;
     hipLaunchKernelGGL(apnet_polar_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, logamp, R, I, n, pha, rea, imag);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 waveform -> signed 16-bit PCM, the conversion the reference's save_audio performs on the host after the
+// D2H copy (utils/io.py:68-76: torchaudio.save(..., encoding="PCM_S", bits_per_sample=16); torchaudio 2.0.2 /
+// libsox 14.4.2, restated in oracle/pcm16.py).  Integer work, bit-exact:
+//   d   = trunc(clamp(x * 2^31, INT32_MIN, INT32_MAX))                 (sox_sample_t; NaN -> INT32_MIN like x86)
+//   pcm = d > INT32_MAX - 2^15 ? 32767 : (d + 2^15) >> 16              (SOX_SAMPLE_TO_SIGNED_16BIT: round half up)
+// Samples at or past an item's length are written as 0.  8 samples per lane: 2 x 16-B loads, one 16-B store.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int pcm16_of(float x) {
+    const float v = x * 2147483648.0f;                 // exact (power of two) or +-inf
+    int d;
+    if (v >= 2147483648.0f) d = 2147483647;
+    else if (v > -2147483648.0f) d = (int)v;           // |v| < 2^31: truncation toward zero, exact
+    else d = (-2147483647 - 1);                        // <= -2^31 and NaN
+    return d > 2147483647 - 32768 ? 32767 : ((d + 32768) >> 16);
+}
+
+__global__ __launch_bounds__(256) void pcm16_kernel(const float* __restrict__ x, short* __restrict__ y, int L,
+                                                    long long x_stride, long long y_stride,
+                                                    const int* __restrict__ lens) {
+    const int b = blockIdx.y;
+    const int Lv = lens ? min(max(lens[b], 0), L) : L;
+    const float* xr = x + (size_t)b * x_stride;
+    short* yr = y + (size_t)b * y_stride;
+    const bool vec = ((x_stride & 3) == 0) && ((y_stride & 7) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+    for (int t0 = (blockIdx.x * 256 + threadIdx.x) * 8; t0 < L; t0 += gridDim.x * 256 * 8) {
+        if (vec && t0 + 8 <= Lv) {
+            const float4 a = *reinterpret_cast<const float4*>(xr + t0);
+            const float4 c = *reinterpret_cast<const float4*>(xr + t0 + 4);
+            uint4 o;
+            o.x = ((unsigned)pcm16_of(a.x) & 0xffffu) | ((unsigned)pcm16_of(a.y) << 16);
+            o.y = ((unsigned)pcm16_of(a.z) & 0xffffu) | ((unsigned)pcm16_of(a.w) << 16);
+            o.z = ((unsigned)pcm16_of(c.x) & 0xffffu) | ((unsigned)pcm16_of(c.y) << 16);
+            o.w = ((unsigned)pcm16_of(c.z) & 0xffffu) | ((unsigned)pcm16_of(c.w) << 16);
+            *reinterpret_cast<uint4*>(yr + t0) = o;
+        } else {
+            for (int e = 0; e < 8 && t0 + e < L; ++e) yr[t0 + e] = t0 + e < Lv ? (short)pcm16_of(xr[t0 + e]) : (short)0;
+        }
+    }
+}
+
+hipError_t launch_pcm16(const float* x, short* y, int B, int L, long long x_stride, long long y_stride,
+                        const int* lens, hipStream_t stream) {
+    unsigned gx = (unsigned)((L + 2047) / 2048);
+    if (gx > 4096u) gx = 4096u;                         // grid-stride past 8 Mi samples per row
+    hipLaunchKernelGGL(pcm16_kernel, dim3(gx, (unsigned)B), dim3(256), 0, stream, x, y, L, x_stride, y_stride, lens);
     return hipGetLastError();
 }
 

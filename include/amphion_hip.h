@@ -175,6 +175,15 @@ int amp_conv_forward_mrf(const amp_conv* c, const float* x_dev, int B, int T, fl
 int amp_apnet_polar(const float* logamp_dev, const float* r_dev, const float* i_dev, size_t n, float* pha_dev,
                     float* rea_dev, float* imag_dev, void* stream);
 
+/* fp32 waveform [B, L] (row stride wav_stride elements) -> signed 16-bit PCM [B, L] (row stride pcm_stride), on
+ * the device, so the D2H copy and any gather move 2 bytes per sample instead of 4.  Replaces the host conversion
+ * inside the reference's save_audio (utils/io.py:68-76 -> torchaudio.save(encoding="PCM_S", bits_per_sample=16);
+ * torchaudio 2.0.2 + libsox 14.4.2 semantics: sample = x * 2^31 clamped and truncated to int32, then rounded
+ * half-up to 16 bits with saturation).  lens_dev (samples per row, may be NULL) zeroes the tail of each row: the
+ * crop `[: l * hop_size]` of models/vocoders/vocoder_inference.py:359.  Bit-exact against oracle/pcm16.py. */
+int amp_wav_to_pcm16(const float* wav_dev, int B, int L, long long wav_stride, const int* lens_dev, int16_t* pcm_dev,
+                     long long pcm_stride, void* stream);
+
 /* Per-conv options (default 0).  PAD_REFLECT: columns outside the input mirror instead of reading zero, i.e.
  * nn.ReflectionPad1d(p) followed by an unpadded conv == this conv created with padding = p (MelGAN,
  * models/vocoders/gan/generator/melgan.py:39,56,92); needs p < T.  TANH: tanh on store (melgan.py:94). */

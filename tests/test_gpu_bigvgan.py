@@ -24,7 +24,10 @@ def test_activation1d_golden(golden):
     assert np.abs(y.numpy() - golden["act1d_T1_y"]).max() <= 5e-6
 
 
-@pytest.mark.parametrize("B,C,T", [(1, 3, 2), (2, 32, 1023), (1, 7, 1024), (2, 5, 1025), (1, 2, 5000)])
+# 1024-sample tiles: rows that are all edge tiles (<= 2048), a tile that is interior to the last sample (2056),
+# interior + ragged last tile (3080, 4100), whole workgroups of interior tiles (9216, 12288), unaligned rows (1025)
+@pytest.mark.parametrize("B,C,T", [(1, 3, 2), (2, 32, 1023), (1, 7, 1024), (2, 5, 1025), (1, 2, 5000), (1, 2, 2048),
+                                   (1, 3, 2056), (2, 2, 3080), (1, 2, 4100), (1, 1, 9216), (1, 2, 12288), (1, 1, 12290)])
 def test_activation1d_vs_oracle(B, C, T):
     from hip_helpers import act1d_forward
 
@@ -36,6 +39,25 @@ def test_activation1d_vs_oracle(B, C, T):
     ref = vo.activation1d(x, al, be, True)
     y = act1d_forward(x, al, be, True, f, f)
     assert (y - ref).abs().max().item() <= 5e-6
+
+
+def test_activation1d_large_arguments():
+    # |alpha * u| > 1e5 leaves the fast range reduction (snake_sin2 falls back to libm's sine).  fp32 sin of such
+    # arguments is ill-conditioned (one ulp of u moves the phase by ~0.02 rad), so the check is the bound
+    # |y - down(up(x))| <= max 1/beta, finiteness, and agreement with the oracle where alpha is small.
+    from hip_helpers import act1d_forward
+
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(1, 4, 4096, generator=g) * 1.5
+    al = torch.tensor([12.5, -0.2, 13.0, 0.1])            # log-scale: exp(12.5) = 2.7e5
+    be = torch.tensor([0.3, -0.1, 0.0, 0.2])
+    f = vo.kaiser_sinc_filter1d(0.25, 0.3, 12)
+    y = act1d_forward(x, al, be, True, f, f)
+    ref = vo.activation1d(x, al, be, True)
+    assert torch.isfinite(y).all()
+    assert (y[:, [1, 3]] - ref[:, [1, 3]]).abs().max().item() <= 5e-6
+    lin = vo.activation1d(x, torch.full((4,), -40.0), be, True)          # alpha -> 0: the activation is x + ~0
+    assert ((y - lin).abs().amax(dim=(0, 2)) <= 1.0 / be.exp() * 1.3 + 1e-3).all()
 
 
 def test_activation1d_module():
