@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU oracle is torch on the host cores.  On a 256-thread GPU host torch's default (all hardware threads)
+    # is ~40x slower than 16 threads for these conv shapes (tests/experiments/cpu_threads_sweep.py), and xdist
+    # workers would oversubscribe further: cap it.
+    import torch
+
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
 
 
 @pytest.fixture(scope="session")

@@ -3,7 +3,7 @@
 configs[1] headline):  c3 BigVGAN-base 24 kHz B=32,  c5 VITS enc_q -> flow -> flow^-1 -> dec B=16,  mel = the
 front end at B=64 x 65 536 samples,  list = the list API on ragged utterances,  lat = single-utterance latency.
 
-    python tools/bench_configs.py [--reps 5] [--only c3|c5|mel|list|lat]
+    python tools/bench_configs.py [--reps 5] [--only c3|c5|mel|pcm|list|lat]
 Product path only (amphion_amd modules + seeded random-init weights); one JSON line per config."""
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -66,6 +66,15 @@ def mel(reps):
              "samples_per_s": 64 * 65536 / ms * 1e3, "algorithmic_GBps": byts / ms / 1e6}]
 
 
+def pcm(reps):
+    from amphion_amd.utils.io import wav_to_pcm16
+    wav = (torch.rand(64, 65536, generator=torch.Generator().manual_seed(2)) * 2.2 - 1.1).to(DEV)
+    ms = timed(lambda: wav_to_pcm16(wav), reps)
+    byts = 64 * 65536 * (4 + 2)
+    return [{"config": "fp32 -> PCM16 (amp_wav_to_pcm16), B=64 x 65536 samples", "ms_per_step": ms,
+             "samples_per_s": 64 * 65536 / ms * 1e3, "algorithmic_GBps": byts / ms / 1e6}]
+
+
 def lst(reps):
     from amphion_amd.models.vocoders.gan.gan_vocoder_inference import synthesis_audios
     cfg, m = hifigan()
@@ -100,9 +109,9 @@ def lat(reps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--only", default="", choices=["", "c3", "c5", "mel", "list", "lat"])
+    ap.add_argument("--only", default="", choices=["", "c3", "c5", "mel", "pcm", "list", "lat"])
     a = ap.parse_args()
-    runs = {"c3": c3, "c5": c5, "mel": mel, "list": lst, "lat": lat}
+    runs = {"c3": c3, "c5": c5, "mel": mel, "pcm": pcm, "list": lst, "lat": lat}
     with torch.no_grad():
         for name, fn in runs.items():
             if a.only in ("", name):
