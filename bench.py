@@ -35,7 +35,7 @@ PEAK_HBM_GBS = 8000.0
 # on MI355X (profiles/r1_mfma_peak_microbench.txt): the chip clocks down to ~1.6 GHz under MFMA load
 # (2192 TF on zeros, 1580-1630 TF on random data), so this -- not 2516.6 -- is what a perfect kernel gets.
 SUSTAINED_F16_TFLOPS = 1600.0
-PROFILE_TRAFFIC_CSV = os.path.join(ROOT, "profiles", "r1_v5_f16x3_fused_hbm_traffic.csv")
+PROFILE_TRAFFIC_CSV = os.path.join(ROOT, "profiles", "r1_v6_f16x3_fused_hbm_traffic.csv")
 # arithmetic of the conv contractions -> (dtype string, peak for ALGORITHMIC flops, note)
 PRECISIONS = {
     "f16x3": ("f32 (split-f16 MFMA: 3 x v_mfma_f32_32x32x16_f16 per term, f32 accumulate)", PEAK_F16_TFLOPS / 3.0,
