@@ -20,6 +20,7 @@ AMP_ARCH_HIFIGAN, AMP_ARCH_BIGVGAN, AMP_ARCH_HIFIGAN_VITS = 0, 1, 2
 AMP_ACT_LRELU, AMP_ACT_SNAKE, AMP_ACT_SNAKEBETA = 0, 1, 2
 AMP_PRECISION_F32, AMP_PRECISION_F16X3 = 0, 1
 AMP_CONV_OPT_PAD_REFLECT, AMP_CONV_OPT_TANH = 1, 2
+AMP_PAD_REPLICATE, AMP_PAD_ZEROS, AMP_PAD_REFLECT = 0, 1, 2
 PRECISIONS = {"f32": AMP_PRECISION_F32, "fp32": AMP_PRECISION_F32, "f16x3": AMP_PRECISION_F16X3}
 
 
@@ -87,6 +88,9 @@ _SIGNATURES = {
     "amp_conv_forward_mrf": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_float, c_void_p]),
     "amp_apnet_polar": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "amp_istft_same": (c_int, [POINTER(amp_mel_desc), c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "amp_snake": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "amp_fir_upsample": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "amp_fir_filter": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "amp_wav_to_pcm16": (c_int, [c_void_p, c_int, c_int, ctypes.c_longlong, c_void_p, c_void_p, ctypes.c_longlong, c_void_p]),
     "amp_conv_set_option": (c_int, [c_void_p, c_int, c_int]),
     "amp_pair_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),

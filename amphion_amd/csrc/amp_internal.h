@@ -113,6 +113,12 @@ hipError_t launch_flip_channels(const float* x, float* y, int B, int C, int T, h
 hipError_t launch_posterior_sample(const float* stats, const float* eps, const int* lens, float* z, int B, int C, int T,
                                    hipStream_t stream);
 
+hipError_t launch_fir_up(const float* x, float* y, int rows, int T, const float* taps_host, int K, int ratio, int pad,
+                         int pad_left, hipStream_t stream);
+hipError_t launch_fir_filter(const float* x, float* y, int rows, int T, int Tout, const float* taps_host, int K,
+                             int stride, int pad_left, int mode, hipStream_t stream);
+hipError_t launch_snake(const float* x, float* y, int B, int C, int T, const float* alpha, const float* beta, int logscale,
+                        hipStream_t stream);
 hipError_t launch_pcm16(const float* x, short* y, int B, int L, long long x_stride, long long y_stride, const int* lens,
                         hipStream_t stream);
 hipError_t launch_apnet_polar(const float* logamp, const float* R, const float* I, size_t n, float* pha, float* rea,

@@ -980,6 +980,48 @@ int amp_apnet_polar(const float* logamp_dev, const float* r_dev, const float* i_
     return AMP_OK;
 }
 
+int amp_snake(const float* x_dev, int B, int C, int T, const float* alpha_dev, const float* beta_dev, int logscale,
+              float* y_dev, void* stream) {
+    if (!x_dev || !y_dev || !alpha_dev) { set_error("amp_snake: null argument"); return AMP_ERR_INVALID; }
+    if (B <= 0 || C <= 0 || T <= 0) { set_error("amp_snake: B=%d C=%d T=%d", B, C, T); return AMP_ERR_INVALID; }
+    AMP_HIP(launch_snake(x_dev, y_dev, B, C, T, alpha_dev, beta_dev, logscale, (hipStream_t)stream));
+    return AMP_OK;
+}
+
+int amp_fir_upsample(const float* x_dev, int B, int C, int T, const float* filt_host, int K, int ratio, float* y_dev,
+                     void* stream) {
+    if (!x_dev || !y_dev || !filt_host) { set_error("amp_fir_upsample: null argument"); return AMP_ERR_INVALID; }
+    if (B <= 0 || C <= 0 || T <= 0 || ratio < 1 || K < ratio) {
+        set_error("amp_fir_upsample: B=%d C=%d T=%d K=%d ratio=%d", B, C, T, K, ratio);
+        return AMP_ERR_INVALID;
+    }
+    if (K > AMP_FIR_MAX_TAPS) { set_error("amp_fir_upsample: %d taps (max %d)", K, AMP_FIR_MAX_TAPS); return AMP_ERR_UNSUPPORTED; }
+    const int pad = K / ratio - 1;                                   // resample.py:24-28
+    const int pad_left = pad * ratio + (K - ratio) / 2;
+    AMP_HIP(launch_fir_up(x_dev, y_dev, B * C, T, filt_host, K, ratio, pad, pad_left, (hipStream_t)stream));
+    return AMP_OK;
+}
+
+int amp_fir_filter(const float* x_dev, int B, int C, int T, const float* filt_host, int K, int stride, int pad_left,
+                   int pad_right, int pad_mode, float* y_dev, void* stream) {
+    if (!x_dev || !y_dev || !filt_host) { set_error("amp_fir_filter: null argument"); return AMP_ERR_INVALID; }
+    if (B <= 0 || C <= 0 || T <= 0 || K < 1 || stride < 1 || pad_left < 0 || pad_right < 0) {
+        set_error("amp_fir_filter: B=%d C=%d T=%d K=%d stride=%d pad=(%d,%d)", B, C, T, K, stride, pad_left, pad_right);
+        return AMP_ERR_INVALID;
+    }
+    if (K > AMP_FIR_MAX_TAPS) { set_error("amp_fir_filter: %d taps (max %d)", K, AMP_FIR_MAX_TAPS); return AMP_ERR_UNSUPPORTED; }
+    if (pad_mode < AMP_PAD_REPLICATE || pad_mode > AMP_PAD_REFLECT) { set_error("amp_fir_filter: unknown pad_mode %d", pad_mode); return AMP_ERR_INVALID; }
+    if (pad_mode == AMP_PAD_REFLECT && (pad_left >= T || pad_right >= T)) {
+        set_error("amp_fir_filter: reflection padding (%d, %d) needs more than that many input samples (T=%d)", pad_left, pad_right, T);
+        return AMP_ERR_INVALID;
+    }
+    const int Tp = T + pad_left + pad_right;
+    if (Tp < K) { set_error("amp_fir_filter: input too short (T=%d, padded %d, K=%d)", T, Tp, K); return AMP_ERR_INVALID; }
+    const int Tout = (Tp - K) / stride + 1;
+    AMP_HIP(launch_fir_filter(x_dev, y_dev, B * C, T, Tout, filt_host, K, stride, pad_left, pad_mode, (hipStream_t)stream));
+    return AMP_OK;
+}
+
 int amp_wav_to_pcm16(const float* wav_dev, int B, int L, long long wav_stride, const int* lens_dev, int16_t* pcm_dev,
                      long long pcm_stride, void* stream) {
     if (!wav_dev || !pcm_dev) { set_error("amp_wav_to_pcm16: null argument"); return AMP_ERR_INVALID; }

@@ -361,6 +361,106 @@ hipError_t launch_act1d(const float* x, float* y, int B, int C, int T, const flo
     return launch_act1d_n<2>(x, y, B, C, T, a_dev, invb_dev, filt_up12, filt_dn12, lens, len_mul, stream);
 }
 
+// ---------------------------------------------------------------------------------------------
+// UpSample1d / LowPassFilter1d (DownSample1d) as stand-alone ops (resample.py:17-65, filter.py:64-99): the two
+// halves of Activation1d for callers that use them on their own, any ratio / kernel size up to 64 taps.
+// Depthwise FIR, one output per lane, rows of [B*C, T] coalesced along time; the taps travel as a kernel argument.
+// ---------------------------------------------------------------------------------------------
+struct FirTaps { float f[AMP_FIR_MAX_TAPS]; };
+
+// y[n] = ratio * sum_m xp[m] * f[n + pad_left - m*ratio],  xp[m] = x[clamp(m - pad, 0, T-1)]   (resample.py:38-42)
+__global__ __launch_bounds__(256) void fir_up_kernel(const float* __restrict__ x, float* __restrict__ y, int T,
+                                                     int K, int ratio, int pad, int pad_left, FirTaps taps) {
+    const int Tout = ratio * T;
+    const int tb = (Tout + 255) / 256;
+    const size_t row = blockIdx.x / tb;
+    const int n = (int)(blockIdx.x - row * tb) * 256 + threadIdx.x;
+    if (n >= Tout) return;
+    const float* xr = x + row * T;
+    const int j = n + pad_left;
+    float acc = 0.f;
+    for (int m = j / ratio; m >= 0 && j - m * ratio < K; --m) {
+        if (m >= T + 2 * pad) continue;
+        int t = m - pad;
+        t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+        acc = fmaf(xr[t], taps.f[j - m * ratio], acc);
+    }
+    y[row * Tout + n] = (float)ratio * acc;
+}
+
+// y[t] = sum_j f[j] * xp[t*stride + j],  xp = x padded by (pad_left, pad_right)            (filter.py:95-99)
+//   mode 0 replicate, 1 zeros ("constant"), 2 reflect; without padding pad_left = pad_right = 0.
+__global__ __launch_bounds__(256) void fir_filter_kernel(const float* __restrict__ x, float* __restrict__ y, int T,
+                                                         int Tout, int K, int stride, int pad_left, int mode,
+                                                         FirTaps taps) {
+    const int tb = (Tout + 255) / 256;
+    const size_t row = blockIdx.x / tb;
+    const int t = (int)(blockIdx.x - row * tb) * 256 + threadIdx.x;
+    if (t >= Tout) return;
+    const float* xr = x + row * T;
+    float acc = 0.f;
+    for (int j = 0; j < K; ++j) {
+        int i = t * stride + j - pad_left;
+        float v;
+        if (i >= 0 && i < T) v = xr[i];
+        else if (mode == 1) v = 0.f;
+        else if (mode == 2) v = xr[i < 0 ? -i : 2 * (T - 1) - i];
+        else v = xr[i < 0 ? 0 : T - 1];
+        acc = fmaf(taps.f[j], v, acc);
+    }
+    y[row * Tout + t] = acc;
+}
+
+hipError_t launch_fir_up(const float* x, float* y, int rows, int T, const float* taps_host, int K, int ratio, int pad,
+                         int pad_left, hipStream_t stream) {
+    FirTaps taps;
+    for (int i = 0; i < AMP_FIR_MAX_TAPS; ++i) taps.f[i] = i < K ? taps_host[i] : 0.f;
+    const size_t blocks = (size_t)rows * (((size_t)ratio * T + 255) / 256);
+    if (blocks > 0x7fffffffu) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fir_up_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, y, T, K, ratio, pad, pad_left, taps);
+    return hipGetLastError();
+}
+
+hipError_t launch_fir_filter(const float* x, float* y, int rows, int T, int Tout, const float* taps_host, int K,
+                             int stride, int pad_left, int mode, hipStream_t stream) {
+    FirTaps taps;
+    for (int i = 0; i < AMP_FIR_MAX_TAPS; ++i) taps.f[i] = i < K ? taps_host[i] : 0.f;
+    const size_t blocks = (size_t)rows * (((size_t)Tout + 255) / 256);
+    if (blocks > 0x7fffffffu) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fir_filter_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, y, T, Tout, K, stride,
+                       pad_left, mode, taps);
+    return hipGetLastError();
+}
+
+// Snake / SnakeBeta on their own (snake.py:51-61, 110-122): y = x + sin(a x)^2 / (b + 1e-9), a = alpha or
+// exp(alpha), b = beta (SnakeBeta) or a.  One pass, rows of [B*C, T].
+__global__ __launch_bounds__(256) void snake_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                    const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                    int logscale, int C, int T) {
+    const int tb = (T + 1023) / 1024;
+    const size_t row = blockIdx.x / tb;
+    const int c = (int)(row % C);
+    float a = alpha[c], b = beta ? beta[c] : a;
+    if (logscale) { a = expf(a); b = beta ? expf(b) : a; }
+    const float invb = 1.0f / (b + 0.000000001f);
+    const int tbeg = (int)(blockIdx.x - row * tb) * 1024 + threadIdx.x;
+    const int tend = min(T, (int)(blockIdx.x - row * tb) * 1024 + 1024);
+    const float* xr = x + row * T;
+    float* yr = y + row * T;
+    for (int t = tbeg; t < tend; t += 256) {
+        const float v = xr[t];
+        yr[t] = fmaf(invb, snake_sin2(v * a), v);
+    }
+}
+
+hipError_t launch_snake(const float* x, float* y, int B, int C, int T, const float* alpha, const float* beta,
+                        int logscale, hipStream_t stream) {
+    const size_t blocks = (size_t)B * C * ((T + 1023) / 1024);
+    if (blocks > 0x7fffffffu) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(snake_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, y, alpha, beta, logscale, C, T);
+    return hipGetLastError();
+}
+
 // APNet head (apnet.py:379-383): pha = atan2(I, R); rea = exp(logamp) * cos(pha); imag = exp(logamp) * sin(pha)
 __global__ __launch_bounds__(256) void apnet_polar_kernel(const float* __restrict__ logamp, const float* __restrict__ R,
                                                           const float* __restrict__ I, size_t n, float* __restrict__ pha,

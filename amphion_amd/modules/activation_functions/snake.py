@@ -1,12 +1,32 @@
-"""Snake / SnakeBeta parameter modules (modules/activation_functions/snake.py:13-122).
-
-Same constructor arguments, parameter names and init as the reference.  ``forward`` runs the
-element-wise formula on whatever device the tensor is on using torch ops -- it is NOT the product
-path: inside BigVGAN the activation always runs fused into the anti-aliased Activation1d HIP kernel.
+"""Snake / SnakeBeta (modules/activation_functions/snake.py:13-122): same constructor arguments, parameter
+names and init as the reference.  Inside BigVGAN the activation runs fused into the anti-aliased Activation1d HIP
+kernel; ``forward`` on its own is the element-wise HIP kernel ``amp_snake`` (ROCm tensors only, no CPU fallback).
 """
+import ctypes
+
 import torch
 from torch import nn
 from torch.nn import Parameter
+
+from amphion_amd import _lib
+
+
+def _snake_forward(mod, x):
+    x = _lib.require_device_tensor(x, type(mod).__name__ + " input")
+    B, C, T = x.shape
+    alpha = mod.alpha.detach().float().contiguous()
+    beta = mod.beta.detach().float().contiguous() if mod.has_beta else None
+    if alpha.device != x.device:
+        raise RuntimeError(f"{type(mod).__name__} parameters are on {alpha.device}, input on {x.device}")
+    if alpha.numel() != C:
+        raise ValueError(f"{type(mod).__name__}({alpha.numel()}) applied to {C} channels")
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().amp_snake(
+            ctypes.c_void_p(x.data_ptr()), B, C, T, ctypes.c_void_p(alpha.data_ptr()),
+            ctypes.c_void_p(beta.data_ptr()) if beta is not None else None, int(mod.alpha_logscale),
+            ctypes.c_void_p(y.data_ptr()), _lib.current_stream_ptr(x.device)))
+    return y
 
 
 class Snake(nn.Module):
@@ -22,6 +42,9 @@ class Snake(nn.Module):
         self.no_div_by_zero = 0.000000001
 
     has_beta = False
+
+    def forward(self, x):  # snake.py:51-61   x + sin^2(a x) / a
+        return _snake_forward(self, x)
 
 
 class SnakeBeta(nn.Module):
@@ -40,3 +63,6 @@ class SnakeBeta(nn.Module):
         self.no_div_by_zero = 0.000000001
 
     has_beta = True
+
+    def forward(self, x):  # snake.py:110-122   x + sin^2(a x) / b
+        return _snake_forward(self, x)

@@ -1,5 +1,6 @@
 """Anti-aliased activation (modules/anti_aliasing/act.py:12-36): up x2 -> Snake -> down x2, executed
-as ONE fused gfx950 kernel (amp_antialias_snake) instead of the reference's three tensor ops."""
+as ONE fused gfx950 kernel (amp_antialias_snake) instead of the reference's three tensor ops.  Any other ratio /
+kernel size (or an activation that is not Snake / SnakeBeta) runs as the three stand-alone HIP ops."""
 import ctypes
 
 import torch
@@ -14,8 +15,7 @@ class Activation1d(nn.Module):
     def __init__(self, activation, up_ratio: int = 2, down_ratio: int = 2, up_kernel_size: int = 12,
                  down_kernel_size: int = 12):
         super().__init__()
-        if (up_ratio, down_ratio, up_kernel_size, down_kernel_size) != (2, 2, 12, 12):
-            raise NotImplementedError("the HIP Activation1d kernel covers the reference's ratio-2 / 12-tap setup")
+        self._fused = (up_ratio, down_ratio, up_kernel_size, down_kernel_size) == (2, 2, 12, 12)
         self.up_ratio = up_ratio
         self.down_ratio = down_ratio
         self.act = activation
@@ -24,6 +24,8 @@ class Activation1d(nn.Module):
 
     def forward(self, x):  # x: [B, C, T]
         x = _lib.require_device_tensor(x, "Activation1d input")
+        if not (self._fused and hasattr(self.act, "alpha") and hasattr(self.act, "alpha_logscale")):
+            return self.downsample(self.act(self.upsample(x)))       # act.py:32-34 as three launches
         B, C, T = x.shape
         y = torch.empty_like(x)
         alpha = self.act.alpha.detach().float().contiguous()

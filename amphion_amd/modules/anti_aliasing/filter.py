@@ -1,9 +1,15 @@
-"""Kaiser-windowed sinc low-pass filter design (modules/anti_aliasing/filter.py:30-99): host-side
-filter construction only -- the filtering itself happens inside the fused Activation1d HIP kernel."""
+"""Kaiser-windowed sinc low-pass filter (modules/anti_aliasing/filter.py:30-99): host-side filter design, and
+LowPassFilter1d.forward on the depthwise FIR kernel ``amp_fir_filter`` (inside Activation1d the filtering is fused
+into ``amp_antialias_snake`` instead)."""
+import ctypes
 import math
 
 import torch
 import torch.nn as nn
+
+from amphion_amd import _lib
+
+_PAD_MODES = {"replicate": _lib.AMP_PAD_REPLICATE, "constant": _lib.AMP_PAD_ZEROS, "reflect": _lib.AMP_PAD_REFLECT}
 
 
 def kaiser_sinc_filter1d(cutoff, half_width, kernel_size):
@@ -31,7 +37,7 @@ def kaiser_sinc_filter1d(cutoff, half_width, kernel_size):
 
 
 class LowPassFilter1d(nn.Module):
-    """Buffer holder for filter.py:64-99 (key ``filter``)."""
+    """filter.py:64-99 (buffer key ``filter``)."""
 
     def __init__(self, cutoff=0.5, half_width=0.6, stride: int = 1, padding: bool = True,
                  padding_mode: str = "replicate", kernel_size: int = 12):
@@ -48,3 +54,19 @@ class LowPassFilter1d(nn.Module):
         self.padding = padding
         self.padding_mode = padding_mode
         self.register_buffer("filter", kaiser_sinc_filter1d(cutoff, half_width, kernel_size))
+
+    def forward(self, x):  # x: [B, C, T]      (filter.py:92-99)
+        x = _lib.require_device_tensor(x, "LowPassFilter1d input")
+        B, C, T = x.shape
+        if self.padding and self.padding_mode not in _PAD_MODES:
+            raise NotImplementedError(f"padding_mode {self.padding_mode!r}: the HIP filter pads by replicate, constant or reflect")
+        pl, pr = (self.pad_left, self.pad_right) if self.padding else (0, 0)
+        mode = _PAD_MODES[self.padding_mode] if self.padding else _lib.AMP_PAD_REPLICATE
+        t_out = (T + pl + pr - self.kernel_size) // self.stride + 1
+        y = torch.empty((B, C, max(t_out, 0)), dtype=torch.float32, device=x.device)
+        taps = self.filter.detach().reshape(-1).float().cpu().contiguous()
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().amp_fir_filter(
+                ctypes.c_void_p(x.data_ptr()), B, C, T, ctypes.c_void_p(taps.data_ptr()), taps.numel(), self.stride, pl, pr,
+                mode, ctypes.c_void_p(y.data_ptr()), _lib.current_stream_ptr(x.device)))
+        return y

@@ -175,6 +175,25 @@ int amp_conv_forward_mrf(const amp_conv* c, const float* x_dev, int B, int T, fl
 int amp_apnet_polar(const float* logamp_dev, const float* r_dev, const float* i_dev, size_t n, float* pha_dev,
                     float* rea_dev, float* imag_dev, void* stream);
 
+/* UpSample1d.forward (modules/anti_aliasing/resample.py:36-45) as a stand-alone op: replicate-pad by
+ * K/ratio - 1, depthwise ConvTranspose1d with the [K] filter at stride = ratio, x ratio, crop -> y [B, C, ratio*T].
+ * filt_host: K <= AMP_FIR_MAX_TAPS floats on the host (the module's `filter` buffer). */
+#define AMP_FIR_MAX_TAPS 64
+int amp_fir_upsample(const float* x_dev, int B, int C, int T, const float* filt_host, int K, int ratio, float* y_dev,
+                     void* stream);
+/* LowPassFilter1d.forward (modules/anti_aliasing/filter.py:92-99; DownSample1d, resample.py:62-65, is this with
+ * stride = ratio): pad (pad_left, pad_right) in `pad_mode`, depthwise Conv1d with the [K] filter at `stride`
+ * -> y [B, C, (T + pad_left + pad_right - K) / stride + 1].  padding=False is pad_left = pad_right = 0. */
+typedef enum amp_pad_mode { AMP_PAD_REPLICATE = 0, AMP_PAD_ZEROS = 1, AMP_PAD_REFLECT = 2 } amp_pad_mode;
+int amp_fir_filter(const float* x_dev, int B, int C, int T, const float* filt_host, int K, int stride, int pad_left,
+                   int pad_right, int pad_mode, float* y_dev, void* stream);
+
+/* Snake.forward / SnakeBeta.forward as a stand-alone element-wise op (modules/activation_functions/snake.py:51-61,
+ * 110-122): y = x + sin(a x)^2 / (b + 1e-9) over [B, C, T]; alpha_dev / beta_dev: [C] on the device, beta_dev NULL
+ * for Snake (b = a); logscale: a = exp(alpha), b = exp(beta). */
+int amp_snake(const float* x_dev, int B, int C, int T, const float* alpha_dev, const float* beta_dev, int logscale,
+              float* y_dev, void* stream);
+
 /* fp32 waveform [B, L] (row stride wav_stride elements) -> signed 16-bit PCM [B, L] (row stride pcm_stride), on
  * the device, so the D2H copy and any gather move 2 bytes per sample instead of 4.  Replaces the host conversion
  * inside the reference's save_audio (utils/io.py:68-76 -> torchaudio.save(encoding="PCM_S", bits_per_sample=16);

@@ -195,6 +195,37 @@ def activation1d(x, alpha, beta=None, logscale=False, filt_up=None, filt_down=No
     return F.conv1d(y, fd, stride=ratio, groups=C)
 
 
+def upsample1d(x, ratio=2, kernel_size=None, filt=None):
+    """UpSample1d.forward modules/anti_aliasing/resample.py:17-45, any ratio / kernel size."""
+    ks = int(6 * ratio // 2) * 2 if kernel_size is None else kernel_size  # :20-22
+    C = x.shape[1]
+    if filt is None:
+        filt = kaiser_sinc_filter1d(0.5 / ratio, 0.6 / ratio, ks, x.dtype)
+    pad = ks // ratio - 1  # :24
+    pad_left = pad * ratio + (ks - ratio) // 2  # :25
+    pad_right = pad * ratio + (ks - ratio + 1) // 2  # :26-28
+    y = F.pad(x, (pad, pad), mode="replicate")  # :38
+    y = ratio * F.conv_transpose1d(y, filt.to(x.dtype).reshape(1, 1, ks).expand(C, -1, -1), stride=ratio, groups=C)
+    return y[..., pad_left:-pad_right]  # :42
+
+
+def lowpass1d(x, filt, stride=1, padding=True, padding_mode="replicate"):
+    """LowPassFilter1d.forward modules/anti_aliasing/filter.py:92-99 with a given [K] filter."""
+    ks = filt.numel()
+    C = x.shape[1]
+    if padding:  # pad_left = k//2 - int(even), pad_right = k//2   (:78-80)
+        x = F.pad(x, (ks // 2 - int(ks % 2 == 0), ks // 2), mode=padding_mode)
+    return F.conv1d(x, filt.to(x.dtype).reshape(1, 1, ks).expand(C, -1, -1), stride=stride, groups=C)
+
+
+def downsample1d(x, ratio=2, kernel_size=None, filt=None):
+    """DownSample1d.forward resample.py:48-65: a LowPassFilter1d(0.5/ratio, 0.6/ratio) with stride = ratio."""
+    ks = int(6 * ratio // 2) * 2 if kernel_size is None else kernel_size
+    if filt is None:
+        filt = kaiser_sinc_filter1d(0.5 / ratio, 0.6 / ratio, ks, x.dtype)
+    return lowpass1d(x, filt.reshape(-1), stride=ratio)
+
+
 def bigvgan_forward(sd, hp, mel, dtype=torch.float32):
     """BigVGAN.forward bigvgan.py:313-331."""
     x = torch.as_tensor(mel).to(dtype)
