@@ -378,17 +378,22 @@ static hipError_t launch_one_h(const ConvArgs& a, hipStream_t stream) {
 
 hipError_t AMP_CAT(launch_conv_h_kt, AMP_KT)(const ConvPlan& p, const ConvArgs& a, hipStream_t stream) {
     constexpr int KT = AMP_KT;
-    // every variant keeps 4 accumulator tiles (64 VGPRs) per wave: the register budget goes to the
-    // per-chunk A-fragment set (8 * KT VGPRs) instead, see the kernel
-    if (p.HALO == 64) {
-        if (p.WM == 4) return launch_one_h<KT, 4, 1, 4, 64>(a, stream);
-        if (p.WM == 2) return launch_one_h<KT, 2, 2, 4, 64>(a, stream);
-        return launch_one_h<KT, 1, 4, 4, 64>(a, stream);
-    } else {
-        if (p.WM == 4) return launch_one_h<KT, 4, 1, 4, 128>(a, stream);
-        if (p.WM == 2) return launch_one_h<KT, 2, 2, 4, 128>(a, stream);
-        return launch_one_h<KT, 1, 4, 4, 128>(a, stream);
+    // 4 accumulator tiles (64 VGPRs) per wave: the register budget goes to the per-chunk A-fragment set
+    // (8 * KT VGPRs) instead, see the kernel.  NI = 2 halves the tile width for grids that would leave most of
+    // the 256 CUs idle (single utterances, frame-rate convs): twice the workgroups, half the work in each.
+#define AMP_LAUNCH_NI(NI_)                                                          \
+    if (p.HALO == 64) {                                                             \
+        if (p.WM == 4) return launch_one_h<KT, 4, 1, NI_, 64>(a, stream);           \
+        if (p.WM == 2) return launch_one_h<KT, 2, 2, NI_, 64>(a, stream);           \
+        return launch_one_h<KT, 1, 4, NI_, 64>(a, stream);                          \
+    } else {                                                                        \
+        if (p.WM == 4) return launch_one_h<KT, 4, 1, NI_, 128>(a, stream);          \
+        if (p.WM == 2) return launch_one_h<KT, 2, 2, NI_, 128>(a, stream);          \
+        return launch_one_h<KT, 1, 4, NI_, 128>(a, stream);                         \
     }
+    if (p.NI == 2) { AMP_LAUNCH_NI(2) }
+    AMP_LAUNCH_NI(4)
+#undef AMP_LAUNCH_NI
 }
 
 }  // namespace amp

@@ -134,6 +134,16 @@ static bool fuse_pairs_enabled() {
     return g_fuse_pairs != 0;
 }
 
+// Half-width conv tiles (NI = 2) for launches that would leave most CUs idle (a single utterance): conv_run()
+// picks them when the full-width grid has fewer workgroups than kSmallGridWorkgroups (the chip holds 2 per CU).
+// One 3-s utterance 1.56 -> 1.24 ms, one 10-s utterance 2.80 -> 2.38 ms; the frame-rate convs of VITS (short
+// contractions) neither gain nor lose (profiles/r1_exp_small_tiles.txt).  AMP_SMALL_TILES=0 switches them off.
+constexpr long long kSmallGridWorkgroups = 384;
+static bool small_tiles_enabled() {
+    static const bool on = [] { const char* e = getenv("AMP_SMALL_TILES"); return !(e && !strcmp(e, "0")); }();
+    return on;
+}
+
 hipError_t launch_conv_f16x3(const ConvPlan& p, const ConvArgs& a, hipStream_t s) {
     switch (p.KT) {
         case 1: return launch_conv_h_kt1(p, a, s);
@@ -282,7 +292,13 @@ static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope
     a.x = x; a.wp = c->wp_dev; a.bias = c->bias_dev; a.res = res; a.y = y;
     a.B = B; a.Cin = c->cin; a.Tin = T; a.xbs = xbs > 0 ? xbs : (long long)c->cin * T; a.nchunks = c->nchunks; a.M = c->M;
     a.Tq = c->transposed ? T + c->ntaps - 1 : Tout;
-    const int NT = c->plan.NT();
+    ConvPlan plan = c->plan;
+    if (c->precision == PREC_F16X3 && small_tiles_enabled()) {
+        // a grid that leaves most CUs idle (a single utterance): half-width tiles, twice the workgroups
+        const long long wgs = (long long)B * ((a.Tq + plan.NT() - 1) / plan.NT()) * ((c->M + plan.Mgroup() - 1) / plan.Mgroup());
+        if (wgs < kSmallGridWorkgroups) plan.NI = 2;
+    }
+    const int NT = plan.NT();
     a.tiles_per_item = (a.Tq + NT - 1) / NT;
     a.off0 = c->off0; a.dstep = c->dstep; a.halo_left = c->halo_left;
     a.wd = NT + c->halo_left + c->halo_right;
@@ -296,11 +312,11 @@ static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope
     }
     if (c->precision == PREC_F32) {
         a.acc_scale = a.inv_scale = 1.f;
-        AMP_HIP(launch_conv(c->plan, a, stream));
+        AMP_HIP(launch_conv(plan, a, stream));
     } else {
         a.acc_scale = 16.f * c->wscale;
         a.inv_scale = 1.f / a.acc_scale;
-        AMP_HIP(launch_conv_f16x3(c->plan, a, stream));
+        AMP_HIP(launch_conv_f16x3(plan, a, stream));
     }
     return AMP_OK;
 }
