@@ -3,18 +3,19 @@
     PYTHONPATH=<repo>/amphion_amd/integration:<repo>:<Amphion checkout> \
         python <Amphion>/bins/vocoder/inference.py ...
 
-``sitecustomize.py`` in this directory calls ``install()``, which registers a one-shot
-``sys.meta_path`` finder for ``models.vocoders.vocoder_inference``: right after the reference
-module body has executed, its ``_vocoders`` / ``_vocoder_forward_funcs`` / ``_vocoder_infer_funcs``
-entries for ``hifigan`` and ``bigvgan`` are replaced (the dicts are read at call time,
-vocoder_inference.py:245,346,507).  ``models`` is a regular package, so it cannot be shadowed --
-it is patched.
+``sitecustomize.py`` in this directory calls ``install()``, which registers a ``sys.meta_path`` finder for
+``models.vocoders.vocoder_inference`` and for ``models.codec.codec_inference`` (which carries its own copy of the
+same three registries, codec_inference.py:39-75): right after a reference module body has executed, its
+``_vocoders`` / ``_vocoder_forward_funcs`` / ``_vocoder_infer_funcs`` entries for the GAN generators built here are
+replaced (the dicts are read at call time, vocoder_inference.py:245,346,507).  ``models`` is a regular package, so
+it cannot be shadowed -- it is patched.
 """
 import importlib.abc
 import importlib.util
 import sys
 
-TARGET = "models.vocoders.vocoder_inference"
+TARGETS = ("models.vocoders.vocoder_inference", "models.codec.codec_inference")
+TARGET = TARGETS[0]
 
 
 class _PatchLoader(importlib.abc.Loader):
@@ -30,14 +31,29 @@ class _PatchLoader(importlib.abc.Loader):
 
         install_into_reference(module)
         module.__amphion_amd_patched__ = True
+        for other in TARGETS:       # a target imported while this finder was busy resolving another one
+            m = sys.modules.get(other)
+            if m is not None and hasattr(m, "_vocoders") and not getattr(m, "__amphion_amd_patched__", False):
+                install_into_reference(m)
+                m.__amphion_amd_patched__ = True
 
 
 class _Finder(importlib.abc.MetaPathFinder):
+    def __init__(self):
+        self._pending = set(TARGETS)
+        self._busy = False
+
     def find_spec(self, fullname, path, target=None):
-        if fullname != TARGET:
+        if self._busy or fullname not in self._pending:
             return None
-        sys.meta_path.remove(self)  # one shot; avoids recursion in find_spec below
-        spec = importlib.util.find_spec(fullname)
+        self._pending.discard(fullname)       # one shot per target
+        self._busy = True                     # find_spec below walks sys.meta_path again
+        try:
+            spec = importlib.util.find_spec(fullname)
+        finally:
+            self._busy = False
+        if not self._pending:
+            sys.meta_path.remove(self)
         if spec is None or spec.loader is None:
             return None
         spec.loader = _PatchLoader(spec.loader)
@@ -45,10 +61,14 @@ class _Finder(importlib.abc.MetaPathFinder):
 
 
 def install():
-    if TARGET in sys.modules:
+    from_loaded = [t for t in TARGETS if t in sys.modules]
+    if from_loaded:
         from amphion_amd.models.vocoders.vocoder_inference import install_into_reference
 
-        install_into_reference(sys.modules[TARGET])
-        return
-    if not any(isinstance(f, _Finder) for f in sys.meta_path):
-        sys.meta_path.insert(0, _Finder())
+        for t in from_loaded:
+            install_into_reference(sys.modules[t])
+            sys.modules[t].__amphion_amd_patched__ = True
+    if len(from_loaded) < len(TARGETS) and not any(isinstance(f, _Finder) for f in sys.meta_path):
+        f = _Finder()
+        f._pending -= set(from_loaded)
+        sys.meta_path.insert(0, f)

@@ -77,3 +77,26 @@ def test_hook_patches_reference_registries():
     env["PYTHONPATH"] = os.pathsep.join([os.path.join(ROOT, "amphion_amd", "integration"), os.path.join(ROOT, "tests", "shims"), ROOT, REF])
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=REF, timeout=300)
     assert "PATCHED True" in r.stdout, r.stdout + r.stderr
+
+
+def test_hook_patches_codec_registries_too():
+    # models/codec/codec_inference.py:39-75 holds its own copy of the three registries
+    code = (
+        "import amphion_amd.integration as ig;"
+        "import types, sys;"
+        "m = types.ModuleType('models.codec.codec_inference');"
+        "m._vocoders = {'hifigan': None, 'diffwave': 'ref'}; m._vocoder_forward_funcs = {}; m._vocoder_infer_funcs = {};"
+        "sys.modules['models.codec.codec_inference'] = m;"
+        "ig.install();"
+        "assert m._vocoders['hifigan'].__module__.startswith('amphion_amd') and m._vocoders['diffwave'] == 'ref';"
+        "assert m._vocoder_infer_funcs['bigvgan'].__module__.startswith('amphion_amd');"
+        "assert any(isinstance(f, ig._Finder) for f in sys.meta_path);"          # still waiting for the vocoder module
+        "import models.vocoders.vocoder_inference as v;"
+        "assert v.__amphion_amd_patched__ and not any(isinstance(f, ig._Finder) for f in sys.meta_path);"
+        "print('BOTH PATCHED')"
+    )
+    env = dict(os.environ)
+    env["WORK_DIR"] = REF
+    env["PYTHONPATH"] = os.pathsep.join([os.path.join(ROOT, "tests", "shims"), ROOT, REF])
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=REF, timeout=300)
+    assert "BOTH PATCHED" in r.stdout, r.stdout + r.stderr
