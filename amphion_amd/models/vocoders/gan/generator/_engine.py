@@ -8,6 +8,7 @@ inside the handle is rebuilt lazily whenever a parameter changes.
 from __future__ import annotations
 
 import ctypes
+import warnings
 import weakref
 
 import torch
@@ -190,6 +191,16 @@ class HipGenerator(nn.Module):
         return h
 
     def _amp_forward(self, x, g=None, lengths=None):
+        # Inference only: the HIP kernels have no backward.  A gradient asked for THROUGH the generator cannot be
+        # honoured -> fail; a module left in training mode merely gets told once.
+        if torch.is_grad_enabled() and isinstance(x, torch.Tensor):
+            if x.requires_grad:
+                raise RuntimeError("amphion_amd generators are inference-only (no backward through the HIP kernels): "
+                                   "detach the input or call under torch.no_grad()")
+            if self.training and not getattr(self, "_amp_warned_training", False):
+                self._amp_warned_training = True
+                warnings.warn("amphion_amd generator called in training mode with autograd on: the output carries no "
+                              "gradient (inference-only kernels); call .eval() / torch.no_grad()", RuntimeWarning, stacklevel=3)
         x = _lib.require_device_tensor(x, "generator input")
         if x.dim() != 3:
             raise ValueError(f"expected [B, C, T] input, got {tuple(x.shape)}")

@@ -189,3 +189,30 @@ def test_load_audio_torch_and_save_feature(tmp_path):
     assert np.load(tmp_path / "out" / "mels" / "uid0.npy").shape == (80, 7)
     save_feature(str(tmp_path / "out"), "mels", "uid0", np.ones((80, 7), np.float32), overrides=False)
     assert np.load(tmp_path / "out" / "mels" / "uid0.npy").sum() == 0
+
+
+def test_generator_is_inference_only():
+    # no backward through the HIP kernels: an input that asks for a gradient is refused, a module left in
+    # training mode is warned once; a CPU tensor is refused either way (no fallback)
+    import warnings
+    from types import SimpleNamespace as NS
+
+    import pytest
+    import torch
+
+    from amphion_amd.models.vocoders.gan.generator.hifigan import HiFiGAN
+
+    hp = dict(resblock="1", upsample_rates=[2, 2], upsample_kernel_sizes=[4, 4], upsample_initial_channel=32,
+              resblock_kernel_sizes=[3], resblock_dilation_sizes=[[1, 3, 5]])
+    m = HiFiGAN(NS(preprocess=NS(n_mel=8), model=NS(hifigan=NS(**hp))))
+    with pytest.raises(RuntimeError, match="inference-only"):
+        m(torch.zeros(1, 8, 4, requires_grad=True))
+    with pytest.warns(RuntimeWarning, match="training mode"), pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 8, 4))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                      # told once only; and never in eval / no_grad
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            m(torch.zeros(1, 8, 4))
+        m2 = HiFiGAN(NS(preprocess=NS(n_mel=8), model=NS(hifigan=NS(**hp)))).eval()
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            m2(torch.zeros(1, 8, 4))
