@@ -26,8 +26,13 @@ def shard_batch(mels: torch.Tensor, world_size: int = None, rank: int = None) ->
     return mels[s:e]
 
 
+# element types RCCL / gloo move natively; anything else (16-bit PCM) travels as raw bytes -- a gather only copies
+_WIRE_DTYPES = {torch.float32, torch.float64, torch.float16, torch.bfloat16, torch.int32, torch.int64, torch.int8, torch.uint8}
+
+
 def gather_audio(local: torch.Tensor, total_items: int, dst: int = 0, group=None, async_op: bool = False):
-    """Gather per-rank [b_r, L] audio on ``dst`` in rank order -> [total_items, L] (None elsewhere).
+    """Gather per-rank [b_r, L] audio (fp32, or int16 PCM from ``utils.io.wav_to_pcm16``: 2 B per sample on the
+    links) on ``dst`` in rank order -> [total_items, L] (None elsewhere).
 
     Shards may be ragged by one item: every rank pads to the largest shard so the collective is a
     fixed-size gather (each peer sends over its own xGMI link to the root; no ring, no reduction).
@@ -35,6 +40,13 @@ def gather_audio(local: torch.Tensor, total_items: int, dst: int = 0, group=None
     ``async_op=True`` (equal shards only) returns ``(result, work)`` without making the compute stream wait:
     the transfer then overlaps the vocoding of the NEXT batch; call ``work.wait()`` before reading ``result``.
     """
+    if local.dtype not in _WIRE_DTYPES:
+        if local.dim() < 2:
+            raise ValueError("gather_audio expects [items, samples] rows")
+        got = gather_audio(local.contiguous().view(torch.uint8), total_items, dst=dst, group=group, async_op=async_op)
+        res, work = got if async_op else (got, None)
+        res = None if res is None else res.view(local.dtype)
+        return (res, work) if async_op else res
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     counts = [shard_bounds(total_items, world, r)[1] - shard_bounds(total_items, world, r)[0] for r in range(world)]

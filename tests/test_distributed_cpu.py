@@ -74,6 +74,13 @@ def _worker(rank, world, port, n_items, q):
                     assert torch.equal(res, want)
                 else:
                     assert res is None
+        # 16-bit PCM rows (amphion_amd.utils.io.wav_to_pcm16 output) travel through the same gather: 2 B / sample
+        pcm = torch.arange((e - s) * 5, dtype=torch.int16).reshape(e - s, 5) + 1000 * rank
+        gp = gather_audio(pcm, n_items)
+        if rank == 0:
+            want = torch.cat([torch.arange((shard_bounds(n_items, world, r)[1] - shard_bounds(n_items, world, r)[0]) * 5,
+                                           dtype=torch.int16).reshape(-1, 5) + 1000 * r for r in range(world)])
+            assert gp.dtype == torch.int16 and torch.equal(gp, want)
     finally:
         dist.destroy_process_group()
 
