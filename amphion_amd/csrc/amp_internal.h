@@ -70,6 +70,32 @@ struct PairArgs {
     int len_mul;
 };
 
+// Arguments of the EXPERIMENTAL fused AMPBlock1 pair (amp_pair_f16x3.hip, off unless AMP_FUSE_AMP=1):
+//   y = res + c2(a2(c1(xin)))   [mode 1: y += ..., mode 2: y = (y + ...) / div],  xin = a1(x) computed by act1d
+struct AmpPairArgs {
+    const float* xin;          // [B, C, T] conv1 input (already activated)
+    const float* res;          // [B, C, T] residual (the block's running x)
+    float* y;                  // [B, C, T] output; must not alias xin
+    const void* wp1;           // conv1 (kernel k, dilation dil): packed f16x3 A fragments
+    const float* bias1;
+    const void* wp2;           // conv2 (kernel k, dilation 1)
+    const float* bias2;
+    const float* act_a;        // a2: per-channel alpha (exp'ed when logscale) ...
+    const float* act_invb;     // ... and 1 / (beta + 1e-9)
+    float fu2[12];             // up-sampling taps x 2 (UpSample1d's gain folded in)
+    float fd[12];              // down-sampling taps
+    int B, C, T;
+    int tiles_per_item;        // ceil(T / NT)
+    int dil;
+    float sc1, isc1, sc2, isc2;
+    int mode;
+    float div;
+    const int* lens;
+    int len_mul;
+};
+int amp_pair_tile(int k, int C, int dil);
+hipError_t launch_amp_pair(int k, const AmpPairArgs& a, hipStream_t stream);
+
 struct ConvPlan {
     int KT;      // taps compiled into the kernel (1,2,3,5,7,11)
     int WM, WN;  // waves along M / N (WM*WN == 4)

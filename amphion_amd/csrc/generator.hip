@@ -124,6 +124,42 @@ hipError_t launch_pair(int k, const PairArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
+int amp_pair_tile_kt3(int, int);
+int amp_pair_tile_kt5(int, int);
+int amp_pair_tile_kt7(int, int);
+int amp_pair_tile_kt11(int, int);
+hipError_t launch_amp_pair_kt3(const AmpPairArgs&, hipStream_t);
+hipError_t launch_amp_pair_kt5(const AmpPairArgs&, hipStream_t);
+hipError_t launch_amp_pair_kt7(const AmpPairArgs&, hipStream_t);
+hipError_t launch_amp_pair_kt11(const AmpPairArgs&, hipStream_t);
+
+int amp_pair_tile(int k, int C, int dil) {
+    switch (k) {
+        case 3: return amp_pair_tile_kt3(C, dil);
+        case 5: return amp_pair_tile_kt5(C, dil);
+        case 7: return amp_pair_tile_kt7(C, dil);
+        case 11: return amp_pair_tile_kt11(C, dil);
+    }
+    return 0;
+}
+
+hipError_t launch_amp_pair(int k, const AmpPairArgs& a, hipStream_t s) {
+    switch (k) {
+        case 3: return launch_amp_pair_kt3(a, s);
+        case 5: return launch_amp_pair_kt5(a, s);
+        case 7: return launch_amp_pair_kt7(a, s);
+        case 11: return launch_amp_pair_kt11(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// AMP_FUSE_AMP=1 runs BigVGAN's AMPBlock1 pairs (c1 -> a2 -> c2 + x) in the EXPERIMENTAL fused kernel of
+// amp_pair_f16x3.hip.  Off by default: that kernel has not run on hardware yet.
+static bool fuse_amp_enabled() {
+    static const bool on = [] { const char* e = getenv("AMP_FUSE_AMP"); return e && !strcmp(e, "1"); }();
+    return on;
+}
+
 // AMP_FUSE_PAIRS=0 runs every ResBlock pair as two conv launches (A/B switch for the fused kernel).
 static int g_fuse_pairs = -1;
 static bool fuse_pairs_enabled() {
@@ -353,6 +389,39 @@ static int pair_run(const amp_conv* c1, const amp_conv* c2, const float* x, int 
     return AMP_OK;
 }
 
+// EXPERIMENTAL fused AMPBlock1 pair (amp_pair_f16x3.hip): y = res + c2(a2(c1(xin))), xin = a1(x) from act1d.
+static bool amp_pair_supported(const amp_conv* c1, const amp_conv* c2) {
+    if (!fuse_amp_enabled() || !fuse_pairs_enabled()) return false;
+    if (c1->precision != PREC_F16X3 || c2->precision != PREC_F16X3) return false;
+    if (c1->pad_reflect || c2->pad_reflect || c1->tanh_out || c2->tanh_out) return false;
+    if (c1->transposed || c2->transposed || c1->cin != c1->cout || c2->cin != c2->cout || c1->cin != c2->cin) return false;
+    if (c1->k != c2->k || c2->dilation != 1 || c1->k != c1->KT) return false;
+    if (c1->padding != (c1->k - 1) / 2 * c1->dilation || c2->padding != (c2->k - 1) / 2) return false;
+    if (!c1->bias_dev || !c2->bias_dev) return false;
+    return amp_pair_tile(c1->k, c1->cin, c1->dilation) > 0;
+}
+
+static int amp_pair_run(const amp_conv* c1, const amp_conv* c2, const float* xin, const float* res, const float* act_a,
+                        const float* act_invb, const float* fu_host, const float* fd_host, int B, int T, float* y,
+                        int mode, float div, hipStream_t stream, const int* lens, int len_mul) {
+    if (xin == y) { set_error("amp_pair_run: xin and y must not alias"); return AMP_ERR_INVALID; }
+    AmpPairArgs a{};
+    a.xin = xin; a.res = res; a.y = y;
+    a.wp1 = c1->wp_dev; a.bias1 = c1->bias_dev; a.wp2 = c2->wp_dev; a.bias2 = c2->bias_dev;
+    a.act_a = act_a; a.act_invb = act_invb;
+    for (int i = 0; i < 12; ++i) { a.fu2[i] = 2.f * fu_host[i]; a.fd[i] = fd_host[i]; }   // x2: UpSample1d's gain (exact)
+    a.B = B; a.C = c1->cin; a.T = T;
+    const int NT = amp_pair_tile(c1->k, c1->cin, c1->dilation);
+    a.tiles_per_item = (T + NT - 1) / NT;
+    a.dil = c1->dilation;
+    a.sc1 = 16.f * c1->wscale; a.isc1 = 1.f / a.sc1;
+    a.sc2 = 16.f * c2->wscale; a.isc2 = 1.f / a.sc2;
+    a.mode = mode; a.div = div;
+    a.lens = lens; a.len_mul = len_mul;
+    AMP_HIP(launch_amp_pair(c1->k, a, stream));
+    return AMP_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // generator handle
 // ------------------------------------------------------------------------------------------------
@@ -367,6 +436,8 @@ struct ActParams {  // one Activation1d
     float* invb_dev = nullptr;  // 1 / (beta + 1e-9)
     float* fu_dev = nullptr;    // 12 taps
     float* fd_dev = nullptr;
+    float fu_host[12] = {};     // the same taps on the host (kernel arguments of the fused AMP pair)
+    float fd_host[12] = {};
 };
 
 struct ResBlock {
@@ -596,6 +667,7 @@ static int build_act(amp_gen* g, const std::string& p, int c, ActParams* out) {
     if ((rc = upload(g, ib.data(), c, &out->invb_dev)) != AMP_OK) return rc;
     if ((rc = upload(g, iu->second.data.data(), 12, &out->fu_dev)) != AMP_OK) return rc;
     if ((rc = upload(g, idn->second.data.data(), 12, &out->fd_dev)) != AMP_OK) return rc;
+    for (int i = 0; i < 12; ++i) { out->fu_host[i] = iu->second.data[i]; out->fd_host[i] = idn->second.data[i]; }
     return AMP_OK;
 }
 
@@ -850,6 +922,18 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
                         const ActParams& a1 = rb.acts[2 * p];
                         const ActParams& a2 = rb.acts[2 * p + 1];
                         AMP_HIP(launch_act1d(cur, ACT, B, C, t, a1.a_dev, a1.invb_dev, a1.fu_dev, a1.fd_dev, lens, lm, st));
+                        if (amp_pair_supported(rb.c1[p].get(), rb.c2[p].get())) {
+                            // EXPERIMENTAL (AMP_FUSE_AMP=1): c1 -> a2 -> c2 + x in one kernel, a2 at the LDS seam
+                            float* dst = last ? XS : (cur == R ? TMP : R);
+                            AMP_RC(amp_pair_run(rb.c1[p].get(), rb.c2[p].get(), ACT, cur, a2.a_dev, a2.invb_dev, a2.fu_host,
+                                                a2.fd_host, B, t, dst, last ? mode_last : 0, (float)nk, st, lens, lm));
+                            cur = dst;
+                            continue;
+                        }
+                        if (cur == TMP) {  // a previous pair was fused into TMP: keep the unfused ping-pong legal
+                            AMP_HIP(hipMemcpyAsync(R, TMP, (size_t)B * C * t * sizeof(float), hipMemcpyDeviceToDevice, st));
+                            cur = R;
+                        }
                         AMP_RC(conv_run(rb.c1[p].get(), ACT, B, t, 1.f, nullptr, 1.f, TMP, 0, 1.f, st, 0, lens, lm));
                         AMP_HIP(launch_act1d(TMP, ACT, B, C, t, a2.a_dev, a2.invb_dev, a2.fu_dev, a2.fd_dev, lens, lm, st));
                         if (!last) { AMP_RC(conv_run(rb.c2[p].get(), ACT, B, t, 1.f, cur, 1.f, R, 0, 1.f, st, 0, lens, lm)); cur = R; }
