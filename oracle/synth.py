@@ -174,6 +174,12 @@ def synth_tensor(key, shape, seed=1234, g_gain=1.0):
         return 0.05 * torch.randn(shape, generator=gen)
     if leaf in ("alpha", "beta"):
         return 0.3 * torch.randn(shape, generator=gen)
+    if leaf == "gamma":  # LayerNorm scale (modules/base/base_module.py:17)
+        return 1.0 + 0.2 * torch.randn(shape, generator=gen)
+    if leaf in ("m", "logs"):  # ElementwiseAffine (modules/flow/modules.py:328-329)
+        return 0.1 * torch.randn(shape, generator=gen)
+    if leaf in ("emb_rel_k", "emb_rel_v"):  # relative-position embeddings (modules/transformer/attentions.py:200-209)
+        return torch.randn(shape, generator=gen) * shape[-1] ** -0.5
     if leaf == "weight":
         fan_in = 1
         for d in shape[1:]:
