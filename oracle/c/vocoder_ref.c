@@ -139,3 +139,22 @@ void ref_logmel(const float* re, const float* im, int B, int bins, int F, const 
                 mel[((size_t)b * n_mel + m) * F + f] = logf(v > clip ? v : clip);
             }
 }
+
+/* fp32 -> signed 16-bit PCM as the reference writes wavs: save_audio utils/io.py:68-76 ->
+ * torchaudio.save(encoding="PCM_S", bits_per_sample=16).  torchaudio 2.0.2 sox_io (effects_chain.cpp,
+ * tensor_input_drain: double(x) * 2^31, clamp to int32, truncate) then libsox 14.4.2 SOX_SAMPLE_TO_SIGNED_16BIT
+ * (sox.h: saturate above INT32_MAX - 2^15, else add 2^15 and drop 16 bits).  Integer restatement in plain C;
+ * parity unpinned (neither library is installed), see oracle/pcm16.py. */
+#include <stdint.h>
+void ref_pcm16(const float* x, int16_t* y, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+        const double v = (double)x[i] * 2147483648.0;
+        int32_t d;
+        if (v != v) d = INT32_MIN;                 /* NaN: what x86's cvttsd2si yields for torch's undefined cast */
+        else if (v >= 2147483647.0) d = INT32_MAX;
+        else if (v <= -2147483648.0) d = INT32_MIN;
+        else d = (int32_t)v;                       /* C conversion truncates toward zero */
+        if (d > INT32_MAX - (1 << 15)) y[i] = 32767;
+        else y[i] = (int16_t)((((uint32_t)d ^ 0x80000000u) + (1u << 15)) >> 16 ^ 0x8000u);
+    }
+}

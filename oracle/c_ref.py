@@ -77,3 +77,11 @@ def logmel(re, im, basis, eps, clip):
     mel = np.empty((B, basis.shape[0], F), np.float32)
     lib().ref_logmel(_p(re), _p(im), B, bins, F, _p(basis), basis.shape[0], ctypes.c_float(eps), ctypes.c_float(clip), _p(mel))
     return mel
+
+
+def pcm16(x):
+    """ref_pcm16: fp32 -> int16 PCM (torchaudio 2.0.2 / libsox semantics), any shape."""
+    x = _f(x)
+    y = np.empty(x.shape, np.int16)
+    lib().ref_pcm16(_p(x), _p(y), ctypes.c_size_t(x.size))
+    return y

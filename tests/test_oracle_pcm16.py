@@ -51,3 +51,16 @@ def test_lens_zero_the_tail_and_nan():
     y = pcm16.float_to_pcm16(x, lens=[4, 0])
     assert y.tolist() == [[8192, 8192, 8192, 8192, 0, 0], [0] * 6]
     assert pcm16.float_to_pcm16(np.array([np.nan], dtype=np.float32))[0] == -32768
+
+
+def test_c_restatement_agrees_bit_for_bit():
+    # oracle/c/vocoder_ref.c: ref_pcm16 -- the same conversion written with C integer types
+    from oracle import c_ref
+
+    rng = np.random.default_rng(1)
+    x = (rng.random(300000, dtype=np.float32) * 2.4 - 1.2).astype(np.float32)
+    lsb = 2.0 ** -15
+    edge = np.array([0.0, 1.0, -1.0, 2.0, -2.0, np.inf, -np.inf, np.nan, 0.5 * lsb, -0.5 * lsb, 32766.5 * lsb, -32767.5 * lsb,
+                     -(0.5 + 2.0 ** -17) * lsb, 1.0 - 2.0 ** -24, 3e38, -3e38, 1e-30], dtype=np.float32)
+    for v in (x, edge, x.reshape(300, 1000)):
+        assert np.array_equal(c_ref.pcm16(v), pcm16.float_to_pcm16(v))
