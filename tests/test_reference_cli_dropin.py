@@ -100,3 +100,28 @@ def test_hook_patches_codec_registries_too():
     env["PYTHONPATH"] = os.pathsep.join([os.path.join(ROOT, "tests", "shims"), ROOT, REF])
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=REF, timeout=300)
     assert "BOTH PATCHED" in r.stdout, r.stdout + r.stderr
+
+
+def test_collator_matches_reference():
+    # models/vocoders/vocoder_dataset.py:229-264 against the mirror, on the same ragged batch
+    code = (
+        "import numpy as np, torch;"
+        "from models.vocoders.vocoder_dataset import VocoderCollator as Ref;"
+        "from amphion_amd.models.vocoders.vocoder_dataset import VocoderCollator as Ours, batch_to_generator_input;"
+        "rng = np.random.default_rng(0);"
+        "lens = [5, 3, 9, 1];"
+        "batch = [{'target_len': n, 'mel': rng.standard_normal((4, n)).astype(np.float32),"
+        "          'frame_pitch': rng.standard_normal(n).astype(np.float32),"
+        "          'audio': rng.standard_normal(n * 8).astype(np.float32)} for n in lens];"
+        "a, b = Ref(None)(batch), Ours(None)(batch);"
+        "assert list(a) == list(b), (list(a), list(b));"
+        "assert all(a[k].dtype == b[k].dtype and torch.equal(a[k], b[k]) for k in a);"
+        "mel, ln = batch_to_generator_input(b);"
+        "assert mel.shape == (4, 4, 9) and ln == lens and torch.equal(mel[1, :, :3], torch.from_numpy(batch[1]['mel']));"
+        "print('COLLATOR OK')"
+    )
+    env = dict(os.environ)
+    env["WORK_DIR"] = REF
+    env["PYTHONPATH"] = os.pathsep.join([os.path.join(ROOT, "tests", "shims"), ROOT, REF])
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=REF, timeout=300)
+    assert "COLLATOR OK" in r.stdout, r.stdout + r.stderr
