@@ -97,3 +97,100 @@ class SynthesizerTrnDecodePath(nn.Module):
         lens = hip_ops.lens_tensor(y_lengths, z_hat.device)
         o_hat = self.dec(hip_ops.sequence_mask_(z_hat.clone(), lens), g=g_tgt)
         return o_hat, y_mask, (z, z_p, z_hat)
+
+
+# ---- EXPERIMENTAL (not yet run on hardware): the text -> duration -> alignment front and SynthesizerTrn.infer ----------
+class TextEncoder(nn.Module):
+    """vits.py:28-67, same arguments and state_dict keys; ``forward(tokens, lengths) -> (x, m, logs, lens)``."""
+
+    def __init__(self, n_vocab, out_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout):
+        super().__init__()
+        from amphion_amd.modules.transformer import Encoder
+
+        self.n_vocab, self.out_channels, self.hidden_channels = n_vocab, out_channels, hidden_channels
+        self.filter_channels, self.n_heads, self.n_layers = filter_channels, n_heads, n_layers
+        self.kernel_size, self.p_dropout = kernel_size, p_dropout
+        self.emb = nn.Embedding(n_vocab, hidden_channels)
+        nn.init.normal_(self.emb.weight, 0.0, hidden_channels**-0.5)
+        self.encoder = Encoder(hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout)
+        self.proj = HipConv1d(hidden_channels, out_channels * 2, 1, weight_norm=False)
+
+    def forward(self, x, x_lengths):
+        w = self.emb.weight.detach()
+        if not w.is_cuda:
+            raise RuntimeError("TextEncoder parameters are on the CPU: the HIP path has no CPU fallback (move the model to 'cuda')")
+        tokens = torch.as_tensor(x).to(device=w.device, dtype=torch.int64).contiguous()
+        lens = hip_ops.lens_tensor(x_lengths, w.device)
+        h = hip_ops.embed_tokens(tokens, w.contiguous(), lens, self.hidden_channels**0.5)   # emb * sqrt(H), [B, H, T], masked
+        h = self.encoder(h, lens)
+        stats = hip_ops.sequence_mask_(self.proj(h), lens)
+        m, logs = torch.split(stats, self.out_channels, dim=1)
+        return h, m.contiguous(), logs.contiguous(), lens
+
+
+class SynthesizerTrn(nn.Module):
+    """Inference side of vits.py:155-379 under the reference's constructor signature and state_dict keys (enc_p, dec,
+    enc_q, flow, dp, emb_g): ``infer`` (:320-369) and ``voice_conversion`` (:371-379).  Training (``forward``) is out of
+    scope -- the kernels have no backward."""
+
+    def __init__(self, n_vocab, spec_channels, segment_size, inter_channels, hidden_channels, filter_channels, n_heads, n_layers,
+                 kernel_size, p_dropout, resblock, resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates,
+                 upsample_initial_channel, upsample_kernel_sizes, n_speakers=0, gin_channels=0, use_sdp=True, **kwargs):
+        super().__init__()
+        from amphion_amd.modules.duration_predictor.standard_duration_predictor import DurationPredictor
+        from amphion_amd.modules.duration_predictor.stochastic_duration_predictor import StochasticDurationPredictor
+
+        self.n_vocab, self.spec_channels, self.inter_channels, self.hidden_channels = n_vocab, spec_channels, inter_channels, hidden_channels
+        self.segment_size, self.n_speakers, self.gin_channels, self.use_sdp = segment_size, n_speakers, gin_channels, use_sdp
+        self.enc_p = TextEncoder(n_vocab, inter_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout)
+        self.dec = HiFiGAN_vits(inter_channels, resblock, resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates,
+                                upsample_initial_channel, upsample_kernel_sizes, gin_channels=gin_channels)
+        self.enc_q = PosteriorEncoder(spec_channels, inter_channels, hidden_channels, 5, 1, 16, gin_channels=gin_channels)
+        self.flow = ResidualCouplingBlock(inter_channels, hidden_channels, 5, 1, 4, gin_channels=gin_channels)
+        if use_sdp:
+            self.dp = StochasticDurationPredictor(hidden_channels, 192, 3, 0.5, 4, gin_channels=gin_channels)
+        else:
+            self.dp = DurationPredictor(hidden_channels, 256, 3, 0.5, gin_channels=gin_channels)
+        if n_speakers >= 1:
+            self.emb_g = nn.Embedding(n_speakers, gin_channels)
+
+    def forward(self, data):
+        raise NotImplementedError("SynthesizerTrn.forward is the training step; this package is inference-only")
+
+    def infer(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1, noise_scale_w=1.0, max_len=None, noise_dp=None, noise_z=None):
+        """vits.py:320-369.  ``noise_dp`` [B, 2, T_text] / ``noise_z`` [B, inter, T_frames] replace the reference's two
+        ``torch.randn`` draws when given (pinned tests).  One host sync: the frame count max(y_lengths) sizes the tensors,
+        as ``sequence_mask(y_lengths, None)`` does in the reference (:344)."""
+        xe, m_p, logs_p, lens = self.enc_p(x, x_lengths)
+        dev = xe.device
+        g = None
+        if self.n_speakers > 0:
+            g = self.emb_g(torch.as_tensor(sid).to(dev).squeeze(-1)).unsqueeze(-1).detach().contiguous()   # [B, gin, 1]: a row lookup
+        if self.use_sdp:
+            logw = self.dp(xe, lens, g=g, reverse=True, noise_scale=noise_scale_w, noise=noise_dp)
+        else:
+            logw = self.dp(xe, lens, g=g)
+        w_ceil, cum, y_lengths = hip_ops.durations(logw, lens, length_scale)
+        t_y = int(y_lengths.max().item())
+        m_e, attn = hip_ops.expand_path(m_p, cum, lens, y_lengths, t_y, want_attn=True)
+        logs_e, _ = hip_ops.expand_path(logs_p, cum, lens, y_lengths, t_y)
+        if noise_z is None:
+            noise_z = torch.randn_like(m_e)
+        z_p = hip_ops.gauss_sample(m_e, logs_e, _lib.require_device_tensor(noise_z, "noise_z"), noise_scale)
+        z = self.flow(z_p, y_lengths, g=g, reverse=True)
+        zm = hip_ops.sequence_mask_(z.clone(), y_lengths)
+        o = self.dec(zm[:, :, :max_len].contiguous() if max_len is not None else zm, g=g)
+        y_mask = (torch.arange(t_y, device=dev).unsqueeze(0) < y_lengths.unsqueeze(1)).unsqueeze(1).to(z.dtype)
+        return {"y_hat": o, "attn": attn, "mask": y_mask, "z": z, "z_p": z_p, "m_p": m_e, "logs_p": logs_e}
+
+    def voice_conversion(self, y, y_lengths, sid_src, sid_tgt):
+        assert self.n_speakers > 0, "n_speakers have to be larger than 0."
+        dev = next(self.parameters()).device
+        g_src = self.emb_g(torch.as_tensor(sid_src).to(dev)).unsqueeze(-1).detach().contiguous()
+        g_tgt = self.emb_g(torch.as_tensor(sid_tgt).to(dev)).unsqueeze(-1).detach().contiguous()
+        z, m_q, logs_q, y_mask = self.enc_q(y, y_lengths, g=g_src)
+        z_p = self.flow(z, y_lengths, g=g_src)
+        z_hat = self.flow(z_p, y_lengths, g=g_tgt, reverse=True)
+        lens = hip_ops.lens_tensor(y_lengths, z_hat.device)
+        o_hat = self.dec(hip_ops.sequence_mask_(z_hat.clone(), lens), g=g_tgt)
+        return o_hat, y_mask, (z, z_p, z_hat)

@@ -118,3 +118,97 @@ class ResidualCouplingLayer(nn.Module):
         if not reverse:
             return x, torch.zeros(B, dtype=x.dtype, device=x.device)  # logdet = sum(logs) = 0 (mean only)
         return x
+
+
+# ---- EXPERIMENTAL (not yet run on hardware): the pieces of the stochastic duration predictor ---------------------------
+class DepthwiseConv1d(nn.Module):
+    """Parameters of nn.Conv1d(C, C, K, groups=C, dilation=d, padding=(K*d - d)//2) under torch's key names; forward =
+    ``amp_dwconv`` on x * mask."""
+
+    def __init__(self, channels, kernel_size, dilation):
+        super().__init__()
+        ref = nn.Conv1d(channels, channels, kernel_size, groups=channels, dilation=dilation, padding=(kernel_size * dilation - dilation) // 2)
+        self.weight = nn.Parameter(ref.weight.data.clone())   # [C, 1, K]
+        self.bias = nn.Parameter(ref.bias.data.clone())
+        self.dilation = dilation
+
+    def forward(self, x, lens=None):
+        return hip_ops.dwconv(x, self.weight.detach().contiguous(), self.bias.detach().contiguous(), lens, self.dilation)
+
+
+class DDSConv(nn.Module):
+    """Dilated and depth-separable convolution, modules/flow/modules.py:25-72."""
+
+    def __init__(self, channels, kernel_size, n_layers, p_dropout=0.0):
+        super().__init__()
+        from amphion_amd.modules.base import LayerNorm
+
+        self.channels, self.kernel_size, self.n_layers, self.p_dropout = channels, kernel_size, n_layers, p_dropout
+        self.convs_sep, self.convs_1x1 = nn.ModuleList(), nn.ModuleList()
+        self.norms_1, self.norms_2 = nn.ModuleList(), nn.ModuleList()
+        for i in range(n_layers):
+            self.convs_sep.append(DepthwiseConv1d(channels, kernel_size, kernel_size**i))
+            self.convs_1x1.append(HipConv1d(channels, channels, 1, weight_norm=False))
+            self.norms_1.append(LayerNorm(channels))
+            self.norms_2.append(LayerNorm(channels))
+
+    def forward(self, x, lens=None):
+        """:63-72 in eval mode (the optional ``x + g`` of :61-62 is fused into the conv that produces x by the callers)."""
+        x = _lib.require_device_tensor(x, "DDSConv input")
+        for i in range(self.n_layers):
+            y = self.convs_sep[i](x, lens)                 # conv(x * mask)
+            y = self.norms_1[i](y, gelu=True)
+            y = self.convs_1x1[i](y)
+            x = self.norms_2[i](y, gelu=True, post=x)      # x + gelu(norm(y))
+        return hip_ops.sequence_mask_(x, lens) if lens is not None else x
+
+
+class Log(nn.Module):
+    """modules/flow/modules.py:304-312 -- used only by the training direction of the duration predictor."""
+
+    def forward(self, x, x_mask, reverse=False, **kwargs):
+        raise NotImplementedError("Log flow: training direction only (inference-only kernels)")
+
+
+class ElementwiseAffine(nn.Module):
+    """modules/flow/modules.py:325-340 (reverse direction on the GPU)."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.channels = channels
+        self.m = nn.Parameter(torch.zeros(channels, 1))
+        self.logs = nn.Parameter(torch.zeros(channels, 1))
+
+    def forward(self, x, lens=None, reverse=False, **kwargs):
+        if not reverse:
+            raise NotImplementedError("ElementwiseAffine forward: training direction only")
+        return hip_ops.affine_reverse(_lib.require_device_tensor(x, "ElementwiseAffine input"), self.m.detach().reshape(-1).contiguous(),
+                                      self.logs.detach().reshape(-1).contiguous(), lens)
+
+
+class ConvFlow(nn.Module):
+    """modules/flow/modules.py:400-458 for in_channels = 2 (one conditioning, one transformed channel)."""
+
+    def __init__(self, in_channels, filter_channels, kernel_size, n_layers, num_bins=10, tail_bound=5.0):
+        super().__init__()
+        if in_channels != 2:
+            raise NotImplementedError("the HIP spline flow covers the duration predictor's 2-channel flows")
+        self.in_channels, self.filter_channels, self.kernel_size, self.n_layers = in_channels, filter_channels, kernel_size, n_layers
+        self.num_bins, self.tail_bound, self.half_channels = num_bins, tail_bound, in_channels // 2
+        self.pre = HipConv1d(self.half_channels, filter_channels, 1, weight_norm=False)
+        self.convs = DDSConv(filter_channels, kernel_size, n_layers, p_dropout=0.0)
+        self.proj = HipConv1d(filter_channels, self.half_channels * (num_bins * 3 - 1), 1, weight_norm=False)
+        self.proj.weight.data.zero_()   # :419-420
+        self.proj.bias.data.zero_()
+
+    def forward(self, x, lens=None, g=None, reverse=False, flip_in=False, flip_out=False):
+        """x [B, 2, T].  ``flip_in`` / ``flip_out`` fold the Flip layers before / after this flow into the spline kernel."""
+        x = _lib.require_device_tensor(x, "ConvFlow input")
+        B, _, T = x.shape
+        # x0 = the conditioning channel: channel 0, or channel 1 when the preceding Flip is folded in
+        x0 = x[:, 1:2] if flip_in else x[:, 0:1]
+        h = self.pre(x0.contiguous(), res=g)                # pre(x0) + g: DDSConv's "x + g" (:61-62) fused into the conv
+        h = self.convs(h, lens)
+        h = self.proj(h)                                    # masked inside the spline kernel (h * x_mask, :428)
+        return hip_ops.spline_flow(x, h, lens, self.num_bins, self.filter_channels, self.tail_bound, inverse=reverse,
+                                   flip_in=flip_in, flip_out=flip_out)

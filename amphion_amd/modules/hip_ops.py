@@ -122,3 +122,86 @@ def posterior_sample(stats, eps, lens):
     _lib.check(_lib.lib().amp_posterior_sample(_ptr(stats), _ptr(eps), _ptr(lens), _ptr(z), B, C2 // 2, T,
                                                _lib.current_stream_ptr(stats.device)))
     return z
+
+
+# ---- EXPERIMENTAL (not yet run on hardware): frame-rate ops of VITS' text -> duration -> alignment front ----------------
+def _stream(t):
+    return _lib.current_stream_ptr(t.device)
+
+
+def layer_norm_c(x, gamma, beta, res=None, post=None, eps=1e-5, gelu=False):
+    """post + act(LN(x + res)) over the channel axis"""
+    B, C, T = x.shape
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().amp_layer_norm_c(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(post), B, C, T, float(eps), int(gelu), _ptr(y),
+                                           _stream(x)))
+    return y
+
+
+def add_channel_bias_(x, cb):
+    """x [B, C, T] += cb [B, C, 1] in place (x + cond(g) for a length-1 condition)"""
+    B, C, T = x.shape
+    _lib.check(_lib.lib().amp_add_channel_bias(_ptr(x), _ptr(cb.reshape(B, C).contiguous()), B, C, T, _stream(x)))
+    return x
+
+
+def rel_attention(q, k, v, emb_k, emb_v, lens, n_heads, window):
+    B, C, T = q.shape
+    out = torch.empty_like(q)
+    _lib.check(_lib.lib().amp_rel_attention(_ptr(q), _ptr(k), _ptr(v), _ptr(emb_k), _ptr(emb_v), _ptr(lens), B, n_heads, C // n_heads, T,
+                                            int(window), _ptr(out), _stream(q)))
+    return out
+
+
+def dwconv(x, weight, bias, lens, dilation):
+    B, C, T = x.shape
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().amp_dwconv(_ptr(x), _ptr(weight), _ptr(bias), _ptr(lens), B, C, T, weight.shape[-1], int(dilation), _ptr(y), _stream(x)))
+    return y
+
+
+def spline_flow(z, h, lens, num_bins, filter_channels, tail_bound, inverse, flip_in=False, flip_out=False):
+    B, _, T = z.shape
+    out = torch.empty_like(z)
+    _lib.check(_lib.lib().amp_spline_flow(_ptr(z), _ptr(h), _ptr(lens), B, T, int(num_bins), int(filter_channels), float(tail_bound),
+                                          int(inverse), int(flip_in), int(flip_out), _ptr(out), _stream(z)))
+    return out
+
+
+def affine_reverse(x, m, logs, lens):
+    B, C, T = x.shape
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().amp_affine_reverse(_ptr(x), _ptr(m), _ptr(logs), _ptr(lens), B, C, T, _ptr(y), _stream(x)))
+    return y
+
+
+def embed_tokens(tokens, weight, lens, scale):
+    B, T = tokens.shape
+    n_vocab, hidden = weight.shape
+    y = torch.empty((B, hidden, T), dtype=torch.float32, device=weight.device)
+    _lib.check(_lib.lib().amp_embed_tokens(_ptr(tokens), _ptr(weight), _ptr(lens), B, T, hidden, n_vocab, float(scale), _ptr(y), _stream(weight)))
+    return y
+
+
+def durations(logw, lens, length_scale):
+    """-> (w_ceil [B, 1, T] float, cum [B, T] int32, y_lengths [B] int32)"""
+    B, _, T = logw.shape
+    w_ceil = torch.empty_like(logw)
+    cum = torch.empty((B, T), dtype=torch.int32, device=logw.device)
+    ylen = torch.empty((B,), dtype=torch.int32, device=logw.device)
+    _lib.check(_lib.lib().amp_durations(_ptr(logw), _ptr(lens), B, T, float(length_scale), _ptr(w_ceil), _ptr(cum), _ptr(ylen), _stream(logw)))
+    return w_ceil, cum, ylen
+
+
+def expand_path(src, cum, xlens, ylens, t_y, want_attn=False):
+    B, D, Tx = src.shape
+    out = torch.empty((B, D, t_y), dtype=torch.float32, device=src.device)
+    attn = torch.empty((B, 1, t_y, Tx), dtype=torch.float32, device=src.device) if want_attn else None
+    _lib.check(_lib.lib().amp_expand_path(_ptr(src), _ptr(cum), _ptr(xlens), _ptr(ylens), B, D, Tx, int(t_y), _ptr(out), _ptr(attn), _stream(src)))
+    return out, attn
+
+
+def gauss_sample(m, logs, noise, noise_scale):
+    out = torch.empty_like(m)
+    _lib.check(_lib.lib().amp_gauss_sample(_ptr(m), _ptr(logs), _ptr(noise), m.numel(), float(noise_scale), _ptr(out), _stream(m)))
+    return out

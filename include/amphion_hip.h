@@ -188,6 +188,51 @@ typedef enum amp_pad_mode { AMP_PAD_REPLICATE = 0, AMP_PAD_ZEROS = 1, AMP_PAD_RE
 int amp_fir_filter(const float* x_dev, int B, int C, int T, const float* filt_host, int K, int stride, int pad_left,
                    int pad_right, int pad_mode, float* y_dev, void* stream);
 
+/* ---- EXPERIMENTAL (not yet run on hardware): frame-rate ops of the text -> duration -> alignment front of VITS
+ * inference, SynthesizerTrn.infer models/tts/vits/vits.py:320-369.  All tensors [B, C, T] fp32 on the
+ * device; lens_dev = int32 [B] valid lengths (NULL = all T). ---- */
+/* LayerNorm over channels (modules/base/base_module.py:20-23) of x (+ res if not NULL: Encoder's norm(x + y),
+ * modules/transformer/attentions.py:69,73), optionally followed by GELU and by "+ post" (DDSConv,
+ * modules/flow/modules.py:64-70: x = x + gelu(norm(y))). */
+int amp_layer_norm_c(const float* x_dev, const float* res_dev, const float* gamma_dev, const float* beta_dev,
+                     const float* post_dev, int B, int C, int T, float eps, int gelu, float* y_dev, void* stream);
+/* x[b, c, :] += cb[b, c]: the broadcast add of a length-1 condition, x + cond(g) (hifigan.py:426-427,
+ * stochastic_duration_predictor.py:64-66). */
+int amp_add_channel_bias(float* x_dev, const float* cb_dev, int B, int C, int T, void* stream);
+/* MultiHeadAttention.attention for self-attention with windowed relative-position embeddings shared by the heads
+ * (modules/transformer/attentions.py:232-272): q, k, v, out [B, H*dk, T]; emb_k, emb_v [2*window+1, dk]. */
+int amp_rel_attention(const float* q_dev, const float* k_dev, const float* v_dev, const float* emb_k_dev,
+                      const float* emb_v_dev, const int* lens_dev, int B, int H, int dk, int T, int window, float* out_dev,
+                      void* stream);
+/* Depthwise dilated Conv1d of x * mask, padding (K*d - d)/2 (DDSConv.convs_sep, modules/flow/modules.py:46-56,63);
+ * w [C, 1, K], bias [C] or NULL. */
+int amp_dwconv(const float* x_dev, const float* w_dev, const float* bias_dev, const int* lens_dev, int B, int C, int T, int K,
+               int dilation, float* y_dev, void* stream);
+/* ConvFlow's spline step (modules/flow/modules.py:435-458 + modules/transformer/transforms.py:56-215): the piecewise
+ * rational-quadratic transform with linear tails of one channel of z [B, 2, T] given h [B, 3*num_bins - 1, T] (masked
+ * here), both channels * mask; flip_in / flip_out fold the neighbouring Flip layers (:315-321) in.  z_out != z. */
+int amp_spline_flow(const float* z_dev, const float* h_dev, const int* lens_dev, int B, int T, int num_bins,
+                    int filter_channels, float tail_bound, int inverse, int flip_in, int flip_out, float* z_out_dev,
+                    void* stream);
+/* ElementwiseAffine reverse: (x - m) * exp(-logs) * mask (modules/flow/modules.py:338-340); m, logs [C]. */
+int amp_affine_reverse(const float* x_dev, const float* m_dev, const float* logs_dev, const int* lens_dev, int B, int C, int T,
+                       float* y_dev, void* stream);
+/* emb(tokens) * scale, transposed to [B, hidden, T] and masked (TextEncoder.forward vits.py:58-62); tokens int64 [B, T],
+ * weight [n_vocab, hidden]. */
+int amp_embed_tokens(const long long* tokens_dev, const float* weight_dev, const int* lens_dev, int B, int T, int hidden,
+                     int n_vocab, float scale, float* y_dev, void* stream);
+/* w_ceil = ceil(exp(logw) * mask * length_scale) [B, T], its running sum (int32 [B, T]) and y_len = max(sum, 1)
+ * (vits.py:341-343, utils/util.py:633). */
+int amp_durations(const float* logw_dev, const int* lens_dev, int B, int T, float length_scale, float* w_ceil_dev, int* cum_dev,
+                  int* ylen_dev, void* stream);
+/* out[b, :, y] = src[b, :, x(y)] along the monotonic path cum[x-1] <= y < cum[x] ( = generate_path(...) @ src,
+ * utils/util.py:625-640, vits.py:345-353); attn_dev [B, 1, Ty, Tx] receives the path itself when not NULL. */
+int amp_expand_path(const float* src_dev, const int* cum_dev, const int* xlens_dev, const int* ylens_dev, int B, int D, int Tx,
+                    int Ty, float* out_dev, float* attn_dev, void* stream);
+/* z_p = m + noise * exp(logs) * noise_scale over n elements (vits.py:355). */
+int amp_gauss_sample(const float* m_dev, const float* logs_dev, const float* noise_dev, size_t n, float noise_scale,
+                     float* out_dev, void* stream);
+
 /* Snake.forward / SnakeBeta.forward as a stand-alone element-wise op (modules/activation_functions/snake.py:51-61,
  * 110-122): y = x + sin(a x)^2 / (b + 1e-9) over [B, C, T]; alpha_dev / beta_dev: [C] on the device, beta_dev NULL
  * for Snake (b = a); logscale: a = exp(alpha), b = exp(beta). */

@@ -1,0 +1,142 @@
+"""EXPERIMENTAL -- the kernels under test (amphion_amd/csrc/vits_text.hip) were written after round 1's GPU budget was
+spent and have NOT run on hardware yet, so this file is skipped unless AMP_RUN_UNVERIFIED=1:
+
+    AMP_RUN_UNVERIFIED=1 python -m pytest tests/test_gpu_vits_infer.py -m gpu -q
+
+Full VITS inference through the SynthesizerTrn drop-in against the golden vectors of the REAL
+reference's ``SynthesizerTrn.infer`` and, op by op, against oracle/vits_infer_oracle.py (itself pinned on those
+vectors by tests/test_oracle_vits_infer.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import synth
+from oracle import vits_infer_oracle as vio
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("AMP_RUN_UNVERIFIED") != "1", reason="unverified kernels: set AMP_RUN_UNVERIFIED=1")]
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = np.load(os.path.join(HERE, "golden", "golden_vits_infer.npz"))
+SMALL = dict(inter_channels=16, hidden_channels=32, filter_channels=64, n_heads=2, n_layers=2, kernel_size=3, p_dropout=0.1,
+             resblock="1", resblock_kernel_sizes=[3, 5], resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5]], upsample_rates=[4, 2],
+             upsample_initial_channel=32, upsample_kernel_sizes=[8, 4])
+VARIANTS = {"sdp": dict(n_speakers=0, gin_channels=0, use_sdp=True), "sdp_spk": dict(n_speakers=3, gin_channels=8, use_sdp=True),
+            "dp": dict(n_speakers=0, gin_channels=0, use_sdp=False)}
+
+
+def _weights(tag):
+    with open(os.path.join(HERE, "golden", f"keys_vits_infer_{tag}.json")) as f:
+        shapes = {k: tuple(s) for k, s in json.load(f)}
+    return synth.synth_state_dict(shapes, 77, g_gain=0.5)
+
+
+def _t(tag, key):
+    return torch.from_numpy(G[f"{tag}_{key}"])
+
+
+def _net(tag):
+    from amphion_amd.models.tts.vits.vits import SynthesizerTrn
+
+    net = SynthesizerTrn(40, 33, 8, **SMALL, **VARIANTS[tag])
+    net.load_state_dict(_weights(tag))
+    return net.cuda().eval()
+
+
+@pytest.mark.parametrize("tag", list(VARIANTS))
+def test_infer_matches_reference(tag):
+    net = _net(tag)
+    kw = VARIANTS[tag]
+    with torch.no_grad():
+        o = net.infer(_t(tag, "x").cuda(), _t(tag, "x_lengths"), sid=_t(tag, "sid") if kw["n_speakers"] else None,
+                      noise_scale=0.667, length_scale=1.1, noise_scale_w=0.8,
+                      noise_dp=_t(tag, "noise_dp").cuda() if kw["use_sdp"] else None, noise_z=_t(tag, "noise_z").cuda())
+    assert torch.equal(o["attn"].cpu(), _t(tag, "attn"))                      # integer durations -> the path is exact
+    assert torch.equal(o["mask"].cpu(), _t(tag, "mask"))
+    valid = _t(tag, "mask").bool()
+    for k, tol in (("m_p", 5e-5), ("logs_p", 5e-5), ("z_p", 1e-4), ("z", 2e-4)):
+        got, want = o[k].cpu(), _t(tag, k)
+        assert got.shape == want.shape, k
+        assert ((got - want) * valid).abs().max().item() <= tol, k            # padded frames: see gauss_sample / flow masks
+    assert (o["y_hat"].cpu() - _t(tag, "y_hat")).abs().max().item() <= 1e-4
+
+
+def test_text_encoder_and_duration_predictors_vs_oracle():
+    for tag in VARIANTS:
+        net, sd = _net(tag), _weights(tag)
+        x, xl = _t(tag, "x"), _t(tag, "x_lengths")
+        with torch.no_grad():
+            h, m, logs, lens = net.enc_p(x.cuda(), xl)
+            rx, rm, rlogs, rmask = vio.text_encoder(sd, "enc_p", x, xl, 32, 16, 2, 2, 3)
+            assert (h.cpu() - rx).abs().max().item() <= 5e-5
+            assert (m.cpu() - rm).abs().max().item() <= 5e-5 and (logs.cpu() - rlogs).abs().max().item() <= 5e-5
+            g = None
+            if VARIANTS[tag]["n_speakers"]:
+                g = net.emb_g(_t(tag, "sid").cuda().squeeze(-1)).unsqueeze(-1)
+            if VARIANTS[tag]["use_sdp"]:
+                logw = net.dp(h, lens, g=g, reverse=True, noise_scale=0.8, noise=_t(tag, "noise_dp").cuda())
+            else:
+                logw = net.dp(h, lens, g=g)
+        assert (logw.cpu() - _t(tag, "logw")).abs().max().item() <= 5e-4     # 3 spline flows deep
+
+
+def test_ops_vs_oracle():
+    from amphion_amd.modules import hip_ops
+
+    g = torch.Generator().manual_seed(5)
+    B, C, T = 3, 24, 50
+    lens = torch.tensor([50, 31, 1])
+    lens_d = lens.to(torch.int32).cuda()
+    mask = (torch.arange(T).view(1, 1, T) < lens.view(B, 1, 1)).float()
+    x, r = torch.randn(B, C, T, generator=g), torch.randn(B, C, T, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    # LayerNorm(x + res), gelu, + post
+    ref = x + torch.nn.functional.gelu(vio.layer_norm_channels(x + r, gamma, beta))
+    got = hip_ops.layer_norm_c(x.cuda(), gamma.cuda(), beta.cuda(), res=r.cuda(), post=x.cuda(), gelu=True).cpu()
+    assert (got - ref).abs().max().item() <= 1e-5
+    # depthwise dilated conv of x * mask
+    for K, d in ((3, 1), (3, 3), (3, 9), (5, 2)):
+        w, b = torch.randn(C, 1, K, generator=g), torch.randn(C, generator=g)
+        ref = torch.nn.functional.conv1d(x * mask, w, b, padding=(K * d - d) // 2, dilation=d, groups=C)
+        got = hip_ops.dwconv(x.cuda(), w.cuda(), b.cuda(), lens_d, d).cpu()
+        assert (got - ref).abs().max().item() <= 1e-5, (K, d)
+    # relative attention (2 heads, window 4), incl. a sequence shorter than the window
+    sd = {"a.conv_q.weight": torch.eye(C).unsqueeze(-1), "a.conv_q.bias": torch.zeros(C)}
+    for n in ("k", "v", "o"):
+        sd[f"a.conv_{n}.weight"], sd[f"a.conv_{n}.bias"] = torch.eye(C).unsqueeze(-1), torch.zeros(C)
+    sd["a.emb_rel_k"], sd["a.emb_rel_v"] = torch.randn(1, 9, C // 2, generator=g) * 0.3, torch.randn(1, 9, C // 2, generator=g) * 0.3
+    for tt in (T, 3):
+        xs = x[:, :, :tt].contiguous()
+        ls = torch.clamp(lens, max=tt)
+        ms = (torch.arange(tt).view(1, 1, tt) < ls.view(B, 1, 1)).float()
+        ref = vio.relative_self_attention(sd, "a", xs, ms, 2, 4)              # identity projections: q = k = v = x
+        got = hip_ops.rel_attention(xs.cuda(), xs.cuda(), xs.cuda(), sd["a.emb_rel_k"][0].cuda(), sd["a.emb_rel_v"][0].cuda(),
+                                    ls.to(torch.int32).cuda(), 2, 4).cpu()
+        assert ((got - ref) * ms).abs().max().item() <= 2e-5, tt
+    # spline, both directions, folded flips
+    z = torch.randn(B, 2, T, generator=g) * 3
+    h = torch.randn(B, 29, T, generator=g)
+    for inverse in (True, False):
+        hm = (h * mask).reshape(B, 1, 29, T).permute(0, 1, 3, 2)
+        y1 = vio.rq_spline(z[:, 1:], hm[..., :10] / 8.0, hm[..., 10:20] / 8.0, hm[..., 20:], inverse, 5.0)
+        ref = torch.cat([z[:, :1], y1], 1) * mask
+        got = hip_ops.spline_flow(z.cuda(), h.cuda(), lens_d, 10, 64, 5.0, inverse).cpu()
+        assert (got - ref).abs().max().item() <= 2e-4, inverse
+        got = hip_ops.spline_flow(torch.flip(z, [1]).cuda(), h.cuda(), lens_d, 10, 64, 5.0, inverse, flip_in=True, flip_out=True).cpu()
+        assert (got - torch.flip(ref, [1])).abs().max().item() <= 2e-4
+    # durations -> path -> expansion
+    logw = torch.randn(B, 1, T, generator=g)
+    w_ceil, cum, ylen = hip_ops.durations(logw.cuda(), lens_d, 1.1)
+    rw = torch.ceil(torch.exp(logw) * mask * 1.1)
+    assert torch.equal(w_ceil.cpu(), rw)
+    ry = torch.clamp_min(rw.sum(dim=(1, 2)), 1).long()
+    assert torch.equal(ylen.cpu().long(), ry)
+    ty = int(ry.max())
+    ymask = (torch.arange(ty).view(1, 1, ty) < ry.view(B, 1, 1)).float()
+    path = vio.generate_path(rw, mask.unsqueeze(2) * ymask.unsqueeze(-1))
+    src = torch.randn(B, 7, T, generator=g)
+    out, attn = hip_ops.expand_path(src.cuda(), cum, lens_d, ylen, ty, want_attn=True)
+    assert torch.equal(attn.cpu(), path)
+    assert torch.equal(out.cpu(), torch.matmul(path.squeeze(1), src.transpose(1, 2)).transpose(1, 2))
