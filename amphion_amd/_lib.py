@@ -75,6 +75,7 @@ _SIGNATURES = {
     "amp_gen_hop": (c_int, [c_void_p]),
     "amp_gen_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "amp_set_group_mb": (c_int, [c_int]),
+    "amp_set_pair_strips": (c_int, [c_int]),
     "amp_gen_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "amp_gen_forward_ragged": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "amp_gen_set_profiling": (c_int, [c_void_p, c_int]),

@@ -34,7 +34,7 @@ def _units():
         units.append(("conv_f16x3.hip", f"conv_f16x3_kt{kt}.o", [f"-DAMP_KT={kt}"]))
     for kt in PAIR_TAPS:
         units.append(("pair_f16x3.hip", f"pair_f16x3_kt{kt}.o", [f"-DAMP_KT={kt}"]))
-        units.append(("amp_pair_f16x3.hip", f"amp_pair_f16x3_kt{kt}.o", [f"-DAMP_KT={kt}"]))   # experimental, AMP_FUSE_AMP=1
+        units.append(("pair_strip_f16x3.hip", f"pair_strip_f16x3_kt{kt}.o", [f"-DAMP_KT={kt}"]))
     return units
 
 

@@ -60,7 +60,11 @@ struct PairArgs {
     const void* wp2;           // conv2 (kernel k, dilation 1)
     const float* bias2;
     int B, C, T;
-    int tiles_per_item;        // ceil(T / NT)
+    int tiles_per_item;        // per-tile kernel (pair_f16x3.hip): ceil(T / NT)
+    int strip_len;             // strip kernel (pair_strip_f16x3.hip): output columns per workgroup ...
+    int strips_per_item;       // ... and workgroups per batch item, ceil(T / strip_len)
+    int stagger;               // experiment: start delay of de-phased workgroups, in s_sleep(127) units (0 = none)
+    int stagger_mode;          // 1: second-slot workgroups (blockIdx >> 8 odd) wait `stagger`; 2: (blockIdx >> 3) & 7 eighths of it
     int dil;
     float slope;               // leaky_relu slope (on x while staging, on conv1's output at the seam)
     float sc1, isc1, sc2, isc2;  // 16 * 2^s operand scaling of each conv and its reciprocal
@@ -69,32 +73,6 @@ struct PairArgs {
     const int* lens;           // ragged batches, see ConvArgs
     int len_mul;
 };
-
-// Arguments of the EXPERIMENTAL fused AMPBlock1 pair (amp_pair_f16x3.hip, off unless AMP_FUSE_AMP=1):
-//   y = res + c2(a2(c1(xin)))   [mode 1: y += ..., mode 2: y = (y + ...) / div],  xin = a1(x) computed by act1d
-struct AmpPairArgs {
-    const float* xin;          // [B, C, T] conv1 input (already activated)
-    const float* res;          // [B, C, T] residual (the block's running x)
-    float* y;                  // [B, C, T] output; must not alias xin
-    const void* wp1;           // conv1 (kernel k, dilation dil): packed f16x3 A fragments
-    const float* bias1;
-    const void* wp2;           // conv2 (kernel k, dilation 1)
-    const float* bias2;
-    const float* act_a;        // a2: per-channel alpha (exp'ed when logscale) ...
-    const float* act_invb;     // ... and 1 / (beta + 1e-9)
-    float fu2[12];             // up-sampling taps x 2 (UpSample1d's gain folded in)
-    float fd[12];              // down-sampling taps
-    int B, C, T;
-    int tiles_per_item;        // ceil(T / NT)
-    int dil;
-    float sc1, isc1, sc2, isc2;
-    int mode;
-    float div;
-    const int* lens;
-    int len_mul;
-};
-int amp_pair_tile(int k, int C, int dil);
-hipError_t launch_amp_pair(int k, const AmpPairArgs& a, hipStream_t stream);
 
 struct ConvPlan {
     int KT;      // taps compiled into the kernel (1,2,3,5,7,11)
@@ -113,6 +91,9 @@ hipError_t launch_conv_f16x3(const ConvPlan& plan, const ConvArgs& a, hipStream_
 // fused pair: output columns per workgroup for (C, k, dilation), 0 = not covered; launch
 int pair_tile(int k, int C, int dil);
 hipError_t launch_pair(int k, const PairArgs& a, hipStream_t stream);
+// strip-mined fused pair (pair_strip_f16x3.hip): columns per step for (C, k, dilation), 0 = not covered
+int strip_step(int k, int C, int dil, int* wg_per_cu);
+hipError_t launch_strip(int k, const PairArgs& a, hipStream_t stream);
 
 // conv_post: y[b,0,t] = tanh( bias + sum_i sum_j w[i][j] * act_in(x[b,i,t+j-pad]) )   (Cout == 1)
 hipError_t launch_conv_post(const float* x, const float* w_dev /*[Cin*K]*/, const float* bias_dev /*[1] or null*/,

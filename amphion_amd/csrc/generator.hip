@@ -124,40 +124,33 @@ hipError_t launch_pair(int k, const PairArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
-int amp_pair_tile_kt3(int, int);
-int amp_pair_tile_kt5(int, int);
-int amp_pair_tile_kt7(int, int);
-int amp_pair_tile_kt11(int, int);
-hipError_t launch_amp_pair_kt3(const AmpPairArgs&, hipStream_t);
-hipError_t launch_amp_pair_kt5(const AmpPairArgs&, hipStream_t);
-hipError_t launch_amp_pair_kt7(const AmpPairArgs&, hipStream_t);
-hipError_t launch_amp_pair_kt11(const AmpPairArgs&, hipStream_t);
+int strip_step_kt3(int, int, int*);
+int strip_step_kt5(int, int, int*);
+int strip_step_kt7(int, int, int*);
+int strip_step_kt11(int, int, int*);
+hipError_t launch_strip_kt3(const PairArgs&, hipStream_t);
+hipError_t launch_strip_kt5(const PairArgs&, hipStream_t);
+hipError_t launch_strip_kt7(const PairArgs&, hipStream_t);
+hipError_t launch_strip_kt11(const PairArgs&, hipStream_t);
 
-int amp_pair_tile(int k, int C, int dil) {
+int strip_step(int k, int C, int dil, int* wg) {
     switch (k) {
-        case 3: return amp_pair_tile_kt3(C, dil);
-        case 5: return amp_pair_tile_kt5(C, dil);
-        case 7: return amp_pair_tile_kt7(C, dil);
-        case 11: return amp_pair_tile_kt11(C, dil);
+        case 3: return strip_step_kt3(C, dil, wg);
+        case 5: return strip_step_kt5(C, dil, wg);
+        case 7: return strip_step_kt7(C, dil, wg);
+        case 11: return strip_step_kt11(C, dil, wg);
     }
     return 0;
 }
 
-hipError_t launch_amp_pair(int k, const AmpPairArgs& a, hipStream_t s) {
+hipError_t launch_strip(int k, const PairArgs& a, hipStream_t s) {
     switch (k) {
-        case 3: return launch_amp_pair_kt3(a, s);
-        case 5: return launch_amp_pair_kt5(a, s);
-        case 7: return launch_amp_pair_kt7(a, s);
-        case 11: return launch_amp_pair_kt11(a, s);
+        case 3: return launch_strip_kt3(a, s);
+        case 5: return launch_strip_kt5(a, s);
+        case 7: return launch_strip_kt7(a, s);
+        case 11: return launch_strip_kt11(a, s);
     }
     return hipErrorInvalidValue;
-}
-
-// AMP_FUSE_AMP=1 runs BigVGAN's AMPBlock1 pairs (c1 -> a2 -> c2 + x) in the EXPERIMENTAL fused kernel of
-// amp_pair_f16x3.hip.  Off by default: that kernel has not run on hardware yet.
-static bool fuse_amp_enabled() {
-    static const bool on = [] { const char* e = getenv("AMP_FUSE_AMP"); return e && !strcmp(e, "1"); }();
-    return on;
 }
 
 // AMP_FUSE_PAIRS=0 runs every ResBlock pair as two conv launches (A/B switch for the fused kernel).
@@ -168,6 +161,40 @@ static bool fuse_pairs_enabled() {
         g_fuse_pairs = (e && !strcmp(e, "0")) ? 0 : 1;
     }
     return g_fuse_pairs != 0;
+}
+
+// AMP_PAIR_STRIP=1 / amp_set_pair_strips(1) runs the fused pairs on the strip-mined kernel (pair_strip_f16x3.hip)
+// instead of the per-tile kernel (pair_f16x3.hip).  Bit-identical results; measured on MI355X (profiles/r2_c_*,
+// r2_d_*): it removes the k - 1 seam columns per tile but loses the free load balancing and phase mixing of 12 000
+// independent tiles -- 33.9 vs 31.9 ms per config-2 step -- so it is OFF by default (kept as the bitwise cross-check
+// of tests/test_gpu_pair.py and as the only fused form for C = 256).
+static int g_pair_strips = -1;
+static bool pair_strips_enabled() {
+    if (g_pair_strips < 0) {
+        const char* e = getenv("AMP_PAIR_STRIP");
+        g_pair_strips = (e && !strcmp(e, "1")) ? 1 : 0;
+    }
+    return g_pair_strips != 0;
+}
+
+// Strip plan: `spi` workgroups per item, each walking ceil((L + k - 1) / n1) steps of n1 columns.  The chip holds
+// `slots` workgroups at a time; cost = rounds of workgroups x steps per workgroup (+ a per-workgroup constant for
+// the pipeline fill), minimised over spi -- long strips waste the least (k - 1 columns once per strip), but a
+// single utterance still has to spread over all CUs.
+static void strip_plan(int B, int T, int n1, int hb, int wg_per_cu, int* strip_len, int* spi_out) {
+    const int slots = wg_per_cu * 256;
+    long best = -1; int best_spi = 1;
+    const int max_spi = (T + n1 - 1) / n1;
+    for (int spi = 1; spi <= max_spi; ++spi) {
+        const int L = (T + spi - 1) / spi;
+        if ((long)(spi - 1) * L >= T) continue;              // the last strip would be empty
+        const long steps = (L + hb + n1 - 1) / n1;
+        const long rounds = ((long)B * spi + slots - 1) / slots;
+        const long cost = rounds * (4 * steps + 1);          // quarter-step fill per workgroup
+        if (best < 0 || cost < best) { best = cost; best_spi = spi; }
+    }
+    *spi_out = best_spi;
+    *strip_len = (T + best_spi - 1) / best_spi;
 }
 
 // Half-width conv tiles (NI = 2) for launches that would leave most CUs idle (a single utterance): conv_run()
@@ -367,6 +394,7 @@ static bool pair_supported(const amp_conv* c1, const amp_conv* c2) {
     if (c1->k != c2->k || c2->dilation != 1 || c1->k != c1->KT) return false;
     if (c1->padding != (c1->k - 1) / 2 * c1->dilation || c2->padding != (c2->k - 1) / 2) return false;
     if (!c1->bias_dev || !c2->bias_dev) return false;
+    if (pair_strips_enabled() && strip_step(c1->k, c1->cin, c1->dilation, nullptr) > 0) return true;
     return pair_tile(c1->k, c1->cin, c1->dilation) > 0;
 }
 
@@ -377,48 +405,24 @@ static int pair_run(const amp_conv* c1, const amp_conv* c2, const float* x, int 
     a.x = x; a.y = y;
     a.wp1 = c1->wp_dev; a.bias1 = c1->bias_dev; a.wp2 = c2->wp_dev; a.bias2 = c2->bias_dev;
     a.B = B; a.C = c1->cin; a.T = T;
-    const int NT = pair_tile(c1->k, c1->cin, c1->dilation);
-    a.tiles_per_item = (T + NT - 1) / NT;
     a.dil = c1->dilation;
     a.slope = slope;
     a.sc1 = 16.f * c1->wscale; a.isc1 = 1.f / a.sc1;
     a.sc2 = 16.f * c2->wscale; a.isc2 = 1.f / a.sc2;
     a.mode = mode; a.div = div;
     a.lens = lens; a.len_mul = len_mul;
-    AMP_HIP(launch_pair(c1->k, a, stream));
-    return AMP_OK;
-}
-
-// EXPERIMENTAL fused AMPBlock1 pair (amp_pair_f16x3.hip): y = res + c2(a2(c1(xin))), xin = a1(x) from act1d.
-static bool amp_pair_supported(const amp_conv* c1, const amp_conv* c2) {
-    if (!fuse_amp_enabled() || !fuse_pairs_enabled()) return false;
-    if (c1->precision != PREC_F16X3 || c2->precision != PREC_F16X3) return false;
-    if (c1->pad_reflect || c2->pad_reflect || c1->tanh_out || c2->tanh_out) return false;
-    if (c1->transposed || c2->transposed || c1->cin != c1->cout || c2->cin != c2->cout || c1->cin != c2->cin) return false;
-    if (c1->k != c2->k || c2->dilation != 1 || c1->k != c1->KT) return false;
-    if (c1->padding != (c1->k - 1) / 2 * c1->dilation || c2->padding != (c2->k - 1) / 2) return false;
-    if (!c1->bias_dev || !c2->bias_dev) return false;
-    return amp_pair_tile(c1->k, c1->cin, c1->dilation) > 0;
-}
-
-static int amp_pair_run(const amp_conv* c1, const amp_conv* c2, const float* xin, const float* res, const float* act_a,
-                        const float* act_invb, const float* fu_host, const float* fd_host, int B, int T, float* y,
-                        int mode, float div, hipStream_t stream, const int* lens, int len_mul) {
-    if (xin == y) { set_error("amp_pair_run: xin and y must not alias"); return AMP_ERR_INVALID; }
-    AmpPairArgs a{};
-    a.xin = xin; a.res = res; a.y = y;
-    a.wp1 = c1->wp_dev; a.bias1 = c1->bias_dev; a.wp2 = c2->wp_dev; a.bias2 = c2->bias_dev;
-    a.act_a = act_a; a.act_invb = act_invb;
-    for (int i = 0; i < 12; ++i) { a.fu2[i] = 2.f * fu_host[i]; a.fd[i] = fd_host[i]; }   // x2: UpSample1d's gain (exact)
-    a.B = B; a.C = c1->cin; a.T = T;
-    const int NT = amp_pair_tile(c1->k, c1->cin, c1->dilation);
+    int wg = 2;
+    const int n1 = pair_strips_enabled() ? strip_step(c1->k, c1->cin, c1->dilation, &wg) : 0;
+    if (n1 > 0) {
+        strip_plan(B, T, n1, c1->k - 1, wg, &a.strip_len, &a.strips_per_item);
+        { const char* e = getenv("AMP_STRIP_SPI_MUL"); if (e && atoi(e) > 1) { a.strips_per_item *= atoi(e); a.strip_len = (T + a.strips_per_item - 1) / a.strips_per_item; } }
+        { const char* e = getenv("AMP_STRIP_STAGGER"); a.stagger = e ? atoi(e) : 0; e = getenv("AMP_STRIP_STAGGER_MODE"); a.stagger_mode = e ? atoi(e) : 1; }
+        AMP_HIP(launch_strip(c1->k, a, stream));
+        return AMP_OK;
+    }
+    const int NT = pair_tile(c1->k, c1->cin, c1->dilation);
     a.tiles_per_item = (T + NT - 1) / NT;
-    a.dil = c1->dilation;
-    a.sc1 = 16.f * c1->wscale; a.isc1 = 1.f / a.sc1;
-    a.sc2 = 16.f * c2->wscale; a.isc2 = 1.f / a.sc2;
-    a.mode = mode; a.div = div;
-    a.lens = lens; a.len_mul = len_mul;
-    AMP_HIP(launch_amp_pair(c1->k, a, stream));
+    AMP_HIP(launch_pair(c1->k, a, stream));
     return AMP_OK;
 }
 
@@ -436,8 +440,6 @@ struct ActParams {  // one Activation1d
     float* invb_dev = nullptr;  // 1 / (beta + 1e-9)
     float* fu_dev = nullptr;    // 12 taps
     float* fd_dev = nullptr;
-    float fu_host[12] = {};     // the same taps on the host (kernel arguments of the fused AMP pair)
-    float fd_host[12] = {};
 };
 
 struct ResBlock {
@@ -667,7 +669,6 @@ static int build_act(amp_gen* g, const std::string& p, int c, ActParams* out) {
     if ((rc = upload(g, ib.data(), c, &out->invb_dev)) != AMP_OK) return rc;
     if ((rc = upload(g, iu->second.data.data(), 12, &out->fu_dev)) != AMP_OK) return rc;
     if ((rc = upload(g, idn->second.data.data(), 12, &out->fd_dev)) != AMP_OK) return rc;
-    for (int i = 0; i < 12; ++i) { out->fu_host[i] = iu->second.data[i]; out->fd_host[i] = idn->second.data[i]; }
     return AMP_OK;
 }
 
@@ -792,6 +793,12 @@ size_t amp_gen_workspace_bytes(const amp_gen* g, int B, int T) {
     if (!g || B <= 0 || T <= 0) return 0;
     const int G = gen_group_items(g, B, T);
     return gen_buf_elems(g, G, T) * sizeof(float) * gen_num_bufs(g) + (size_t)G * g->d.upsample_initial_channel * sizeof(float) + 256;
+}
+
+int amp_set_pair_strips(int on) {
+    if (on != 0 && on != 1) { set_error("amp_set_pair_strips: %d", on); return AMP_ERR_INVALID; }
+    g_pair_strips = on;
+    return AMP_OK;
 }
 
 int amp_set_group_mb(int megabytes) {
@@ -922,14 +929,6 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
                         const ActParams& a1 = rb.acts[2 * p];
                         const ActParams& a2 = rb.acts[2 * p + 1];
                         AMP_HIP(launch_act1d(cur, ACT, B, C, t, a1.a_dev, a1.invb_dev, a1.fu_dev, a1.fd_dev, lens, lm, st));
-                        if (amp_pair_supported(rb.c1[p].get(), rb.c2[p].get())) {
-                            // EXPERIMENTAL (AMP_FUSE_AMP=1): c1 -> a2 -> c2 + x in one kernel, a2 at the LDS seam
-                            float* dst = last ? XS : (cur == R ? TMP : R);
-                            AMP_RC(amp_pair_run(rb.c1[p].get(), rb.c2[p].get(), ACT, cur, a2.a_dev, a2.invb_dev, a2.fu_host,
-                                                a2.fd_host, B, t, dst, last ? mode_last : 0, (float)nk, st, lens, lm));
-                            cur = dst;
-                            continue;
-                        }
                         if (cur == TMP) {  // a previous pair was fused into TMP: keep the unfused ping-pong legal
                             AMP_HIP(hipMemcpyAsync(R, TMP, (size_t)B * C * t * sizeof(float), hipMemcpyDeviceToDevice, st));
                             cur = R;

@@ -1,0 +1,397 @@
+// Fused ResBlock pair, strip-mined along time (round 2; successor of the per-tile kernel in pair_f16x3.hip):
+//
+//     y = x + c2( lrelu( c1( lrelu(x) ) ) )         [+ the running MRF sum, / num_kernels]
+//
+// (ONE iteration of ResBlock1.forward, hifigan.py:93-100).  The per-tile kernel gave every workgroup N1 xt
+// columns and kept NT = N1 - (k - 1) outputs: both convs paid the k - 1 seam columns on every tile (11.6 % of
+// the MFMAs at k = 11, N1 = 96) and every tile re-staged its full dilated halo.  Here a workgroup walks a
+// STRIP of one utterance in steps of N1 columns and carries conv2's halo in LDS:
+//
+//   step s    conv1 (kernel KT, dilation d) on the N1 xt columns [X, X + N1), K loop over 16-channel chunks of x
+//             staged through the double-buffered LDS tile (as in conv_f16x3.hip);
+//   seam      the last KT - 1 xt columns of the previous step move to the front of the xt tile (each lane moves
+//             the values it wrote itself), then bias + leaky_relu + conv2's zero padding + x16 + hi/lo split of
+//             the new columns -> xt tile [chunk][plane hi|lo][octet][KT - 1 old | N1 new][8 x f16];
+//   conv2     (kernel KT, dilation 1) on the N1 outputs [X - H2, X + N1 - H2): K loop over the xt chunks in
+//             LDS, no staging, no barriers; its last chunk fetches the next step's first A fragments;
+//   epilogue  the staging loads of the NEXT step's first chunk are issued, then + bias, + residual x, MRF
+//             accumulate, store.
+//
+// Only the first step of a strip computes KT - 1 columns it throws away.  Per output element the order of
+// operations (bias, chunks, taps, the three MFMAs of a term) is that of the per-tile kernel and of
+// conv_f16x3.hip, so the result has the same bits however the time axis is cut (tests/test_gpu_pair.py).
+//
+// WM x WN waves: C = 32 * WM channels (C = 256 runs 8 waves, one workgroup per CU: the xt tile of all 256
+// channels is 108 KB); compiled once per tap count:  -DAMP_KT=<3|5|7|11>.
+#include "amp_internal.h"
+
+#ifndef AMP_KT
+#error "compile with -DAMP_KT=<taps>"
+#endif
+
+namespace amp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+union FragS {
+    uint4 u;
+    f16x8 h;
+};
+
+#define AMP_PIN_VMEM() __builtin_amdgcn_sched_barrier(0x386)
+
+template <int KT, int WM, int WN, int NI, int SX>
+__global__ __launch_bounds__(64 * WM * WN, 2) void pair_strip_kernel(const PairArgs a) {
+    constexpr int NTHR = 64 * WM * WN;
+    constexpr int N1 = 32 * NI * WN;          // xt columns per step = output columns per step
+    constexpr int H2 = (KT - 1) / 2;
+    constexpr int HB = KT - 1;                // xt columns carried from the previous step
+    constexpr int XT = N1 + HB;               // xt row length
+    constexpr int NCH = 2 * WM;               // 16-channel chunks (C = 32 * WM)
+    constexpr int XBUF = 4 * SX;              // uint4 per x staging buffer [plane][octet][SX]
+    constexpr int XTCH = 4 * XT;              // uint4 per xt chunk       [plane][octet][XT]
+    constexpr int NST = (4 * SX) / NTHR;      // staging items (column x channel quad) per thread
+    static_assert(SX % 64 == 0, "staging items must have a wave-uniform channel quad");
+    static_assert((4 * SX) % NTHR == 0, "staging items must divide over the threads");
+    static_assert(HB <= 32, "the carried columns must belong to the last n-tile");
+    extern __shared__ __attribute__((aligned(16))) uint4 smem4[];  // [2][XBUF] + [NCH][XTCH]
+    uint4* const xt4 = smem4 + 2 * XBUF;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int nbx = gridDim.x;  // XCD-contiguous runs of strips, see conv_f16x3.hip
+    const int bx = (nbx & 7) == 0 ? (int)(blockIdx.x & 7) * (nbx >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int item = bx / a.strips_per_item;
+    const int strip = bx - item * a.strips_per_item;
+    constexpr int C = 32 * WM;
+    const int T = a.T;
+    const int O = strip * a.strip_len;        // first output column of the strip
+    const int Oend = O + a.strip_len < T ? O + a.strip_len : T;
+    if (O >= Oend) return;                    // workgroup-uniform
+    const int nsteps = (Oend - O + HB + N1 - 1) / N1;
+    int Tv = T;                               // valid columns of this item (ragged batch)
+    if (a.lens) { const int l = a.lens[item] * a.len_mul; Tv = l < Tv ? l : Tv; }
+    const int dil = a.dil;
+    const int h1 = H2 * dil;
+
+    const float* xb = a.x + (size_t)item * C * T;
+    const float kpos = 16.f, kneg = 16.f * a.slope;
+
+    // Residual x at this lane's OUTPUT positions: for C <= 64 (HBM-bound pairs) fetched at the start of a step,
+    // next to the staging loads of the same cache lines (pair_f16x3.hip); C >= 128 re-reads in the epilogue.
+    constexpr bool RES_EARLY = WM < 4;
+    const int colw = wn * (32 * NI) + l31;    // this lane's column inside the step (n-tile 0)
+    const float* xres = a.x + (size_t)item * C * T + (size_t)(32 * wm + 4 * hi) * T;
+    float* yr = a.y + (size_t)item * C * T + (size_t)(32 * wm + 4 * hi) * T;
+
+    // Step-local, opaque copies of T and the row bases (set at the top of every step): with the plain values hipcc
+    // hoists every row offset r * T and the 48 residual / output addresses out of the step loop and holds them
+    // across both convs (all 106 SGPRs + 256 VGPRs + spills); re-deriving them per step costs a few SALU ops.
+    int Ts = T;
+    const float* xres_s = xres;
+    float* yr_s = yr;
+    float xs[NST][4];
+    auto stage_load = [&](int chunk, int tbase) {
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int ibase = wave * 64 + NTHR * it;         // wave-uniform
+            const int qd = ibase / SX;                       // channel quad 0..3
+            const int col = ibase - qd * SX + lane;
+            int t = tbase + col;
+            t = t < 0 ? 0 : t;
+            t = t > Ts - 1 ? Ts - 1 : t;
+            const int ch0 = chunk * KC16 + 4 * qd;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xs[it][e] = xb[(size_t)(ch0 + e) * Ts + t];
+        }
+    };
+    auto stage_store = [&](int buf, int tbase) {
+        uint2* dst = reinterpret_cast<uint2*>(smem4 + buf * XBUF);
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int ibase = wave * 64 + NTHR * it;
+            const int qd = ibase / SX;
+            const int col = ibase - qd * SX + lane;
+            const int t = tbase + col;
+            const bool tok = (t >= 0) && (t < Tv);
+            union { uint2 u; _Float16 h[4]; } fh, fl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = tok ? xs[it][e] : 0.f;
+                v = v * (v > 0.f ? kpos : kneg);
+                split_f16(v, fh.h[e], fl.h[e]);
+            }
+            const int o2 = (((qd >> 1) * SX + col) << 1) + (qd & 1);
+            dst[o2] = fh.u;
+            dst[4 * SX + o2] = fl.u;
+        }
+    };
+
+    // A fragments [mb][chunk][tap][plane][lane] x uint4, one register set, reloaded one chunk ahead; the reload
+    // during conv1's last chunk fetches conv2's first chunk, the one during conv2's last chunk the next step's.
+    const uint4* wa1 = static_cast<const uint4*>(a.wp1) + (size_t)wm * NCH * (KT * 128) + lane;
+    const uint4* wa2 = static_cast<const uint4*>(a.wp2) + (size_t)wm * NCH * (KT * 128) + lane;
+    FragS a_h[KT], a_l[KT];
+    const int rd1 = hi * SX + colw;
+    const int rd2 = hi * XT + colw;
+
+    if (a.stagger > 0) {   // experiment: de-phase co-resident workgroups
+        const int n = a.stagger_mode == 1 ? (((int)blockIdx.x >> 8) & 1) * a.stagger : ((((int)blockIdx.x >> 3) & 7) * a.stagger) >> 3;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+    int X = O - H2;                           // first xt column of the step
+    stage_load(0, X - h1);
+#pragma unroll
+    for (int g = 0; g < KT; ++g) {
+        a_h[g].u = wa1[g * 128];
+        a_l[g].u = wa1[g * 128 + 64];
+    }
+    AMP_PIN_VMEM();
+
+#pragma clang loop unroll(disable)
+    for (int s = 0; s < nsteps; ++s, X += N1) {
+        // hipcc would hoist the step-invariant bias values and row addresses out of this loop (60+ registers held
+        // across both convs -> spills); the opaque pointers make it re-derive them where they are used
+        const float* bias1 = a.bias1;
+        const float* bias2 = a.bias2;
+        asm volatile("" : "+s"(bias1), "+s"(bias2));
+        Ts = T; xres_s = xres; yr_s = yr;
+        asm volatile("" : "+s"(Ts), "+v"(xres_s), "+v"(yr_s));
+        const int tbase = X - h1;             // global column of staged column 0
+        // output columns of this step: q = X - H2 + col
+        int qc[NI];
+        bool okc[NI];
+#pragma unroll
+        for (int t = 0; t < NI; ++t) {
+            const int q = X - H2 + colw + 32 * t;
+            okc[t] = (q >= O) && (q < Oend);
+            qc[t] = q < 0 ? 0 : (q < Ts ? q : Ts - 1);
+        }
+        f32x16 rv[NI];
+        if (RES_EARLY) {
+#pragma unroll
+            for (int t = 0; t < NI; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[t][r] = xres_s[(size_t)((r & 3) + 8 * (r >> 2)) * Ts + qc[t]];
+        }
+
+        // ---------------- conv1 ----------------
+        f32x16 acc[NI];
+        {
+            const float s1 = a.sc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float bv = bias1[32 * wm + (r & 3) + 8 * (r >> 2) + 4 * hi] * s1;
+#pragma unroll
+                for (int t = 0; t < NI; ++t) acc[t][r] = bv;
+            }
+        }
+        stage_store(0, tbase);
+        __syncthreads();
+
+#pragma unroll 1
+        for (int c = 0; c < NCH; ++c) {
+            const bool more = (c + 1) < NCH;
+            stage_load(more ? c + 1 : c, tbase);
+            AMP_PIN_VMEM();
+            const uint4* wan = more ? wa1 + (size_t)(c + 1) * (KT * 128) : wa2;
+            const uint4* base = smem4 + (c & 1) * XBUF + rd1;
+#pragma unroll
+            for (int g = 0; g < KT; ++g) {
+                const uint4* bg = base + g * dil;
+                FragS bh[NI], bl[NI];
+#pragma unroll
+                for (int t = 0; t < NI; ++t) {
+                    bh[t].u = bg[32 * t];
+                    bl[t].u = bg[2 * SX + 32 * t];
+                }
+#pragma unroll
+                for (int t = 0; t < NI; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[g].h, bh[t].h, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NI; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[g].h, bl[t].h, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NI; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l[g].h, bh[t].h, acc[t], 0, 0, 0);
+                a_h[g].u = wan[g * 128];
+                a_l[g].u = wan[g * 128 + 64];
+                AMP_PIN_VMEM();
+            }
+            if (more) stage_store((c + 1) & 1, tbase);
+            __syncthreads();
+        }
+
+        // ---------------- seam: carry the halo, xt = lrelu(conv1) -> LDS, split-f16 B layout ----------------
+        {
+            uint2* xt2 = reinterpret_cast<uint2*>(xt4);
+            // position of xt column `col` of this step = HB + col.  The lane that wrote column col >= N1 - HB in the
+            // previous step moves it from HB + col to HB + col - N1 before overwriting it (own data, in order).
+            if (s > 0 && wn == WN - 1) {
+                const int col = colw + 32 * (NI - 1);
+                if (col >= N1 - HB) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int o4 = (2 * wm + (j >> 1)) * XTCH + (j & 1) * XT + HB + col;
+                        const uint2 vh = xt2[(o4 << 1) + hi];
+                        const uint2 vl = xt2[((o4 + 2 * XT) << 1) + hi];
+                        xt2[((o4 - N1) << 1) + hi] = vh;
+                        xt2[((o4 - N1 + 2 * XT) << 1) + hi] = vl;
+                    }
+                }
+            }
+            const float i1 = a.isc1;
+            const float slope = a.slope;
+#pragma unroll
+            for (int t = 0; t < NI; ++t) {
+                const int col = colw + 32 * t;                   // xt column of this step
+                const int q = X + col;                           // its global column
+                const bool qok = (q >= 0) && (q < Tv);           // conv2 zero-pads xt outside the utterance
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    union { uint2 u; _Float16 h[4]; } fh, fl;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = acc[t][4 * j + i] * i1;
+                        v = v > 0.f ? v : v * slope;
+                        v = qok ? v * 16.f : 0.f;
+                        split_f16(v, fh.h[i], fl.h[i]);
+                    }
+                    // channels 32*wm + 8*j + 4*hi + i  ->  chunk 2*wm + (j >> 1), octet j & 1, half hi
+                    const int o4 = (2 * wm + (j >> 1)) * XTCH + (j & 1) * XT + HB + col;
+                    xt2[(o4 << 1) + hi] = fh.u;
+                    xt2[((o4 + 2 * XT) << 1) + hi] = fl.u;
+                }
+            }
+        }
+        {
+            const float s2 = a.sc2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float bv = bias2[32 * wm + (r & 3) + 8 * (r >> 2) + 4 * hi] * s2;
+#pragma unroll
+                for (int t = 0; t < NI; ++t) acc[t][r] = bv;
+            }
+        }
+        __syncthreads();
+
+        // ---------------- conv2 over the xt tile ----------------
+#pragma unroll 1
+        for (int c = 0; c < NCH; ++c) {
+            const uint4* wan = (c + 1) < NCH ? wa2 + (size_t)(c + 1) * (KT * 128) : wa1;
+            const uint4* base = xt4 + c * XTCH + rd2;
+#pragma unroll
+            for (int g = 0; g < KT; ++g) {
+                const uint4* bg = base + g;
+                FragS bh[NI], bl[NI];
+#pragma unroll
+                for (int t = 0; t < NI; ++t) {
+                    bh[t].u = bg[32 * t];
+                    bl[t].u = bg[2 * XT + 32 * t];
+                }
+#pragma unroll
+                for (int t = 0; t < NI; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[g].h, bh[t].h, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NI; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[g].h, bl[t].h, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NI; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l[g].h, bh[t].h, acc[t], 0, 0, 0);
+                a_h[g].u = wan[g * 128];
+                a_l[g].u = wan[g * 128 + 64];
+                AMP_PIN_VMEM();
+            }
+        }
+
+        // ---------------- epilogue: + residual, MRF accumulate, store ----------------
+        // loads are unconditional from clamped addresses (batched, one wait), stores are predicated.  The staging loads
+        // of the next step's first chunk go first (their registers are free again; they land under the epilogue).
+        stage_load(0, (s + 1) < nsteps ? tbase + N1 : tbase);
+        AMP_PIN_VMEM();
+        {
+            const float i2 = a.isc2;
+            const int mode = a.mode;
+            if (!RES_EARLY) {
+#pragma unroll
+                for (int t = 0; t < NI; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[t][r] = xres_s[(size_t)((r & 3) + 8 * (r >> 2)) * Ts + qc[t]];
+            }
+#pragma unroll
+            for (int t = 0; t < NI; ++t) acc[t] = acc[t] * i2 + rv[t];
+            if (mode != 0) {   // wave-uniform
+#pragma unroll
+                for (int t = 0; t < NI; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[t][r] = yr_s[(size_t)((r & 3) + 8 * (r >> 2)) * Ts + qc[t]];
+#pragma unroll
+                for (int t = 0; t < NI; ++t) acc[t] += rv[t];
+                if (mode == 2) {
+#pragma unroll
+                    for (int t = 0; t < NI; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[t][r] = acc[t][r] / a.div;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NI; ++t)
+                if (okc[t]) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) yr_s[(size_t)((r & 3) + 8 * (r >> 2)) * Ts + qc[t]] = acc[t][r];
+                }
+        }
+    }
+}
+
+template <int KT, int WM, int WN, int NI, int SX>
+static hipError_t launch_strip_one(const PairArgs& a, hipStream_t stream) {
+    constexpr int N1 = 32 * NI * WN;
+    constexpr int XT = N1 + (KT - 1);
+    const size_t lds = ((size_t)2 * 4 * SX + (size_t)2 * WM * 4 * XT) * sizeof(uint4);
+    static unsigned long long attr_set = 0;   // per device: the attribute belongs to the device's copy of the function
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!((attr_set >> dev) & 1ull) && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_strip_kernel<KT, WM, WN, NI, SX>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set |= 1ull << dev;
+    }
+    dim3 grid((unsigned)(a.B * a.strips_per_item));
+    hipLaunchKernelGGL((pair_strip_kernel<KT, WM, WN, NI, SX>), grid, dim3(64 * WM * WN), lds, stream, a);
+    return hipGetLastError();
+}
+
+#define AMP_CAT2(a, b) a##b
+#define AMP_CAT(a, b) AMP_CAT2(a, b)
+
+// Step width (xt columns = output columns per step) for C channels, or 0 when (C, KT, dilation) is not covered;
+// *wg_per_cu = resident workgroups per CU (LDS / register bound), used by the host to size the strips.
+int AMP_CAT(strip_step_kt, AMP_KT)(int C, int dil, int* wg_per_cu) {
+    constexpr int KT = AMP_KT;
+    const int span = (KT - 1) * dil;   // staged halo = 2 * h1
+    int n1 = 0, wg = 2;
+    if (C == 256) { n1 = (96 + span <= 256) ? 96 : 0; wg = 1; }
+    else if (C == 128) n1 = (96 + span <= 192) ? 96 : 0;
+    else if (C == 64) n1 = (128 + span <= 192) ? 128 : 0;
+    else if (C == 32) n1 = (256 + span <= 320) ? 256 : 0;
+    if (wg_per_cu) *wg_per_cu = wg;
+    return n1;
+}
+
+hipError_t AMP_CAT(launch_strip_kt, AMP_KT)(const PairArgs& a, hipStream_t stream) {
+    constexpr int KT = AMP_KT;
+    const int span = (KT - 1) * a.dil;
+    if (a.C == 256) return launch_strip_one<KT, 8, 1, 3, 256>(a, stream);
+    if (a.C == 128) return span <= 32 ? launch_strip_one<KT, 4, 1, 3, 128>(a, stream) : launch_strip_one<KT, 4, 1, 3, 192>(a, stream);
+    if (a.C == 64) return launch_strip_one<KT, 2, 2, 2, 192>(a, stream);
+    if (a.C == 32) return launch_strip_one<KT, 1, 4, 2, 320>(a, stream);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace amp

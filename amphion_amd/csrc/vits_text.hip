@@ -1,7 +1,5 @@
-// EXPERIMENTAL -- written after round 1's GPU budget was spent; NOT yet run on hardware.  Covered by
-// tests/test_gpu_vits_infer.py (skipped unless AMP_RUN_UNVERIFIED=1) against oracle/vits_infer_oracle.py, which IS
-// pinned on the reference's golden vectors.  A line-by-line numpy transliteration of the spline, attention and
-// duration / path kernels agrees with that oracle (tests/experiments/vits_text_emulation.py).
+// First run on MI355X in round 2: tests/test_gpu_vits_infer.py green (every op against oracle/vits_infer_oracle.py,
+// SynthesizerTrn.infer against the reference's golden vectors: durations / path exact, waveform <= 1e-4).
 //
 // Frame-rate kernels of the text -> duration -> alignment front of VITS inference (SURVEY.md §8 f.4,
 // SynthesizerTrn.infer models/tts/vits/vits.py:320-369).  T_text is 10^2, channels ~200: everything here is

@@ -99,7 +99,7 @@ class SynthesizerTrnDecodePath(nn.Module):
         return o_hat, y_mask, (z, z_p, z_hat)
 
 
-# ---- EXPERIMENTAL (not yet run on hardware): the text -> duration -> alignment front and SynthesizerTrn.infer ----------
+# ---- the text -> duration -> alignment front and SynthesizerTrn.infer ----------
 class TextEncoder(nn.Module):
     """vits.py:28-67, same arguments and state_dict keys; ``forward(tokens, lengths) -> (x, m, logs, lens)``."""
 

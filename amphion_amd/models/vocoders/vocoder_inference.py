@@ -1,6 +1,7 @@
 """Drop-in side of models/vocoders/vocoder_inference.py: the three registries the reference's
-drivers dispatch through (:39-75), ``load_nnvocoder`` (:397-457), ``tensorize`` (:460-468) and
-``synthesis`` (:471-515), bound to the MI355X generators.
+drivers dispatch through (:39-75), ``load_nnvocoder`` (:397-457), ``tensorize`` (:460-468),
+``synthesis`` (:471-515) and the batch loop of ``VocoderInference.inference`` (:334-374, ``inference_batches``),
+bound to the MI355X generators.
 
 ``install_into_reference(mod)`` overwrites the ``hifigan`` / ``bigvgan`` / ``melgan`` entries of the reference
 module's own dicts, which is how ``bins/vocoder/inference.py`` runs unchanged on the HIP path
@@ -71,9 +72,12 @@ def load_nnvocoder(cfg, vocoder_name, weights_file, from_multi_gpu=False):
     model = _vocoders[vocoder_name](cfg)
     if not os.path.isdir(weights_file):
         ckpt = torch.load(weights_file, map_location="cpu")
-        sd = ckpt["generator_state_dict"]
-        if from_multi_gpu:
-            sd = _strip_module_prefix(sd, model.state_dict())
+        if vocoder_name in ("bigvgan", "hifigan", "melgan", "nsfhifigan"):   # :409-437
+            sd = ckpt["generator_state_dict"]
+            if from_multi_gpu:
+                sd = _strip_module_prefix(sd, model.state_dict())
+        else:                                                                # every other vocoder, :438-446
+            sd = ckpt["state_dict"]
         model.load_state_dict(sd)
     else:
         root = os.path.join(weights_file, "checkpoint")
@@ -93,6 +97,37 @@ def load_nnvocoder(cfg, vocoder_name, weights_file, from_multi_gpu=False):
     if torch.cuda.is_available():
         model = model.cuda()
     return model.eval()
+
+
+def inference_batches(cfg, model, batches, uids, output_dir, test_batch_size=None):
+    """The batch loop of ``VocoderInference.inference`` (vocoder_inference.py:334-374) over collated batches
+    (``VocoderCollator``: ``mel`` [B, T_max, n_mel], ``audio`` [B, T_max * hop], ``target_len`` [B], optional
+    ``frame_pitch``): forward function of the registry on ``mel.transpose(-1, -2)``, chunk into items, crop prediction
+    and ground truth to ``target_len * hop_size``, write ``pred/<uid>.wav`` and ``gt/<uid>.wav`` as 16-bit PCM.
+
+    ``uids`` is the metadata order (``test_dataset.metadata[i * batch_size + j]["Uid"]``, :362).  Returns the list of
+    cropped predictions (GPU tensors) in that order.  One conversion kernel + one D2H copy of int16 per batch
+    (``utils.io.save_audios``) instead of per-item fp32 copies."""
+    from amphion_amd.utils.io import save_audios
+
+    os.makedirs(os.path.join(output_dir, "pred"), exist_ok=True)
+    os.makedirs(os.path.join(output_dir, "gt"), exist_ok=True)
+    fwd = _vocoder_forward_funcs[cfg.model.generator]
+    device = next(model.parameters()).device
+    hop, fs = cfg.preprocess.hop_size, cfg.preprocess.sample_rate
+    preds = []
+    k = 0
+    for batch in batches:
+        kw = {"f0s": batch["frame_pitch"].float()} if getattr(cfg.preprocess, "use_frame_pitch", False) else {}
+        audio_pred = fwd(cfg, model, batch["mel"].transpose(-1, -2), device=device, **kw)
+        lens = [int(l) * hop for l in batch["target_len"]]
+        names = [str(u) for u in uids[k:k + len(lens)]]
+        k += len(lens)
+        pred = (audio_pred.squeeze(1) if audio_pred.dim() == 3 else audio_pred).to(device)   # the forward func returns CPU audio (:38)
+        save_audios([os.path.join(output_dir, "pred", n + ".wav") for n in names], pred, lens, fs)
+        save_audios([os.path.join(output_dir, "gt", n + ".wav") for n in names], batch["audio"].to(device), lens, fs)
+        preds.extend(row[:l] for row, l in zip(pred, lens))
+    return preds
 
 
 def tensorize(data, device, n_samples):

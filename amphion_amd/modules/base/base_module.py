@@ -1,5 +1,5 @@
 """LayerNorm over the channel axis of [B, C, T] (modules/base/base_module.py:11-24), same parameter names
-(``gamma``, ``beta``).  EXPERIMENTAL: the HIP kernel behind it (amp_layer_norm_c) has not run on hardware yet."""
+(``gamma``, ``beta``).  HIP kernel: amp_layer_norm_c (vits_text.hip)."""
 import torch
 import torch.nn as nn
 

@@ -1,5 +1,5 @@
 """DurationPredictor (modules/duration_predictor/standard_duration_predictor.py:13-61), same arguments and parameter
-names.  EXPERIMENTAL: not yet run on hardware."""
+names."""
 import torch.nn as nn
 
 from amphion_amd import _lib

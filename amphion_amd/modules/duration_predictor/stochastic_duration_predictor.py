@@ -1,6 +1,5 @@
 """StochasticDurationPredictor, inference direction (modules/duration_predictor/stochastic_duration_predictor.py:14-130),
-same arguments and state_dict keys (the posterior branch used only in training keeps its parameters so checkpoints load).
-EXPERIMENTAL: not yet run on hardware."""
+same arguments and state_dict keys (the posterior branch used only in training keeps its parameters so checkpoints load)."""
 import torch
 import torch.nn as nn
 

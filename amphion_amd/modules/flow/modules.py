@@ -120,7 +120,7 @@ class ResidualCouplingLayer(nn.Module):
         return x
 
 
-# ---- EXPERIMENTAL (not yet run on hardware): the pieces of the stochastic duration predictor ---------------------------
+# ---- the pieces of the stochastic duration predictor ---------------------------
 class DepthwiseConv1d(nn.Module):
     """Parameters of nn.Conv1d(C, C, K, groups=C, dilation=d, padding=(K*d - d)//2) under torch's key names; forward =
     ``amp_dwconv`` on x * mask."""

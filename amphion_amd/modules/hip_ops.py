@@ -124,7 +124,7 @@ def posterior_sample(stats, eps, lens):
     return z
 
 
-# ---- EXPERIMENTAL (not yet run on hardware): frame-rate ops of VITS' text -> duration -> alignment front ----------------
+# ---- frame-rate ops of VITS' text -> duration -> alignment front ----------------
 def _stream(t):
     return _lib.current_stream_ptr(t.device)
 

@@ -1,7 +1,7 @@
 """Encoder / MultiHeadAttention / FFN of the VITS text encoder (modules/transformer/attentions.py:16-77,165-358,361-417):
 same constructor arguments and parameter names; 1x1 / k-tap convs on the implicit-GEMM kernel, attention with
 windowed relative-position embeddings in ``amp_rel_attention``.  Masks are the valid lengths (int32 [B] on the device).
-EXPERIMENTAL: not yet run on hardware (tests/test_gpu_vits_infer.py, AMP_RUN_UNVERIFIED=1)."""
+GPU parity: tests/test_gpu_vits_infer.py."""
 from __future__ import annotations
 
 import torch

@@ -4,14 +4,21 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no torch.distributed environment launches its own N ranks (it re-executes
+itself through torch.distributed.run on 127.0.0.1); under an external launcher it reads RANK / LOCAL_RANK / WORLD_SIZE.
+
 A "step" is one forward of the hot path (HiFi-GAN V1 generator, mel -> waveform) over one batch of
 synthetic mels already resident in HBM: BASELINE.json configs[1] = B=64 x 80 mel x 256 frames per GPU
 (weak scaling: every rank runs its own B=64 shard; for N>1 the step includes the RCCL gather of the
-audio to rank 0).  Prints ONE JSON line on rank 0.
+audio to rank 0; before the timed region rank 0 checks that the gathered [64 N, L] tensor equals N
+single-GPU runs bit for bit).  Prints ONE JSON line on rank 0; at N = 1 the line also carries the CPU baseline, the
+PyTorch-ROCm library baseline and the other BASELINE.json configs (C3 BigVGAN, C5 VITS, mel front end, latency).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,7 +42,7 @@ PEAK_HBM_GBS = 8000.0
 # on MI355X (profiles/r1_mfma_peak_microbench.txt): the chip clocks down to ~1.6 GHz under MFMA load
 # (2192 TF on zeros, 1580-1630 TF on random data), so this -- not 2516.6 -- is what a perfect kernel gets.
 SUSTAINED_F16_TFLOPS = 1600.0
-PROFILE_TRAFFIC_CSV = os.path.join(ROOT, "profiles", "r1_v6_f16x3_fused_hbm_traffic.csv")
+PROFILE_TRAFFIC_CSV = os.path.join(ROOT, "profiles", "r2_hbm_traffic.csv")   # written by tools/summarize_prof.py from a PMC pass
 # arithmetic of the conv contractions -> (dtype string, peak for ALGORITHMIC flops, note)
 PRECISIONS = {
     "f16x3": ("f32 (split-f16 MFMA: 3 x v_mfma_f32_32x32x16_f16 per term, f32 accumulate)", PEAK_F16_TFLOPS / 3.0,
@@ -91,10 +98,103 @@ def cpu_baseline(sd, hp, budget_s=20.0):
         "unit": "samples/s",
         "x_realtime": samples / el / SAMPLE_RATE,
         "cores": torch.get_num_threads(),
+        "threads": torch.get_num_threads(),
+        "host_cores": os.cpu_count(),
         "kind": "port",
         "sample": f"{reps} x HiFi-GAN V1 forward at B={B}, T={T} (oracle/vocoder_oracle.py, torch CPU fp32, "
                   f"{torch.get_num_threads()} threads), {el:.1f} s",
+        "sample_note": "B=4 rather than the GPU line's B=64: one B=64 forward is ~30 s on this path (the same per-item "
+                       "work 16 times; torch's CPU convs do not speed up with batch), i.e. the whole bounded sample; "
+                       "threads = the measured optimum of tests/experiments/cpu_threads_sweep.py, not the host's core count",
     }
+
+
+def library_baseline(sd, hp, device, reps=3):
+    """The reference's op sequence (oracle/vocoder_oracle.py = hifigan.py:203-219 incl. the per-forward weight-norm
+    fold) run ON THE GPU through PyTorch-ROCm -- MIOpen convolutions + eager element-wise kernels -- at the bench
+    shape, i.e. what the unmodified reference gets on this MI355X.  A reported baseline beside
+    cpu_baseline, same checker-only use of oracle/."""
+    from amphion_amd.utils.synthetic import synthetic_mel
+    from oracle import vocoder_oracle as vo
+
+    sd_dev = {k: v.to(device) for k, v in sd.items()}
+    mel = synthetic_mel(B_PER_GPU, N_MEL, T_FRAMES, seed=0).to(device)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        vo.hifigan_forward(sd_dev, hp, mel)
+        torch.cuda.synchronize()
+        first = time.perf_counter() - t0
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            vo.hifigan_forward(sd_dev, hp, mel)
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    n = B_PER_GPU * T_FRAMES * 256
+    del sd_dev
+    torch.cuda.empty_cache()
+    return {"value": n / ms * 1e3, "unit": "samples/s", "x_realtime": n / ms * 1e3 / SAMPLE_RATE, "ms_per_step": ms,
+            "first_call_s": first, "kind": "reference ops on PyTorch-ROCm (MIOpen convs, eager element-wise, fp32)",
+            "sample": f"{reps} x HiFi-GAN V1 forward at B={B_PER_GPU}, T={T_FRAMES} on the same GPU, after one warm-up call "
+                      f"({first:.1f} s: MIOpen solver search)", "torch": torch.__version__}
+
+
+def conv_flop_per_frame(convs):
+    """sum of 2 * Cin * Cout * k * (outputs per mel frame) over (cin, cout, k, outputs_per_frame) tuples"""
+    return sum(2.0 * ci * co * k * m for ci, co, k, m in convs)
+
+
+def other_configs(reps=5):
+    """The other BASELINE.json configs on this GPU, driver-timed in the same run (product path only; runners in
+    tools/bench_configs.py), each with its own algorithmic cost and roofline fraction."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_configs as bc
+
+    out = {}
+    with torch.no_grad():
+        # C3 BigVGAN-base 24 kHz, B=32: convs = HiFi-GAN V1's with a 100-bin conv_pre; the 73 anti-aliased Snake
+        # activations are VALU work (per element: 2x up 12 taps, 2 Snake, 12-tap down), reported as their HBM bytes
+        r = bc.c3(reps)[0]
+        n = 32 * 256 * 256
+        flop = (FLOP_PER_SAMPLE_ALL + 2.0 * (100 - N_MEL) * 512 * 7 / 256) * n
+        r.update({"algorithmic_conv_tflop": flop / 1e12, "conv_tflops": flop / r["ms_per_step"] / 1e9,
+                  "frac_of_f16x3_mfma_peak": flop / r["ms_per_step"] / 1e9 / (PEAK_F16_TFLOPS / 3.0)})
+        out["c3_bigvgan"] = r
+        torch.cuda.empty_cache()
+        # C5 VITS decode path B=16: enc_q (513 -> 192, WN 16 x k5) + flow both ways (4 couplings x WN 4 x k5, twice) + decoder
+        r = bc.c5(reps)[0]
+        H = 192
+        wn = lambda layers, k: [(H, 2 * H, k, 1)] * layers + [(H, 2 * H, 1, 1)] * (layers - 1) + [(H, H, 1, 1)]
+        enc_q = [(513, H, 1, 1)] + wn(16, 5) + [(H, 2 * H, 1, 1)]
+        coupling = [(H // 2, H, 1, 1)] + wn(4, 5) + [(H, H // 2, 1, 1)]
+        frame_flop = conv_flop_per_frame(enc_q) + 2 * 4 * conv_flop_per_frame(coupling)
+        n = 16 * 256 * 256
+        flop = (FLOP_PER_SAMPLE_ALL + 2.0 * (H - N_MEL) * 512 * 7 / 256) * n + frame_flop * 16 * 256
+        r.update({"algorithmic_conv_tflop": flop / 1e12, "conv_tflops": flop / r["ms_per_step"] / 1e9,
+                  "frac_of_f16x3_mfma_peak": flop / r["ms_per_step"] / 1e9 / (PEAK_F16_TFLOPS / 3.0)})
+        out["c5_vits_decode"] = r
+        torch.cuda.empty_cache()
+        r = bc.mel(max(reps, 10))[0]
+        r.update({"algorithmic_bytes": 64 * 65536 * 4 + 64 * 80 * 256 * 4, "frac_of_hbm_peak": r["algorithmic_GBps"] / PEAK_HBM_GBS})
+        out["mel_front_end"] = r
+        out["latency"] = [x for x in bc.lat(reps) if "hipGraph" not in x["config"]]
+        torch.cuda.empty_cache()
+    return out
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def relaunch_command(argv, n):
+    """`python bench.py --gpus N` outside a launcher: the command that starts N ranks of this script on this node."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
 
 
 def main():
@@ -102,7 +202,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU, library and other-config legs (profiling runs)")
     ap.add_argument("--precision", choices=sorted(PRECISIONS), default="f16x3",
                     help="arithmetic of the conv contractions (include/amphion_hip.h: amp_precision)")
     args = ap.parse_args()
@@ -110,10 +210,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (the HIP path has no CPU fallback)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: start our own N ranks (one process per GPU, RCCL over xGMI) and pass their line through
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus}: this node exposes {torch.cuda.device_count()} GPU(s)")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.call(relaunch_command(sys.argv[1:], args.gpus), env=env))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -156,6 +262,20 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    gather_check = None
+    if world > 1:
+        # the gathered [64 N, L] tensor must equal N single-GPU runs bit for bit: rank 0 recomputes
+        # every rank's shard (same seeded mel, same weights) on its own GPU and compares -- untimed
+        got = step()
+        fence()
+        if rank == 0:
+            with torch.no_grad():
+                for r in range(world):
+                    ref = model(synthetic_mel(B_PER_GPU, N_MEL, T_FRAMES, seed=r).to(device)).squeeze(1)
+                    if not torch.equal(got[r * B_PER_GPU:(r + 1) * B_PER_GPU], ref):
+                        raise SystemExit(f"gather check FAILED: rows of rank {r} differ from a single-GPU run of its shard")
+            gather_check = f"gathered [{total_items}, {L}] == {world} single-GPU runs, bitwise"
+        dist.barrier()
     # HIP events around the kernel groups of EVERY timed forward, recorded on the launch stream without
     # synchronising (a ring of `steps` event sets inside the handle); read back after the closing fence.
     # dominant kernel: the fused ResBlock pairs of stage 1 (C=128), kernel 11 -- resblock j=2 of stage i=1 is
@@ -198,13 +318,17 @@ def main():
         dom_s = (sum(dom_ms) / len(dom_ms)) * 1e-3 / dom_launches
         dom_tflops = dom_flop / dom_s / 1e12
         traffic = None
-        kname = "pair_f16x3_kernel<11, 4, 1, 3, 192>" if fused else "conv_mfma_kernel<11, 4, 1, 8, 64>"
-        if fused and os.path.exists(PROFILE_TRAFFIC_CSV):              # PMC pass of an earlier run of this command
-            for line in open(PROFILE_TRAFFIC_CSV):
-                if kname in line:
-                    traffic = float(line.rsplit(",", 1)[1]) * 1e6      # FETCH_SIZE x2 (gfx950) + WRITE_SIZE, bytes/launch
+        strips = os.environ.get("AMP_PAIR_STRIP", "1") != "0"
+        kname = ("pair_strip_kernel<11, 4, 1, 3, *>" if strips else "pair_f16x3_kernel<11, 4, 1, 3, 192>") if fused else "conv_mfma_kernel<11, 4, 1, 8, 64>"
+        if fused and os.path.exists(PROFILE_TRAFFIC_CSV):              # PMC pass of an EARLIER run of this command (static)
+            tr = [float(line.rsplit(",", 1)[1]) * float(line.rsplit(",", 6)[1]) for line in open(PROFILE_TRAFFIC_CSV)
+                  if kname.split("*")[0] in line]
+            nl = [float(line.rsplit(",", 6)[1]) for line in open(PROFILE_TRAFFIC_CSV) if kname.split("*")[0] in line]
+            if tr:
+                traffic = sum(tr) / sum(nl) * 1e6                      # FETCH_SIZE x2 (gfx950) + WRITE_SIZE, bytes/launch
         roofline = {
-            "kernel": kname + (" (fused ResBlock pair, C=128, k=11: conv1 -> LDS -> conv2 + residual)" if fused else ""),
+            "kernel": kname + (" (fused ResBlock pair, C=128, k=11: conv1 -> LDS -> conv2 + residual; the three launches of "
+                               "resblock j=2 of stage 1, dilations 1 / 3 / 5)" if fused else ""),
             "bound": "mfma",
             "achieved": dom_tflops,
             "peak": peak_tflops,
@@ -212,8 +336,8 @@ def main():
             "unit": "TFLOP/s",
             "frac": dom_tflops / peak_tflops,
             "traffic": traffic,
-            "traffic_note": "HBM-side bytes per launch from rocprofv3 FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, "
-                            + os.path.relpath(PROFILE_TRAFFIC_CSV, ROOT) if traffic else None,
+            "traffic_source": ("static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command "
+                               "(FETCH x2 gfx950 correction), " + os.path.relpath(PROFILE_TRAFFIC_CSV, ROOT)) if traffic else None,
             "algorithmic_flop_per_launch": dom_flop,
             "algorithmic_bytes_per_launch": dom_bytes,
             "launch_us": dom_s * 1e6,
@@ -254,7 +378,12 @@ def main():
             },
             "roofline": roofline,
         }
+        if gather_check:
+            result["gather_check"] = gather_check
         if not args.no_cpu_baseline and world == 1:
+            del out
+            result["other_configs"] = other_configs()
+            result["library_baseline"] = library_baseline(sd, hp, device)
             result["cpu_baseline"] = cpu_baseline(sd, hp)
         print(json.dumps(result))
     if world > 1:

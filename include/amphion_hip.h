@@ -120,6 +120,12 @@ size_t amp_gen_workspace_bytes(const amp_gen* g, int B, int T);
  * Results do not depend on it. */
 int amp_set_group_mb(int megabytes);
 
+/* Fused ResBlock pairs (hifigan.py:93-100) run the per-tile kernel -- 0, the default -- or the strip-mined kernel (a
+ * workgroup walks a strip of one utterance and carries conv2's halo in LDS; also covers C = 256) -- 1; also the
+ * environment variable AMP_PAIR_STRIP.  Results are bit-identical (tests/test_gpu_pair.py); a tuning / cross-check
+ * switch. */
+int amp_set_pair_strips(int on);
+
 /* Replaces HiFiGAN.forward (hifigan.py:203-219), BigVGAN.forward (bigvgan.py:313-331) and
  * HiFiGAN_vits.forward (hifigan.py:424-443):  mel_dev [B, n_in, T]  ->  wav_dev [B, 1, T*hop].
  * cond_dev: optional speaker embedding g [B, gin_channels, 1] (HiFiGAN_vits), else NULL. */
@@ -188,7 +194,7 @@ typedef enum amp_pad_mode { AMP_PAD_REPLICATE = 0, AMP_PAD_ZEROS = 1, AMP_PAD_RE
 int amp_fir_filter(const float* x_dev, int B, int C, int T, const float* filt_host, int K, int stride, int pad_left,
                    int pad_right, int pad_mode, float* y_dev, void* stream);
 
-/* ---- EXPERIMENTAL (not yet run on hardware): frame-rate ops of the text -> duration -> alignment front of VITS
+/* ---- frame-rate ops of the text -> duration -> alignment front of VITS
  * inference, SynthesizerTrn.infer models/tts/vits/vits.py:320-369.  All tensors [B, C, T] fp32 on the
  * device; lens_dev = int32 [B] valid lengths (NULL = all T). ---- */
 /* LayerNorm over channels (modules/base/base_module.py:20-23) of x (+ res if not NULL: Encoder's norm(x + y),

@@ -1,4 +1,5 @@
-"""GPU parity: the fused ResBlock1-pair kernel (pair_f16x3.hip) vs the oracle ops, hifigan.py:93-100."""
+"""GPU parity: the fused ResBlock1-pair kernels (strip-mined pair_strip_f16x3.hip, the default, and the per-tile
+pair_f16x3.hip) vs the oracle ops, hifigan.py:93-100, and against each other / the unfused conv sequence bit for bit."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -33,15 +34,87 @@ PAIR_CASES = [
     (32, 5, 6, 2, 333),       # k5 (recipe net), dilation 6
     (128, 5, 2, 1, 64),
     (64, 11, 5, 1, 1),        # T = 1
+    (256, 3, 1, 1, 200),      # C = 256 (stage 0 of HiFi-GAN V1): 8-wave strip kernel only
+    (256, 11, 5, 2, 97),
+    (256, 7, 3, 1, 1031),
+]
+# shapes that make a workgroup walk several steps of a strip (many more columns than 512 workgroups x one step)
+STRIP_CASES = [
+    # C, k, dilation, B, T
+    (128, 11, 5, 40, 2000),
+    (128, 3, 1, 64, 1100),
+    (64, 7, 3, 70, 1500),
+    (32, 11, 1, 33, 5000),
+    (256, 11, 3, 48, 700),
+    (128, 7, 5, 1, 70000),    # one long utterance
 ]
 
 
-@pytest.mark.parametrize("C,k,d,B,T", PAIR_CASES)
-def test_pair_matches_oracle(C, k, d, B, T):
+def _pair_inputs(C, k, B, T):
+    w1 = _rand(C, C, k, seed=1, scale=(C * k) ** -0.5)
+    b1 = _rand(C, seed=2, scale=0.1)
+    w2 = _rand(C, C, k, seed=3, scale=(C * k) ** -0.5)
+    b2 = _rand(C, seed=4, scale=0.1)
+    return w1, b1, w2, b2, _rand(B, C, T, seed=5)
+
+
+@pytest.fixture
+def strips():
+    """Switches the fused pairs to the strip-mined kernel (amp_set_pair_strips) for one call sequence."""
+    from amphion_amd import _lib
+
+    def use(on):
+        _lib.check(_lib.lib().amp_set_pair_strips(1 if on else 0))
+    yield use
+    _lib.check(_lib.lib().amp_set_pair_strips(0))
+
+
+@pytest.mark.parametrize("C,k,d,B,T", [c for c in PAIR_CASES if c[0] <= 128] + [c for c in STRIP_CASES if c[0] <= 128])
+def test_strip_kernel_equals_tile_kernel_bitwise(C, k, d, B, T, strips):
+    """Per output element both kernels run the same operations in the same order: however the time axis is cut
+    (tiles of 86 columns or strips of many 96-column steps) the result has the same bits."""
     from amphion_amd import _lib
     from hip_helpers import pair_forward
 
     _lib.set_precision("f16x3")
+    w1, b1, w2, b2, x = _pair_inputs(C, k, B, T)
+    y_tile = pair_forward(w1, b1, w2, b2, x, dilation=d)
+    strips(True)
+    y_strip = pair_forward(w1, b1, w2, b2, x, dilation=d)
+    strips(False)
+    assert not torch.isnan(y_strip).any()
+    assert torch.equal(y_strip, y_tile)
+
+
+@pytest.mark.parametrize("C,k,d,B,T", STRIP_CASES + [c for c in PAIR_CASES if c[0] == 256])
+def test_strip_partition_invariance_and_oracle(C, k, d, B, T, strips):
+    """The strip plan depends on (B, T): a batch walks long strips, a single item many short ones.  Every item of the
+    batch must equal that item run alone bit for bit (the only bitwise cross-check for C = 256, which the per-tile
+    kernel does not cover), and the probed items must match the fp64 oracle."""
+    from amphion_amd import _lib
+    from hip_helpers import pair_forward
+
+    _lib.set_precision("f16x3")
+    strips(True)
+    w1, b1, w2, b2, x = _pair_inputs(C, k, B, T)
+    y = pair_forward(w1, b1, w2, b2, x, dilation=d)
+    assert not torch.isnan(y).any()
+    for b in sorted({0, B // 2, B - 1}):
+        y1 = pair_forward(w1, b1, w2, b2, x[b:b + 1], dilation=d)
+        assert torch.equal(y[b:b + 1], y1), f"item {b}"
+        Tp = min(T, 6000)   # oracle on a prefix: exact for the first Tp - receptive field columns
+        ref = _ref(w1.double(), b1.double(), w2.double(), b2.double(), x[b:b + 1, :, :Tp].double(), d, 0.1)
+        keep = Tp if Tp == T else Tp - (k - 1) * (d + 1)
+        assert (y1[..., :keep].double() - ref[..., :keep]).abs().max().item() <= 5e-6
+
+
+@pytest.mark.parametrize("C,k,d,B,T", PAIR_CASES)
+def test_pair_matches_oracle(C, k, d, B, T, strips):
+    from amphion_amd import _lib
+    from hip_helpers import pair_forward
+
+    _lib.set_precision("f16x3")
+    strips(C == 256)            # C = 256 is covered by the strip-mined kernel only
     w1 = _rand(C, C, k, seed=1, scale=(C * k) ** -0.5)
     b1 = _rand(C, seed=2, scale=0.1)
     w2 = _rand(C, C, k, seed=3, scale=(C * k) ** -0.5)
