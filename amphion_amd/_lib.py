@@ -60,6 +60,7 @@ class amp_mel_desc(ctypes.Structure):
         ("pad_mode", c_int32),
         ("mag_eps", c_float),
         ("log_clip", c_float),
+        ("mel_bands_dev", c_void_p),
     ]
 
 
@@ -76,6 +77,7 @@ _SIGNATURES = {
     "amp_gen_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "amp_set_group_mb": (c_int, [c_int]),
     "amp_set_pair_strips": (c_int, [c_int]),
+    "amp_range_check": (c_int, [c_void_p]),
     "amp_gen_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "amp_gen_forward_ragged": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "amp_gen_set_profiling": (c_int, [c_void_p, c_int]),
@@ -116,6 +118,7 @@ _SIGNATURES = {
     "amp_istft_forward": (c_int, [POINTER(amp_mel_desc), c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "amp_mel_num_frames": (c_int, [POINTER(amp_mel_desc), c_int]),
     "amp_mel_forward_ragged": (c_int, [POINTER(amp_mel_desc), c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "amp_mel_backward": (c_int, [POINTER(amp_mel_desc), c_void_p, c_int, c_int] + [c_void_p] * 11),
     "amp_mel_forward": (c_int, [POINTER(amp_mel_desc), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
@@ -158,6 +161,20 @@ def check(status):
     if status < 0:
         raise AmpError(status, lib().amp_last_error().decode("utf-8", "replace"))
     return status
+
+
+AMP_ERR_RANGE = -6
+
+
+def range_check(device=None):
+    """Synchronise the current stream of ``device`` and raise ``AmpError`` (status AMP_ERR_RANGE) if any f16x3 launch
+    since the last check staged an activation beyond the split-f16 operand range (|x| > 4094 or non-finite): the
+    output of that launch is not the fp32 reference's (``amp_range_check``)."""
+    import torch
+
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(dev):
+        check(lib().amp_range_check(current_stream_ptr(dev)))
 
 
 def require_device_tensor(t, name="tensor"):

@@ -46,6 +46,7 @@ struct ConvArgs {
     // layer zero-pads at the utterance's OWN end, so a padded batch equals the per-utterance results)
     const int* lens;            // [B] on the device, or nullptr (all items valid on [0, Tin))
     int len_mul;
+    unsigned* range_flag;       // f16x3: set to 1 when a staged operand leaves the f16 range (|x| * 16 > 65504) or is not finite
     int pad_reflect;            // 1: out-of-range columns mirror (nn.ReflectionPad1d + unpadded conv, melgan.py:39,56,92)
     int tanh_out;               // 1: tanh on store (melgan.py:94)
 };
@@ -72,6 +73,7 @@ struct PairArgs {
     float div;
     const int* lens;           // ragged batches, see ConvArgs
     int len_mul;
+    unsigned* range_flag;      // see ConvArgs
 };
 
 struct ConvPlan {
@@ -136,6 +138,12 @@ hipError_t launch_mel(const amp_mel_desc& d, const float* wav, const int* lens, 
                       const float* melbasis, float* mel, float* mag, float* re, float* im, hipStream_t stream);
 
 void set_error(const char* fmt, ...);
+
+// The f16x3 kernels stage fp32 activations as hi + lo f16 pairs after an exact x16: anything beyond |x| = 4094 (or
+// non-finite) cannot be represented.  They OR 1 into this per-device word when that happens (range_guard.hip).
+unsigned* range_flag_for_current_device();
+// true when `v` (already scaled) does not fit the f16 operand range
+__device__ __forceinline__ bool f16_range_bad(float v) { return !(__builtin_fabsf(v) <= 65504.f); }
 
 // v = hi + lo with hi = f16(v), lo = f16(v - hi): the split-f16 operand form of the f16x3 kernels.
 // The empty asm makes `v` opaque: under HIP's default -ffp-contract=fast hipcc otherwise folds the

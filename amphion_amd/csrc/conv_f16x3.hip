@@ -151,6 +151,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
     // lose its vmcnt bookkeeping), stage_store applies the zero padding as a select, then leaky_relu,
     // the x16 scaling and the hi/lo split.  4*S is a multiple of 256 and S of 64: every thread has
     // exactly NST items and an item's quad is wave-uniform.
+    bool range_bad = false;      // any staged operand outside the f16 range (reported through a.range_flag)
     float xs[NST][4];
     auto stage_load = [&](int chunk) {
 #pragma unroll
@@ -189,6 +190,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
             for (int e = 0; e < 4; ++e) {
                 float v = (tok && (ch0 + e) < a.Cin) ? xs[it][e] : 0.f;
                 v = v * (v > 0.f ? kpos : kneg);
+                range_bad |= f16_range_bad(v);
                 split_f16(v, fh.h[e], fl.h[e]);
             }
             // uint2 index inside a plane: ((octet * S + col) * 2 + half)
@@ -251,6 +253,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
         if (more) stage_store(c + 1, (c + 1) & 1);
         __syncthreads();
     }
+
+    if (a.range_flag && __any(range_bad) && lane == 0) atomicOr(a.range_flag, 1u);
 
     // ---- epilogue: undo the operand scaling, MRF mean, activation-on-store, (polyphase) scatter ----
     const float slope_out = a.slope_out;
@@ -361,12 +365,14 @@ static hipError_t launch_one_h(const ConvArgs& a, hipStream_t stream) {
     constexpr int NT = 32 * NI * WN;
     constexpr int S = NT + HALO;
     const size_t lds = (size_t)2 * 4 * S * sizeof(uint4);
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
+    static unsigned long long attr_set = 0;   // per device: the attribute belongs to that device's copy of the function
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!((attr_set >> dev) & 1ull) && lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16x3_kernel<KT, WM, WN, NI, HALO>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set |= 1ull << dev;
     }
     dim3 grid((unsigned)(a.B * a.tiles_per_item), (unsigned)((a.M + 32 * WM - 1) / (32 * WM)));
     hipLaunchKernelGGL((conv_f16x3_kernel<KT, WM, WN, NI, HALO>), grid, dim3(256), lds, stream, a);

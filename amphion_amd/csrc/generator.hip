@@ -55,6 +55,74 @@ hipError_t launch_conv_h_kt11(const ConvPlan&, const ConvArgs&, hipStream_t);
 
 static const int kSupportedKT[] = {1, 2, 3, 5, 7, 11};
 
+// ---- f16 operand-range guard -------------------------------------------------------------------------------------
+// The f16x3 kernels OR 1 into a per-device word when a staged operand does not fit the split-f16 form (|x| > 4094
+// after the exact x16, or non-finite): the fp32 reference has no such cliff, so the result of that launch is NOT the
+// reference's.  amp_gen_forward copies the word to pinned host memory behind its last kernel (no synchronisation) and
+// the NEXT call on that device that finds the copy complete returns AMP_ERR_RANGE; amp_range_check() synchronises and
+// reports immediately.  Both clear the word.
+struct RangeGuard {
+    unsigned* dev = nullptr;       // device word the kernels write
+    unsigned* host = nullptr;      // pinned mirror
+    hipEvent_t ev = nullptr;
+    bool pending = false;          // an async copy of `dev` is in flight / unread
+};
+static RangeGuard g_guard[64];
+
+static RangeGuard* guard_for_current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    RangeGuard& g = g_guard[dev];
+    if (!g.dev) {
+        if (hipMalloc(&g.dev, sizeof(unsigned)) != hipSuccess) { g.dev = nullptr; return nullptr; }
+        if (hipMemset(g.dev, 0, sizeof(unsigned)) != hipSuccess || hipHostMalloc(&g.host, sizeof(unsigned)) != hipSuccess ||
+            hipEventCreateWithFlags(&g.ev, hipEventDisableTiming) != hipSuccess) {
+            (void)hipFree(g.dev);
+            g.dev = nullptr;
+            return nullptr;
+        }
+        *g.host = 0;
+    }
+    return &g;
+}
+
+unsigned* range_flag_for_current_device() {
+    RangeGuard* g = guard_for_current_device();
+    return g ? g->dev : nullptr;
+}
+
+static bool stream_is_capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+}
+
+static const char kRangeMsg[] =
+    "an activation left the split-f16 operand range of the f16x3 kernels (|x| > 4094 or non-finite) in a previous "
+    "launch on this device: its output is not the fp32 reference's; re-run with amp_set_precision(AMP_PRECISION_F32)";
+
+// non-blocking: reports (and clears) a flag whose copy has already landed
+static int range_poll(hipStream_t st) {
+    RangeGuard* g = guard_for_current_device();
+    if (!g || !g->pending || stream_is_capturing(st)) return AMP_OK;
+    if (hipEventQuery(g->ev) != hipSuccess) return AMP_OK;       // still in flight
+    g->pending = false;
+    if (*g->host == 0) return AMP_OK;
+    *g->host = 0;
+    AMP_HIP(hipMemsetAsync(g->dev, 0, sizeof(unsigned), st));
+    set_error("%s", kRangeMsg);
+    return AMP_ERR_RANGE;
+}
+
+// enqueue the copy of the flag behind everything launched so far on `st`
+static int range_publish(hipStream_t st) {
+    RangeGuard* g = guard_for_current_device();
+    if (!g || stream_is_capturing(st)) return AMP_OK;
+    AMP_HIP(hipMemcpyAsync(g->host, g->dev, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    AMP_HIP(hipEventRecord(g->ev, st));
+    g->pending = true;
+    return AMP_OK;
+}
+
 // Process-wide default for handles created from now on: AMP_PRECISION=f32|f16x3, amp_set_precision().
 static int g_precision = -1;
 static int default_precision() {
@@ -369,6 +437,7 @@ static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope
     a.slope_in = slope_in; a.slope_out = slope_out; a.mode = mode; a.div = div;
     a.lens = lens; a.len_mul = len_mul;
     a.pad_reflect = c->pad_reflect; a.tanh_out = c->tanh_out;
+    a.range_flag = c->precision == PREC_F16X3 ? range_flag_for_current_device() : nullptr;
     if (c->pad_reflect && (c->halo_left >= T || c->halo_right >= T)) {
         set_error("amp_conv_forward: reflection padding %d needs more than %d input samples", c->halo_left > c->halo_right ? c->halo_left : c->halo_right, T);
         return AMP_ERR_INVALID;
@@ -411,10 +480,12 @@ static int pair_run(const amp_conv* c1, const amp_conv* c2, const float* x, int 
     a.sc2 = 16.f * c2->wscale; a.isc2 = 1.f / a.sc2;
     a.mode = mode; a.div = div;
     a.lens = lens; a.len_mul = len_mul;
+    a.range_flag = range_flag_for_current_device();
     int wg = 2;
     const int n1 = pair_strips_enabled() ? strip_step(c1->k, c1->cin, c1->dilation, &wg) : 0;
     if (n1 > 0) {
         strip_plan(B, T, n1, c1->k - 1, wg, &a.strip_len, &a.strips_per_item);
+        { const char* e = getenv("AMP_STRIP_STEPS"); if (e && atoi(e) > 0) { a.strip_len = atoi(e) * n1 - (c1->k - 1); a.strips_per_item = (T + a.strip_len - 1) / a.strip_len; } }
         { const char* e = getenv("AMP_STRIP_SPI_MUL"); if (e && atoi(e) > 1) { a.strips_per_item *= atoi(e); a.strip_len = (T + a.strips_per_item - 1) / a.strips_per_item; } }
         { const char* e = getenv("AMP_STRIP_STAGGER"); a.stagger = e ? atoi(e) : 0; e = getenv("AMP_STRIP_STAGGER_MODE"); a.stagger_mode = e ? atoi(e) : 1; }
         AMP_HIP(launch_strip(c1->k, a, stream));
@@ -986,6 +1057,7 @@ int amp_gen_forward_ragged(amp_gen* g, const float* mel_dev, const float* cond_d
     if (workspace_bytes < amp_gen_workspace_bytes(g, B, T)) { set_error("amp_gen_forward: workspace too small (%zu < %zu)", workspace_bytes, amp_gen_workspace_bytes(g, B, T)); return AMP_ERR_INVALID; }
     if (cond_dev && !g->cond) { set_error("amp_gen_forward: cond given but gin_channels == 0"); return AMP_ERR_INVALID; }
     hipStream_t st = (hipStream_t)stream_;
+    AMP_RC(range_poll(st));            // a previous forward left the f16 operand range: say so now
     const amp_gen_desc& d = g->d;
     const int G = gen_group_items(g, B, T);
     const int ngroups = (B + G - 1) / G;
@@ -1019,7 +1091,24 @@ int amp_gen_forward_ragged(amp_gen* g, const float* mel_dev, const float* cond_d
                                  ps ? ps->ev_rb.data() + (size_t)d.n_stages * (d.n_kernels + 1) * gi : nullptr));
     }
     if (ps) { AMP_HIP(hipEventRecord(ps->ev_end, st)); ps->valid = true; ++g->prof_count; }
+    AMP_RC(range_publish(st));
     return AMP_OK;
+}
+
+int amp_range_check(void* stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    RangeGuard* g = guard_for_current_device();
+    if (!g) return AMP_OK;             // nothing has run on this device yet
+    if (stream_is_capturing(st)) { set_error("amp_range_check: the stream is capturing"); return AMP_ERR_STATE; }
+    unsigned v = 0;
+    AMP_HIP(hipMemcpyAsync(&v, g->dev, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    AMP_HIP(hipStreamSynchronize(st));
+    g->pending = false;
+    *g->host = 0;
+    if (v == 0) return AMP_OK;
+    AMP_HIP(hipMemsetAsync(g->dev, 0, sizeof(unsigned), st));
+    set_error("%s", kRangeMsg);
+    return AMP_ERR_RANGE;
 }
 
 void amp_gen_destroy(amp_gen* g) { delete g; }
@@ -1139,6 +1228,8 @@ int amp_conv_set_option(amp_conv* c, int option, int value) {
         if (value && c->transposed) { set_error("amp_conv_set_option: reflection padding on a transposed conv"); return AMP_ERR_UNSUPPORTED; }
         c->pad_reflect = value != 0;
     } else if (option == AMP_CONV_OPT_TANH) {
+        // the polyphase scatter epilogues of a transposed conv apply leaky-ReLU only (conv_f16x3.hip)
+        if (value && c->transposed) { set_error("amp_conv_set_option: tanh on a transposed conv"); return AMP_ERR_UNSUPPORTED; }
         c->tanh_out = value != 0;
     } else {
         set_error("amp_conv_set_option: unknown option %d", option);

@@ -1,5 +1,7 @@
-// Mel / STFT front end on gfx950: framing (reflect padding) * window -> radix-2 Stockham FFT in LDS ->
-// |X| -> mel filterbank -> log, one workgroup per frame, nothing but the final features leaves the CU.
+// Mel / STFT front end on gfx950: framing (reflect padding) * window -> FFT -> |X| -> mel filterbank -> log in one
+// kernel; nothing but the final features leaves the CU.  n_fft = 1024 runs mel1024_kernel (one wave per frame,
+// radix-8 real FFT, lane-constant twiddles, 128-B row stores); any other power of two the generic mel_kernel below
+// (radix-2 Stockham FFT in LDS, one workgroup per frame).
 //
 // Replaces utils/mel.py:20-170 (torch.stft + sqrt + matmul + log as 5 separate tensor ops) and the
 // conv1d-with-Fourier-basis STFT of utils/stft.py:152-181,259-278 (TacotronSTFT).
@@ -92,15 +94,254 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ wav,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// n_fft = 1024 (every 22.05 / 24 kHz config of the reference: config/fs2.json:25-31, config/vocoder.json:34-40,
+// config/vits.json): one WAVE per frame, radix-8, real-input FFT, nothing recomputed per frame.
+//
+//   z[m] = x[2m] + i x[2m+1]  (m < 512)  ->  512-point complex FFT as 8 x 8 x 8 Stockham passes: lane j owns the
+//   radix-8 butterfly j of each pass (8 complex values in registers); between passes the wave exchanges through its
+//   own 4 KB of LDS (no workgroup barrier: LDS operations of one wave execute in order)  ->  real-FFT split
+//   X[k] = E - i W^k O with the partner Z[512 - k] fetched by a lane permute  ->  |X| -> LDS  ->  mel filterbank
+//   over each filter's non-zero band  ->  log  ->  LDS tile [mel][32 frames]  ->  128-B row stores.
+//
+// The twiddles of passes 1 / 2 and of the split depend only on (lane, q): computed once per wave with sincospif
+// and held in registers for all its frames, like the 16 window values of the lane's sample slots.  A workgroup is
+// 8 waves x 4 frames = 32 consecutive frames of one utterance: the samples are read straight from global memory
+// (each lane 2 consecutive samples per slot = one 512-B wave access; the 4x frame overlap is served by L1 / L2).
+// mag / re / im outputs (extract_linear_features, amplitude_phase_spectrum) are written per frame at stride F.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// in-place 8-point DFT (forward, e^{-2 pi i / 8}), natural order in, natural order out
+__device__ __forceinline__ void dft8(float2 (&v)[8]) {
+    const float h = 0.70710678118654752440f;
+    // stage 1: pairs (q, q + 4)
+    float2 a0 = make_float2(v[0].x + v[4].x, v[0].y + v[4].y), a4 = make_float2(v[0].x - v[4].x, v[0].y - v[4].y);
+    float2 a1 = make_float2(v[1].x + v[5].x, v[1].y + v[5].y), a5 = make_float2(v[1].x - v[5].x, v[1].y - v[5].y);
+    float2 a2 = make_float2(v[2].x + v[6].x, v[2].y + v[6].y), a6 = make_float2(v[2].x - v[6].x, v[2].y - v[6].y);
+    float2 a3 = make_float2(v[3].x + v[7].x, v[3].y + v[7].y), a7 = make_float2(v[3].x - v[7].x, v[3].y - v[7].y);
+    // twiddles of the odd half: a5 *= w8, a6 *= -i, a7 *= w8^3
+    a5 = make_float2((a5.x + a5.y) * h, (a5.y - a5.x) * h);
+    a6 = make_float2(a6.y, -a6.x);
+    a7 = make_float2((a7.y - a7.x) * h, -(a7.x + a7.y) * h);
+    // stage 2: 4-point DFTs of (a0, a1, a2, a3) -> even outputs, (a4, a5, a6, a7) -> odd outputs
+    float2 b0 = make_float2(a0.x + a2.x, a0.y + a2.y), b2 = make_float2(a0.x - a2.x, a0.y - a2.y);
+    float2 b1 = make_float2(a1.x + a3.x, a1.y + a3.y), b3 = make_float2(a1.x - a3.x, a1.y - a3.y);
+    b3 = make_float2(b3.y, -b3.x);
+    float2 c0 = make_float2(a4.x + a6.x, a4.y + a6.y), c2 = make_float2(a4.x - a6.x, a4.y - a6.y);
+    float2 c1 = make_float2(a5.x + a7.x, a5.y + a7.y), c3 = make_float2(a5.x - a7.x, a5.y - a7.y);
+    c3 = make_float2(c3.y, -c3.x);
+    v[0] = make_float2(b0.x + b1.x, b0.y + b1.y);
+    v[4] = make_float2(b0.x - b1.x, b0.y - b1.y);
+    v[2] = make_float2(b2.x + b3.x, b2.y + b3.y);
+    v[6] = make_float2(b2.x - b3.x, b2.y - b3.y);
+    v[1] = make_float2(c0.x + c1.x, c0.y + c1.y);
+    v[5] = make_float2(c0.x - c1.x, c0.y - c1.y);
+    v[3] = make_float2(c2.x + c3.x, c2.y + c3.y);
+    v[7] = make_float2(c2.x - c3.x, c2.y - c3.y);
+}
+
+// cos / sin of pi q / 8, q = 0..7: exp(-2 pi i q / 16) of the real-FFT split
+__device__ constexpr float kC16[8] = {1.f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f,
+                                      0.f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f};
+__device__ constexpr float kS16[8] = {0.f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f,
+                                      1.f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f};
+
+constexpr int MEL_WAVES = 8;       // waves per workgroup
+constexpr int MEL_FPW = 4;         // frames per wave
+constexpr int MEL_FPB = MEL_WAVES * MEL_FPW;   // 32 frames per workgroup: one 128-B row of every mel channel
+constexpr int MEL_XROW = 10;       // exchange-buffer row: 8 complex + 2 pad (80 B: the 16-B stores of pass 0 stay aligned)
+constexpr int MEL_MAGROW = 520;    // 513 bins, padded
+constexpr int MEL_MAXMEL = 256;
+
+__global__ __launch_bounds__(64 * MEL_WAVES, 4) void mel1024_kernel(const float* __restrict__ wav, const int* __restrict__ lens,
+                                                                  int L, int F, int hop, int pad, int n_mel, float mag_eps,
+                                                                  float log_clip, const float* __restrict__ window,
+                                                                  const float* __restrict__ melbasis,
+                                                                  const int* __restrict__ bands, float* __restrict__ mel,
+                                                                  float* __restrict__ mag, float* __restrict__ re_out,
+                                                                  float* __restrict__ im_out) {
+    constexpr int N = 1024, M = 512, BINS = 513;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float2* const xch = reinterpret_cast<float2*>(smem);                      // [MEL_WAVES][64 * MEL_XROW]
+    float* const magl = smem + 2 * MEL_WAVES * 64 * MEL_XROW;                 // [MEL_WAVES][MEL_MAGROW]
+    float* const melt = magl + MEL_WAVES * MEL_MAGROW;                        // [n_mel][MEL_FPB + 1]
+    const int tid = threadIdx.x;
+    const int j = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fblocks = (F + MEL_FPB - 1) / MEL_FPB;
+    const int b = blockIdx.x / fblocks;
+    const int f0 = (blockIdx.x - b * fblocks) * MEL_FPB;
+    const float* wb = wav + (size_t)b * L;
+    // ragged batch: item b holds lens[b] samples; its reflection padding mirrors at ITS end and it has
+    // (lens[b] + 2*pad - n_fft) / hop + 1 frames -- later frames of the row are left untouched
+    int Li = L, Fi = F;
+    if (lens) {
+        Li = lens[b] < L ? lens[b] : L;
+        Fi = Li <= pad ? 0 : (Li + 2 * pad - N) / hop + 1;
+        Fi = Fi < F ? Fi : F;
+    }
+    if (f0 >= Fi) return;   // workgroup-uniform
+
+    // lane constants: twiddles (the 16 window values of the lane's sample slots are re-read per frame: L1 hits,
+    // and 16 registers fewer keep two workgroups per CU)
+    const float2* win = reinterpret_cast<const float2*>(window) + j;
+    float2 tw1[8], tw2[8];
+    const int k1 = j & 7;
+#pragma unroll
+    for (int q = 1; q < 8; ++q) {
+        float sn, cs;
+        sincospif(-2.0f * (float)(q * k1) / 64.0f, &sn, &cs);     // pass 1: exp(-2 pi i q k / 64),  k = j mod 8
+        tw1[q] = make_float2(cs, sn);
+        sincospif(-2.0f * (float)(q * j) / 512.0f, &sn, &cs);     // pass 2: exp(-2 pi i q j / 512)
+        tw2[q] = make_float2(cs, sn);
+    }
+    float2 wsp;                                                   // split: exp(-2 pi i j / 1024)
+    {
+        float sn, cs;
+        sincospif(-2.0f * (float)j / 1024.0f, &sn, &cs);
+        wsp = make_float2(cs, sn);
+    }
+    float2* xw = xch + w * (64 * MEL_XROW);
+    float* mg = magl + w * MEL_MAGROW;
+
+    for (int fi = 0; fi < MEL_FPW; ++fi) {
+        const int fl = w * MEL_FPW + fi;            // frame inside the workgroup tile
+        const int f = f0 + fl;
+        if (f >= Fi) break;                         // wave-uniform
+        float2 v[8];
+        const int s0 = f * hop - pad + 2 * j;
+        if (s0 - 2 * j >= 0 && f * hop - pad + N <= Li) {          // interior frame (wave-uniform): no reflection
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float* p = wb + s0 + 128 * q;
+                const float2 wq = win[64 * q];
+                v[q] = make_float2(p[0] * wq.x, p[1] * wq.y);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int s = s0 + 128 * q;
+                const float2 wq = win[64 * q];
+                v[q] = make_float2(wb[reflect_index(s, Li)] * wq.x, wb[reflect_index(s + 1, Li)] * wq.y);
+            }
+        }
+        // pass 0 (Ns = 1): no twiddles; out[8 j + q]
+        dft8(v);
+        {
+            float4* row = reinterpret_cast<float4*>(xw + j * MEL_XROW);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) row[q] = make_float4(v[2 * q].x, v[2 * q].y, v[2 * q + 1].x, v[2 * q + 1].y);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // pass 1 (Ns = 8): in[j + 64 q] -> twiddle exp(-2 pi i q k / 64) -> out[8 (j - k) + k + 8 q]
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = j + 64 * q;
+            v[q] = xw[(i >> 3) * MEL_XROW + (i & 7)];
+        }
+#pragma unroll
+        for (int q = 1; q < 8; ++q) v[q] = cmul(v[q], tw1[q]);
+        dft8(v);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = 8 * (j - k1) + k1 + 8 * q;
+            xw[(i >> 3) * MEL_XROW + (i & 7)] = v[q];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // pass 2 (Ns = 64): in[j + 64 q] -> twiddle exp(-2 pi i q j / 512) -> Z[j + 64 q]
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = j + 64 * q;
+            v[q] = xw[(i >> 3) * MEL_XROW + (i & 7)];
+        }
+#pragma unroll
+        for (int q = 1; q < 8; ++q) v[q] = cmul(v[q], tw2[q]);
+        dft8(v);
+        __builtin_amdgcn_wave_barrier();
+        // real-FFT split, k = j + 64 q: partner Z[512 - k] sits in lane (64 - j) & 63, register 7 - q (lane 0: (8 - q) & 7)
+        const int src = (64 - j) & 63;
+        const size_t ob = ((size_t)b * BINS) * F + f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float2 zp = make_float2(__shfl(v[7 - q].x, src, 64), __shfl(v[7 - q].y, src, 64));
+            if (j == 0) zp = v[(8 - q) & 7];
+            const float2 z = v[q];
+            const float2 e = make_float2(0.5f * (z.x + zp.x), 0.5f * (z.y - zp.y));       // (Z + conj Zp) / 2
+            const float2 o = make_float2(0.5f * (z.x - zp.x), 0.5f * (z.y + zp.y));       // (Z - conj Zp) / 2
+            // W^k = wsp * exp(-2 pi i q / 16)
+            const float2 wk = cmul(wsp, make_float2(kC16[q], -kS16[q]));
+            const float2 t = cmul(wk, o);                                                 // X = E - i W^k O
+            const float2 x = make_float2(e.x + t.y, e.y - t.x);
+            const int k = j + 64 * q;
+            const float m = sqrtf(x.x * x.x + x.y * x.y + mag_eps);
+            mg[k] = m;
+            if (mag) mag[ob + (size_t)k * F] = m;
+            if (re_out) re_out[ob + (size_t)k * F] = x.x;
+            if (im_out) im_out[ob + (size_t)k * F] = x.y;
+            if (q == 0 && j == 0) {                                                       // Nyquist bin from Z[0]
+                const float xn = z.x - z.y;
+                const float mn = sqrtf(xn * xn + mag_eps);
+                mg[M] = mn;
+                if (mag) mag[ob + (size_t)M * F] = mn;
+                if (re_out) re_out[ob + (size_t)M * F] = xn;
+                if (im_out) im_out[ob + (size_t)M * F] = 0.f;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (mel) {
+            for (int m = j; m < n_mel; m += 64) {
+                const int lo = bands ? bands[2 * m] : 0;
+                const int hi = bands ? bands[2 * m + 1] : BINS;
+                const float* row = melbasis + (size_t)m * BINS;
+                float acc = 0.f;
+                for (int k = lo; k < hi; ++k) acc = fmaf(row[k], mg[k], acc);
+                if (log_clip > 0.f) acc = logf(fmaxf(acc, log_clip));
+                melt[m * (MEL_FPB + 1) + fl] = acc;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (!mel) return;
+    __syncthreads();
+    // melt [n_mel][32 frames] -> mel[b][m][f0 .. f0 + 32): one 128-B segment per channel
+    const int nfr = (Fi - f0) < MEL_FPB ? (Fi - f0) : MEL_FPB;
+    for (int idx = tid; idx < n_mel * MEL_FPB; idx += 64 * MEL_WAVES) {
+        const int m = idx >> 5, fl = idx & 31;
+        if (fl < nfr) mel[((size_t)b * n_mel + m) * F + f0 + fl] = melt[m * (MEL_FPB + 1) + fl];
+    }
+}
+
 hipError_t launch_mel(const amp_mel_desc& d, const float* wav, const int* lens, int B, int L, int F, const float* window,
                       const float* melbasis, float* mel, float* mag, float* re, float* im, hipStream_t stream) {
+    const int pad = d.pad_mode == 0 ? (d.n_fft - d.hop_size) / 2 : d.n_fft / 2;
+    const int n_mel = mel ? d.n_mel : 0;
+    if (d.n_fft == 1024 && n_mel <= MEL_MAXMEL && (pad & 1) == 0 && (d.hop_size & 1) == 0) {
+        // wave-per-frame radix-8 real FFT (every shipped config of the reference)
+        const size_t lds = (size_t)(2 * MEL_WAVES * 64 * MEL_XROW + MEL_WAVES * MEL_MAGROW + (size_t)n_mel * (MEL_FPB + 1)) * sizeof(float);
+        static unsigned long long attr_set = 0;   // per device
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        if (!((attr_set >> dev) & 1ull)) {
+            const size_t mx = (size_t)(2 * MEL_WAVES * 64 * MEL_XROW + MEL_WAVES * MEL_MAGROW + (size_t)MEL_MAXMEL * (MEL_FPB + 1)) * sizeof(float);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mel1024_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx);
+            if (e != hipSuccess) return e;
+            attr_set |= 1ull << dev;
+        }
+        const int fblocks = (F + MEL_FPB - 1) / MEL_FPB;
+        hipLaunchKernelGGL(mel1024_kernel, dim3((unsigned)((size_t)B * fblocks)), dim3(64 * MEL_WAVES), lds, stream, wav, lens, L, F,
+                           d.hop_size, pad, n_mel, d.mag_eps, d.log_clip, window, melbasis,
+                           static_cast<const int*>(d.mel_bands_dev), mel, mag, re, im);
+        return hipGetLastError();
+    }
+    // generic power-of-two n_fft: one workgroup per frame, radix-2
     int log2n = 0;
     while ((1 << log2n) < d.n_fft) ++log2n;
-    const int pad = d.pad_mode == 0 ? (d.n_fft - d.hop_size) / 2 : d.n_fft / 2;
     const size_t lds = (size_t)(2 * d.n_fft + d.n_fft / 2) * sizeof(float2) + (size_t)(d.n_fft / 2 + 1) * sizeof(float);
     dim3 grid((unsigned)((size_t)B * F));
     hipLaunchKernelGGL(mel_kernel, grid, dim3(256), lds, stream, wav, lens, L, F, d.n_fft, log2n, d.hop_size, pad,
-                       mel ? d.n_mel : 0, d.mag_eps, d.log_clip, window, melbasis, mel, mag, re, im);
+                       n_mel, d.mag_eps, d.log_clip, window, melbasis, mel, mag, re, im);
     return hipGetLastError();
 }
 
@@ -210,6 +451,114 @@ hipError_t launch_istft(const amp_mel_desc& d, int mode, const float* a, const f
     return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the log-mel front end (the training-time mel loss, gan_vocoder_trainer.py:387-392:
+// loss = 45 * L1(extract_mel_features(y_gt), extract_mel_features(y_pred)) needs d loss / d y_pred).
+//
+//   lm = log(max(mel, clip)),  mel = B |X|,  |X| = sqrt(re^2 + im^2 + eps),  X = rDFT(window * frame of reflect-pad(x))
+//
+//   g_mel = g_lm / mel  where mel >= clip (torch.clamp passes the gradient there), else 0
+//   g_|X| = B^T g_mel ;  g_re = g_|X| re / |X| ;  g_im = g_|X| im / |X|
+//   g_frame[n] = window[n] * Re sum_{k=0}^{N/2} (g_re + i g_im)[k] e^{+2 pi i k n / N}
+//              = window[n] * N * irfft(H)[n],   H = G at k = 0, N/2 and G / 2 in between (the one-sided sum counts
+//                interior bins once, the Hermitian extension twice)                    -> istft_frames_kernel
+//   g_xpad = overlap-add of the frames ;  g_x[s] = g_xpad[s + pad] + the mirrored positions of the reflection padding
+// ------------------------------------------------------------------------------------------------
+// kernel 1: (g_lm, mel, |X|, re, im) -> H_re, H_im  [B, bins, F];  block = 32 frames x 8 bin lanes
+__global__ __launch_bounds__(256) void mel_grad_spec_kernel(const float* __restrict__ g_lm, const float* __restrict__ mel,
+                                                            const float* __restrict__ mag, const float* __restrict__ re,
+                                                            const float* __restrict__ im, const float* __restrict__ melbasis,
+                                                            int F, int bins, int n_mel, float log_clip,
+                                                            float* __restrict__ h_re, float* __restrict__ h_im) {
+    extern __shared__ float gm[];                 // [n_mel][32]  g_mel of this tile
+    const int fblocks = (F + 31) / 32;
+    const int b = blockIdx.x / fblocks;
+    const int f0 = (blockIdx.x - b * fblocks) * 32;
+    const int fl = threadIdx.x & 31, kl = threadIdx.x >> 5;
+    const int f = f0 + fl;
+    for (int m = kl; m < n_mel; m += 8) {
+        float g = 0.f;
+        if (f < F) {
+            const size_t o = ((size_t)b * n_mel + m) * F + f;
+            const float v = mel[o];
+            if (log_clip > 0.f) g = (v >= log_clip) ? g_lm[o] / v : 0.f;   // mel holds the LINEAR mel energy here
+            else g = g_lm[o];
+        }
+        gm[m * 32 + fl] = g;
+    }
+    __syncthreads();
+    if (f >= F) return;
+    for (int k = kl; k < bins; k += 8) {
+        float acc = 0.f;
+        for (int m = 0; m < n_mel; ++m) acc = fmaf(melbasis[(size_t)m * bins + k], gm[m * 32 + fl], acc);
+        const size_t o = ((size_t)b * bins + k) * F + f;
+        const float mg = mag[o];
+        const float wk = (k == 0 || k == bins - 1) ? 1.f : 0.5f;
+        const float s = mg > 0.f ? wk * acc / mg : 0.f;
+        h_re[o] = s * re[o];
+        h_im[o] = s * im[o];
+    }
+}
+
+// kernel 3: overlap-add of the frame gradients + fold the reflection padding back onto the samples
+__global__ __launch_bounds__(256) void mel_grad_ola_kernel(const float* __restrict__ frames, const int* __restrict__ lens, int L,
+                                                           int F, int n_fft, int hop, int pad, float* __restrict__ g_wav) {
+    const int b = blockIdx.y;
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= L) return;
+    int Li = L, Fi = F;
+    if (lens) {
+        Li = lens[b] < L ? lens[b] : L;
+        Fi = Li <= pad ? 0 : (Li + 2 * pad - n_fft) / hop + 1;
+        Fi = Fi < F ? Fi : F;
+    }
+    float acc = 0.f;
+    if (s < Li) {
+        const float* fb = frames + (size_t)b * F * n_fft;
+        // padded positions that read sample s: t = s + pad, and through the reflection t = pad - s (s >= 1) and
+        // t = pad + 2 (Li - 1) - s (s <= Li - 2); the padded signal is Li + 2 pad long
+        int tpos[3];
+        tpos[0] = s + pad;
+        tpos[1] = (s >= 1 && s <= pad) ? pad - s : -1;
+        tpos[2] = (s <= Li - 2 && 2 * (Li - 1) - s < Li + pad) ? pad + 2 * (Li - 1) - s : -1;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int t = tpos[i];
+            if (t < 0) continue;
+            int fa = (t - n_fft + hop) / hop;              // first frame covering t
+            if (t - n_fft + 1 <= 0) fa = 0;
+            int fz = t / hop;
+            if (fz > Fi - 1) fz = Fi - 1;
+            for (int f = fa; f <= fz; ++f) acc += fb[(size_t)f * n_fft + (t - f * hop)];
+        }
+    }
+    g_wav[(size_t)b * L + s] = acc;
+}
+
+hipError_t launch_mel_backward(const amp_mel_desc& d, const int* lens, int B, int L, int F, const float* window,
+                               const float* melbasis, const float* mel_lin, const float* mag, const float* re, const float* im,
+                               const float* g_lm, float* h_re, float* h_im, float* frames, float* g_wav, hipStream_t stream) {
+    const int bins = d.n_fft / 2 + 1;
+    const int pad = d.pad_mode == 0 ? (d.n_fft - d.hop_size) / 2 : d.n_fft / 2;
+    const int fblocks = (F + 31) / 32;
+    hipLaunchKernelGGL(mel_grad_spec_kernel, dim3((unsigned)((size_t)B * fblocks)), dim3(256), (size_t)d.n_mel * 32 * sizeof(float), stream,
+                       g_lm, mel_lin, mag, re, im, melbasis, F, bins, d.n_mel, d.log_clip, h_re, h_im);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    int log2n = 0;
+    while ((1 << log2n) < d.n_fft) ++log2n;
+    const size_t lds = (size_t)(2 * d.n_fft + d.n_fft / 2) * sizeof(float2);
+    // frames = irfft(H) * window * inv_scale / n_fft * n_fft ... istft_frames_kernel multiplies by inv_scale / n_fft: we want x n_fft
+    hipLaunchKernelGGL(istft_frames_kernel, dim3((unsigned)((size_t)B * F)), dim3(256), lds, stream, h_re, h_im, 0, F, d.n_fft, log2n,
+                       (float)d.n_fft, window, frames);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(mel_grad_ola_kernel, dim3((unsigned)((L + 255) / 256), (unsigned)B), dim3(256), 0, stream, frames, lens, L, F,
+                       d.n_fft, d.hop_size, pad, g_wav);
+    return hipGetLastError();
+}
+
 }  // namespace amp
 
 using namespace amp;
@@ -272,6 +621,26 @@ int amp_istft_same(const amp_mel_desc* d, const float* re_dev, const float* im_d
     if (d->hop_size <= 0 || d->hop_size > d->n_fft || ((d->win_size - d->hop_size) & 1) || B <= 0 || F <= 0) { set_error("amp_istft_same: hop=%d B=%d F=%d", d->hop_size, B, F); return AMP_ERR_INVALID; }
     hipError_t e = launch_istft(*d, 1, re_dev, im_dev, B, F, window_dev, envelope_dev, frames_ws_dev, wav_dev, (hipStream_t)stream);
     if (e != hipSuccess) { set_error("amp_istft_same: %s", hipGetErrorString(e)); return AMP_ERR_HIP; }
+    return AMP_OK;
+}
+
+int amp_mel_backward(const amp_mel_desc* d, const int32_t* lens_dev, int B, int L, const float* window_dev,
+                     const float* melbasis_dev, const float* mel_linear_dev, const float* mag_dev, const float* re_dev,
+                     const float* im_dev, const float* grad_logmel_dev, float* spec_ws_dev, float* frames_ws_dev,
+                     float* grad_wav_dev, void* stream) {
+    if (!d || !window_dev || !melbasis_dev || !mel_linear_dev || !mag_dev || !re_dev || !im_dev || !grad_logmel_dev || !spec_ws_dev ||
+        !frames_ws_dev || !grad_wav_dev) { set_error("amp_mel_backward: null argument"); return AMP_ERR_INVALID; }
+    if (d->n_fft < 64 || d->n_fft > 4096 || (d->n_fft & (d->n_fft - 1)) != 0) {
+        set_error("amp_mel_backward: n_fft=%d must be a power of two in [64, 4096]", d->n_fft);
+        return AMP_ERR_UNSUPPORTED;
+    }
+    if (d->hop_size <= 0 || d->n_mel <= 0 || B <= 0 || L <= 0) { set_error("amp_mel_backward: hop=%d n_mel=%d B=%d L=%d", d->hop_size, d->n_mel, B, L); return AMP_ERR_INVALID; }
+    const int F = amp_mel_num_frames(d, L);
+    if (F <= 0) { set_error("amp_mel_backward: no frames for L=%d", L); return AMP_ERR_INVALID; }
+    const size_t nspec = (size_t)B * (d->n_fft / 2 + 1) * F;
+    hipError_t e = launch_mel_backward(*d, lens_dev, B, L, F, window_dev, melbasis_dev, mel_linear_dev, mag_dev, re_dev, im_dev,
+                                       grad_logmel_dev, spec_ws_dev, spec_ws_dev + nspec, frames_ws_dev, grad_wav_dev, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("amp_mel_backward: %s", hipGetErrorString(e)); return AMP_ERR_HIP; }
     return AMP_OK;
 }
 

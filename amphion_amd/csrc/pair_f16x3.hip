@@ -109,6 +109,7 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairArgs a) {
         }
     }
 
+    bool range_bad = false;      // any staged operand outside the f16 range (reported through a.range_flag)
     float xs[NST][4];
     auto stage_load = [&](int chunk) {
 #pragma unroll
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairArgs a) {
             for (int e = 0; e < 4; ++e) {
                 float v = tok ? xs[it][e] : 0.f;
                 v = v * (v > 0.f ? kpos : kneg);
+                range_bad |= f16_range_bad(v);
                 split_f16(v, fh.h[e], fl.h[e]);
             }
             const int o2 = (((qd >> 1) * SX + col) << 1) + (qd & 1);
@@ -215,6 +217,7 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairArgs a) {
                     float v = acc[t][4 * j + i] * i1;
                     v = v > 0.f ? v : v * slope;
                     v = qok ? v * 16.f : 0.f;
+                    range_bad |= f16_range_bad(v);
                     split_f16(v, fh.h[i], fl.h[i]);
                 }
                 // channels 32*wm + 8*j + 4*hi + i  ->  chunk 2*wm + (j >> 1), octet j & 1, half hi
@@ -301,6 +304,7 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairArgs a) {
                 for (int r = 0; r < 16; ++r) yr[(size_t)((r & 3) + 8 * (r >> 2)) * T + qc[t]] = acc[t][r];
             }
     }
+    if (a.range_flag && __any(range_bad) && lane == 0) atomicOr(a.range_flag, 1u);
 }
 
 template <int KT, int WM, int WN, int NI, int SX>
@@ -308,12 +312,14 @@ static hipError_t launch_pair_one(const PairArgs& a, hipStream_t stream) {
     constexpr int N1 = 32 * NI * WN;
     constexpr int XT = N1 + 12;
     const size_t lds = ((size_t)2 * 4 * SX + (size_t)2 * WM * 4 * XT) * sizeof(uint4);
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
+    static unsigned long long attr_set = 0;   // per device: the attribute belongs to that device's copy of the function
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!((attr_set >> dev) & 1ull) && lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_f16x3_kernel<KT, WM, WN, NI, SX>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set |= 1ull << dev;
     }
     dim3 grid((unsigned)(a.B * a.tiles_per_item));
     hipLaunchKernelGGL((pair_f16x3_kernel<KT, WM, WN, NI, SX>), grid, dim3(256), lds, stream, a);

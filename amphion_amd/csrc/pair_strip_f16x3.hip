@@ -25,6 +25,9 @@
 // channels is 108 KB); compiled once per tap count:  -DAMP_KT=<3|5|7|11>.
 #include "amp_internal.h"
 
+#include <stdlib.h>
+#include <string.h>
+
 #ifndef AMP_KT
 #error "compile with -DAMP_KT=<taps>"
 #endif
@@ -94,6 +97,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void pair_strip_kernel(const PairA
     int Ts = T;
     const float* xres_s = xres;
     float* yr_s = yr;
+    bool range_bad = false;      // any staged operand outside the f16 range (reported through a.range_flag)
     float xs[NST][4];
     auto stage_load = [&](int chunk, int tbase) {
 #pragma unroll
@@ -123,6 +127,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void pair_strip_kernel(const PairA
             for (int e = 0; e < 4; ++e) {
                 float v = tok ? xs[it][e] : 0.f;
                 v = v * (v > 0.f ? kpos : kneg);
+                range_bad |= f16_range_bad(v);
                 split_f16(v, fh.h[e], fl.h[e]);
             }
             const int o2 = (((qd >> 1) * SX + col) << 1) + (qd & 1);
@@ -259,6 +264,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void pair_strip_kernel(const PairA
                         float v = acc[t][4 * j + i] * i1;
                         v = v > 0.f ? v : v * slope;
                         v = qok ? v * 16.f : 0.f;
+                        range_bad |= f16_range_bad(v);
                         split_f16(v, fh.h[i], fl.h[i]);
                     }
                     // channels 32*wm + 8*j + 4*hi + i  ->  chunk 2*wm + (j >> 1), octet j & 1, half hi
@@ -346,6 +352,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void pair_strip_kernel(const PairA
                 }
         }
     }
+    if (a.range_flag && __any(range_bad) && lane == 0) atomicOr(a.range_flag, 1u);
 }
 
 template <int KT, int WM, int WN, int NI, int SX>
@@ -370,6 +377,14 @@ static hipError_t launch_strip_one(const PairArgs& a, hipStream_t stream) {
 #define AMP_CAT2(a, b) a##b
 #define AMP_CAT(a, b) AMP_CAT2(a, b)
 
+// AMP_STRIP_WIDE=1 (experiment): 8-wave workgroups with twice the step width, one per CU -- waves (wm, 0) and (wm, 1)
+// fetch the same A fragments (the second hits L1), the k - 1 seam columns and the dilated halo are paid once per 2 x
+// the columns.
+static bool strip_wide() {
+    static const bool on = [] { const char* e = getenv("AMP_STRIP_WIDE"); return e && !strcmp(e, "1"); }();
+    return on;
+}
+
 // Step width (xt columns = output columns per step) for C channels, or 0 when (C, KT, dilation) is not covered;
 // *wg_per_cu = resident workgroups per CU (LDS / register bound), used by the host to size the strips.
 int AMP_CAT(strip_step_kt, AMP_KT)(int C, int dil, int* wg_per_cu) {
@@ -377,6 +392,9 @@ int AMP_CAT(strip_step_kt, AMP_KT)(int C, int dil, int* wg_per_cu) {
     const int span = (KT - 1) * dil;   // staged halo = 2 * h1
     int n1 = 0, wg = 2;
     if (C == 256) { n1 = (96 + span <= 256) ? 96 : 0; wg = 1; }
+    else if (strip_wide() && C == 128) { n1 = (192 + span <= 256) ? 192 : 0; wg = 1; }
+    else if (strip_wide() && C == 64) { n1 = (256 + span <= 384) ? 256 : 0; wg = 1; }
+    else if (strip_wide() && C == 32) { n1 = (512 + span <= 640) ? 512 : 0; wg = 1; }
     else if (C == 128) n1 = (96 + span <= 192) ? 96 : 0;
     else if (C == 64) n1 = (128 + span <= 192) ? 128 : 0;
     else if (C == 32) n1 = (256 + span <= 320) ? 256 : 0;
@@ -388,6 +406,11 @@ hipError_t AMP_CAT(launch_strip_kt, AMP_KT)(const PairArgs& a, hipStream_t strea
     constexpr int KT = AMP_KT;
     const int span = (KT - 1) * a.dil;
     if (a.C == 256) return launch_strip_one<KT, 8, 1, 3, 256>(a, stream);
+    if (strip_wide()) {
+        if (a.C == 128) return launch_strip_one<KT, 4, 2, 3, 256>(a, stream);
+        if (a.C == 64) return launch_strip_one<KT, 2, 4, 2, 384>(a, stream);
+        if (a.C == 32) return launch_strip_one<KT, 1, 8, 2, 640>(a, stream);
+    }
     if (a.C == 128) return span <= 32 ? launch_strip_one<KT, 4, 1, 3, 128>(a, stream) : launch_strip_one<KT, 4, 1, 3, 192>(a, stream);
     if (a.C == 64) return launch_strip_one<KT, 2, 2, 2, 192>(a, stream);
     if (a.C == 32) return launch_strip_one<KT, 1, 4, 2, 320>(a, stream);

@@ -16,6 +16,29 @@ import sys
 
 TARGETS = ("models.vocoders.vocoder_inference", "models.codec.codec_inference")
 TARGET = TARGETS[0]
+# generator modules whose CLASSES other models import directly instead of going through the registries:
+# models/tts/vits/vits.py:20 (HiFiGAN_vits as Generator), models/tts/jets/jets.py:23,454-458 (HiFiGAN with
+# n_mel = attention_dim as the JETS waveform decoder).  Their class attributes are replaced right after the module
+# body ran, so a later `from models.vocoders.gan.generator.hifigan import HiFiGAN` binds the MI355X class
+# (inference only: these classes have no backward).
+CLASS_TARGETS = {
+    "models.vocoders.gan.generator.hifigan": ("HiFiGAN", "HiFiGAN_vits"),
+    "models.vocoders.gan.generator.bigvgan": ("BigVGAN",),
+    "models.vocoders.gan.generator.melgan": ("MelGAN",),
+    "models.vocoders.gan.generator.nsfhifigan": ("NSFHiFiGAN",),
+    "models.vocoders.gan.generator.apnet": ("APNet",),
+}
+
+
+def _patch_classes(module, fullname):
+    import importlib
+
+    ours = importlib.import_module("amphion_amd." + fullname)
+    for name in CLASS_TARGETS[fullname]:
+        if hasattr(module, name) and hasattr(ours, name):
+            setattr(module, "_reference_" + name, getattr(module, name))     # the original stays reachable
+            setattr(module, name, getattr(ours, name))
+    module.__amphion_amd_patched__ = True
 
 
 class _PatchLoader(importlib.abc.Loader):
@@ -27,6 +50,9 @@ class _PatchLoader(importlib.abc.Loader):
 
     def exec_module(self, module):
         self._inner.exec_module(module)
+        if module.__name__ in CLASS_TARGETS:
+            _patch_classes(module, module.__name__)
+            return
         from amphion_amd.models.vocoders.vocoder_inference import install_into_reference
 
         install_into_reference(module)
@@ -40,7 +66,7 @@ class _PatchLoader(importlib.abc.Loader):
 
 class _Finder(importlib.abc.MetaPathFinder):
     def __init__(self):
-        self._pending = set(TARGETS)
+        self._pending = set(TARGETS) | set(CLASS_TARGETS)
         self._busy = False
 
     def find_spec(self, fullname, path, target=None):
@@ -68,7 +94,11 @@ def install():
         for t in from_loaded:
             install_into_reference(sys.modules[t])
             sys.modules[t].__amphion_amd_patched__ = True
-    if len(from_loaded) < len(TARGETS) and not any(isinstance(f, _Finder) for f in sys.meta_path):
+    cls_loaded = [t for t in CLASS_TARGETS if t in sys.modules]
+    for t in cls_loaded:
+        if not getattr(sys.modules[t], "__amphion_amd_patched__", False):
+            _patch_classes(sys.modules[t], t)
+    if (len(from_loaded) < len(TARGETS) or len(cls_loaded) < len(CLASS_TARGETS)) and not any(isinstance(f, _Finder) for f in sys.meta_path):
         f = _Finder()
-        f._pending -= set(from_loaded)
+        f._pending -= set(from_loaded) | set(cls_loaded)
         sys.meta_path.insert(0, f)

@@ -115,6 +115,8 @@ class HipGenerator(nn.Module):
         self._amp_handle = None
         self._amp_finalizer = None
         self._amp_sig = None
+        self._amp_snap = None
+        self._amp_epoch = 0
         self._amp_device = None
         self._amp_ws = None
         self._amp_profiling = 0
@@ -158,16 +160,50 @@ class HipGenerator(nn.Module):
         return self.state_dict().items()
 
     def _amp_signature(self):
+        """Full identity of the weights: (key, storage address, in-place version, shape) of every state tensor.  A walk
+        over the module tree (~0.25 ms for HiFi-GAN V1's 234 tensors): taken when the handle is built and whenever the
+        per-forward check below fails."""
         return tuple((k, v.data_ptr(), v._version, tuple(v.shape)) for k, v in self.state_dict(keep_vars=True).items())
+
+    def _amp_snapshot(self):
+        """Per-forward change detection without the tree walk (~0.05 ms): the Parameter / buffer OBJECTS registered in
+        every sub-module, plus (address, version) of each -- catches load_state_dict and optimizer steps (in-place:
+        version), .to() / .cuda() / .float() (new storage), remove_weight_norm and any re-registered Parameter
+        (object identity).  A sub-MODULE swapped for another after the first forward is only seen through
+        ``invalidate()`` -- the reference never does that to a built generator."""
+        mods = list(self.modules())
+        tens = [t for m in mods for d in (m._parameters, m._buffers) for t in d.values()]
+        return mods, tens, [(t.data_ptr(), t._version) if t is not None else None for t in tens]
+
+    def _amp_unchanged(self):
+        mods, tens, marks = self._amp_snap
+        i = 0
+        for m in mods:
+            for d in (m._parameters, m._buffers):
+                for t in d.values():
+                    if i >= len(tens) or t is not tens[i]:
+                        return False
+                    if t is not None and marks[i] != (t.data_ptr(), t._version):
+                        return False
+                    i += 1
+        return i == len(tens)
+
+    def invalidate(self):
+        """Forget the packed weights: the next forward re-reads every parameter."""
+        self._amp_release()
 
     def _amp_release(self):
         if self._amp_finalizer is not None:
             self._amp_finalizer()  # destroys the handle once
-        self._amp_handle = self._amp_finalizer = self._amp_sig = self._amp_device = None
+        self._amp_handle = self._amp_finalizer = self._amp_sig = self._amp_device = self._amp_snap = None
+        self._amp_epoch = getattr(self, "_amp_epoch", 0) + 1          # captured graphs of the old handle are dead
 
     def _amp_ensure(self, device):
+        if self._amp_handle is not None and device == self._amp_device and self._amp_unchanged():
+            return self._amp_handle
         sig = self._amp_signature()
         if self._amp_handle is not None and sig == self._amp_sig and device == self._amp_device:
+            self._amp_snap = self._amp_snapshot()      # same weights behind re-registered objects
             return self._amp_handle
         self._amp_release()
         L = _lib.lib()
@@ -175,22 +211,28 @@ class HipGenerator(nn.Module):
         h = ctypes.c_void_p()
         _lib.check(L.amp_gen_create(ctypes.byref(desc), ctypes.byref(h)))
         fin = weakref.finalize(self, _destroy_handle, h.value)
+        prev_prec = L.amp_get_precision()
         try:
             for key, t in self._amp_weights():
                 c = t.detach().to("cpu", torch.float32).contiguous()
                 shape = (ctypes.c_int64 * c.dim())(*c.shape)
                 _lib.check(L.amp_gen_set_weight(h, key.encode(), ctypes.c_void_p(c.data_ptr()), shape, c.dim()))
             with torch.cuda.device(device):
+                if getattr(self, "_amp_force_f32", False):      # forward_exact_range fell back: pack for the fp32 kernels
+                    _lib.check(L.amp_set_precision(_lib.AMP_PRECISION_F32))
                 _lib.check(L.amp_gen_finalize(h))
                 if self._amp_profiling:
                     _lib.check(L.amp_gen_set_profiling(h, int(self._amp_profiling)))
         except Exception:
             fin()
             raise
+        finally:
+            L.amp_set_precision(prev_prec)
         self._amp_handle, self._amp_finalizer, self._amp_sig, self._amp_device = h, fin, sig, device
+        self._amp_snap = self._amp_snapshot()
         return h
 
-    def _amp_forward(self, x, g=None, lengths=None):
+    def _amp_forward(self, x, g=None, lengths=None, workspace=None):
         # Inference only: the HIP kernels have no backward.  A gradient asked for THROUGH the generator cannot be
         # honoured -> fail; a module left in training mode merely gets told once.
         if torch.is_grad_enabled() and isinstance(x, torch.Tensor):
@@ -228,14 +270,44 @@ class HipGenerator(nn.Module):
             lens_ptr = ctypes.c_void_p(lengths.data_ptr())
         hop = L.amp_gen_hop(h)
         need = L.amp_gen_workspace_bytes(h, B, T)
-        if self._amp_ws is None or self._amp_ws.numel() < need or self._amp_ws.device != dev:
-            self._amp_ws = None
-            self._amp_ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        ws = workspace
+        if ws is None:
+            if self._amp_ws is None or self._amp_ws.numel() < need or self._amp_ws.device != dev:
+                self._amp_ws = None
+                self._amp_ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            ws = self._amp_ws
+        elif ws.numel() < need or ws.device != dev:
+            raise ValueError("workspace too small for this (B, T)")
         out = torch.empty((B, 1, T * hop), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.check(L.amp_gen_forward_ragged(h, ctypes.c_void_p(x.data_ptr()), cond_ptr, lens_ptr, B, T,
-                                                ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(self._amp_ws.data_ptr()),
-                                                self._amp_ws.numel(), _lib.current_stream_ptr(dev)))
+                                                ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+                                                ws.numel(), _lib.current_stream_ptr(dev)))
+        return out
+
+    def check_range(self):
+        """Synchronise and raise ``AmpError`` (``status == _lib.AMP_ERR_RANGE``) if a forward since the last check
+        staged an activation outside the split-f16 operand range (|x| > 4094 or non-finite; the fp32 reference has no
+        such limit).  A later forward reports the same without synchronising.  ``forward_exact_range`` is the
+        self-healing form."""
+        _lib.range_check(next(self.parameters()).device)
+
+    def forward_exact_range(self, x, g=None, lengths=None):
+        """Forward with the fp32 reference's operand range: runs the f16x3 kernels, checks the range flag (one
+        synchronisation) and, if an activation did not fit, repeats the call on the exact-fp32 MFMA kernels (handle
+        rebuilt once; it stays in fp32 from then on)."""
+        out = self._amp_forward(x, g, lengths=lengths)
+        try:
+            self.check_range()
+        except _lib.AmpError as e:
+            if e.status != _lib.AMP_ERR_RANGE or getattr(self, "_amp_force_f32", False):
+                raise
+            warnings.warn("amphion_amd: an activation left the split-f16 operand range; this generator now runs the "
+                          "exact-fp32 kernels", RuntimeWarning, stacklevel=2)
+            self._amp_force_f32 = True
+            self._amp_release()
+            out = self._amp_forward(x, g, lengths=lengths)
+            self.check_range()
         return out
 
     def forward_ragged(self, x, lengths, g=None):
@@ -256,6 +328,11 @@ class HipGenerator(nn.Module):
         ``static_in`` (same shape), call ``replay()``, read ``static_out``.  The kernels launch on the caller's
         stream and neither allocate nor synchronise, so plain stream capture works; one eager warm-up forward
         runs first (it builds the handle and sets the >64 KiB dynamic-LDS attributes outside the capture).
+
+        The graph records raw device pointers: it owns its OWN workspace (kept alive by ``replay``; eager forwards of
+        other shapes may re-allocate the module's), and it is tied to the packed weights of the current handle --
+        ``replay()`` raises once the parameters changed (``load_state_dict``, ``.to()``, ``set_precision`` ...) instead
+        of reading freed memory; capture again after such a change.
         """
         dev = next(self.parameters()).device
         if dev.type != "cuda":
@@ -267,18 +344,26 @@ class HipGenerator(nn.Module):
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side), torch.no_grad():
-            self._amp_forward(static_in, static_g)      # warm-up: handle, workspace, function attributes
+            self._amp_forward(static_in, static_g)      # warm-up: handle, function attributes
+            need = _lib.lib().amp_gen_workspace_bytes(self._amp_handle, B, T)
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)   # the graph's own scratch
+            self._amp_forward(static_in, static_g, workspace=ws)
         torch.cuda.current_stream(dev).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph), torch.no_grad():
-            static_out = self._amp_forward(static_in, static_g)
+            static_out = self._amp_forward(static_in, static_g, workspace=ws)
         self.set_profiling(was_profiling)
+        epoch, handle = self._amp_epoch, self._amp_handle.value
 
         def replay():
+            if self._amp_epoch != epoch or self._amp_handle is None or self._amp_handle.value != handle or not self._amp_unchanged():
+                raise RuntimeError("captured graph is stale: the generator's parameters / device / precision changed "
+                                   "after capture(); capture again")
             graph.replay()
             return static_out
 
         replay.graph = graph
+        replay.workspace = ws
         replay.static_g = static_g
         return replay, static_in, static_out
 

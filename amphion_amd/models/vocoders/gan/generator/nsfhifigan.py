@@ -104,6 +104,11 @@ class NSFHiFiGAN(HipGenerator):
         """nsfhifigan.py:258-283.  ``f0`` is accepted and (as in the reference, by its own overwrite) ignored."""
         if f0 is not None and not isinstance(f0, torch.Tensor):
             raise TypeError("f0 must be a tensor or None")
+        if f0 is not None and f0.shape[-1] < x.shape[-1]:
+            # the reference crops x to min(len(x), len(x_source)) after every transposed conv (:267-269): with fewer
+            # f0 frames than mel frames its output is SHORTER and its right edge differs; that crop is not built here
+            raise ValueError(f"NSFHiFiGAN: f0 has {f0.shape[-1]} frames but the mel has {x.shape[-1]}: the reference would "
+                             "crop the waveform to the f0 length -- pad f0 (pad_f0_to_tensors) or trim the mel")
         return self._amp_forward(x)
 
     def remove_weight_norm(self):

@@ -33,7 +33,8 @@ typedef enum amp_status {
     AMP_ERR_MISSING_WEIGHT = -2, /* finalize(): a tensor the architecture needs was never set */
     AMP_ERR_HIP = -3,            /* a HIP runtime call failed */
     AMP_ERR_UNSUPPORTED = -4,    /* configuration outside what the kernels cover */
-    AMP_ERR_STATE = -5           /* call order violated (e.g. forward before finalize) */
+    AMP_ERR_STATE = -5,          /* call order violated (e.g. forward before finalize) */
+    AMP_ERR_RANGE = -6           /* an activation left the split-f16 operand range (see amp_range_check) */
 } amp_status;
 
 typedef enum amp_arch {
@@ -119,6 +120,16 @@ size_t amp_gen_workspace_bytes(const amp_gen* g, int B, int T);
  * faster setting on MI355X).  Also settable with the environment variable AMP_GROUP_MB.
  * Results do not depend on it. */
 int amp_set_group_mb(int megabytes);
+
+/* Operand-range guard of the f16x3 arithmetic.  Activations are staged as hi + lo f16 pairs after an exact x16, so
+ * |x| up to 4094 is representable; the fp32 reference (F.conv1d) has no such limit.  Every f16x3 kernel sets a
+ * per-device flag when a staged value is larger or not finite -- the output of that launch is then NOT the
+ * reference's (inf / NaN).  amp_range_check synchronises `stream` and returns AMP_ERR_RANGE if any launch on the
+ * current device since the last check was affected (and clears the flag), AMP_OK otherwise.  amp_gen_forward reports
+ * the same condition WITHOUT synchronising: a call that finds the flag of an earlier, finished forward set returns
+ * AMP_ERR_RANGE instead of running.  Remedy: amp_set_precision(AMP_PRECISION_F32) and rebuild the handle (the exact
+ * fp32 MFMA kernels have the reference's range). */
+int amp_range_check(void* stream);
 
 /* Fused ResBlock pairs (hifigan.py:93-100) run the per-tile kernel -- 0, the default -- or the strip-mined kernel (a
  * workgroup walks a strip of one utterance and carries conv2's halo in LDS; also covers C = 256) -- 1; also the
@@ -315,6 +326,9 @@ typedef struct amp_mel_desc {
                             1: reflect-pad n_fft/2 (utils/stft.py:152-165, TacotronSTFT) */
     float mag_eps;       /* added under the sqrt: 1e-9 (mel.py:166), 1e-6 (mel.py:99), 0 (stft.py:177) */
     float log_clip;      /* clamp before log: 1e-5 (mel.py:10-12); <=0 -> no log (raw mel / magnitude) */
+    const int32_t* mel_bands_dev; /* optional, device: [n_mel][2] = first and one-past-last FFT bin with a non-zero
+                            weight in each row of melbasis (librosa's triangular filters touch 2..40 of the 513 bins);
+                            NULL = every row is summed over all bins.  Must cover every non-zero of the basis. */
 } amp_mel_desc;
 
 /* Number of frames produced for L samples. */
@@ -335,6 +349,18 @@ int amp_mel_forward(const amp_mel_desc* d, const float* wav_dev, int B, int L, c
 int amp_mel_forward_ragged(const amp_mel_desc* d, const float* wav_dev, const int32_t* lens_dev, int B, int L,
                            const float* window_dev, const float* melbasis_dev, float* mel_dev, float* mag_dev,
                            float* re_dev, float* im_dev, void* stream);
+
+/* Backward of amp_mel_forward for the training-time mel loss (models/vocoders/gan/gan_vocoder_trainer.py:387-392:
+ * 45 * L1(extract_mel_features(y_gt), extract_mel_features(y_pred)) differentiated w.r.t. y_pred).  Inputs are what a
+ * forward with log_clip <= 0 returns for the same audio -- mel_linear_dev [B, n_mel, F] (mel energies BEFORE the log),
+ * mag_dev / re_dev / im_dev [B, n_fft/2+1, F] -- plus grad_logmel_dev [B, n_mel, F] = d loss / d log(max(mel,
+ * d->log_clip)) (d->log_clip <= 0: the gradient w.r.t. the linear mel).  Output grad_wav_dev [B, L].
+ * spec_ws_dev: scratch of 2 * B * (n_fft/2+1) * F floats, frames_ws_dev: B * F * n_fft floats.  lens_dev as in
+ * amp_mel_forward_ragged (NULL = full rows). */
+int amp_mel_backward(const amp_mel_desc* d, const int32_t* lens_dev, int B, int L, const float* window_dev,
+                     const float* melbasis_dev, const float* mel_linear_dev, const float* mag_dev, const float* re_dev,
+                     const float* im_dev, const float* grad_logmel_dev, float* spec_ws_dev, float* frames_ws_dev,
+                     float* grad_wav_dev, void* stream);
 
 /* Replaces STFT.inverse (utils/stft.py:183-222; used by STFT.forward and griffin_lim :78-95): magnitude and
  * phase [B, n_fft/2+1, F] -> waveform [B, hop*(F-1)] (overlap-add of the windowed inverse FFTs, divided by the

@@ -111,3 +111,42 @@ def test_hipgraph_capture_replays_bit_identically():
         out = replay()
         torch.cuda.synchronize()
         assert out is static_out and torch.equal(out, eager)
+
+
+def test_hipgraph_capture_survives_other_shapes_and_refuses_stale_weights():
+    """The captured graph owns its workspace (an eager forward of a larger shape re-allocates the module's scratch
+    without touching it) and is tied to the packed weights: after a parameter change replay() raises instead of
+    reading freed memory."""
+    from amphion_amd.models.vocoders.gan.generator.hifigan import HiFiGAN
+
+    hp = vo.hifigan_v1_hp()
+    m = HiFiGAN(NS(preprocess=NS(n_mel=80, hop_size=256), model=NS(hifigan=NS(**hp))))
+    sd = synth.synth_state_dict(synth.hifigan_param_shapes(80, hp), 1234)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    mel = synth.synth_mel(1, 80, 40, seed=3).cuda()
+    with torch.no_grad():
+        eager = m(mel).clone()
+    replay, static_in, static_out = m.capture(1, 40)
+    with torch.no_grad():
+        m(synth.synth_mel(3, 80, 200, seed=4).cuda())       # larger (B, T): the module's workspace is re-allocated
+        junk = torch.full((64, 1024, 1024), 7.0, device="cuda")   # recycle whatever the allocator freed
+    static_in.copy_(mel)
+    out = replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    del junk
+    with torch.no_grad():
+        m.conv_post.bias.add_(0.25)                           # weights changed -> handle rebuilt on the next forward
+    with pytest.raises(RuntimeError, match="stale"):
+        replay()
+    with torch.no_grad():
+        m(mel)                                                # rebuilds the handle
+    with pytest.raises(RuntimeError, match="stale"):
+        replay()
+    replay2, static_in2, _ = m.capture(1, 40)
+    static_in2.copy_(mel)
+    out2 = replay2()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        assert torch.equal(out2, m(mel))

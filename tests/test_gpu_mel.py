@@ -2,7 +2,8 @@
 and utils/stft.py, and vs the CPU oracle on seeded audio.
 
 Tolerances (fp32): linear spectra 2e-5 relative to the spectrum's max (FFT rounding differs from
-pocketfft's); log-mel 1e-3 absolute (the log amplifies rounding of small mel energies)."""
+pocketfft's); log-mel 1e-4 absolute wherever the mel energy exceeds 1e-3, 1e-3 below that (the log amplifies the
+rounding of small energies: d log m = dm / m); the measured errors are printed (run with -s)."""
 import numpy as np
 import pytest
 import torch
@@ -10,6 +11,18 @@ import torch
 from oracle import vocoder_oracle as vo
 
 pytestmark = pytest.mark.gpu
+
+
+def _check_logmel(out, ref, what):
+    """log-mel parity at the north-star tolerance: <= 1e-4 where mel > 1e-3, <= 1e-3 elsewhere; prints what it measured."""
+    out, ref = np.asarray(out, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    assert out.shape == ref.shape
+    d = np.abs(out - ref)
+    big = np.exp(ref) > 1e-3
+    eb = float(d[big].max()) if big.any() else 0.0
+    print(f"[mel] {what}: max |err| {eb:.2e} where mel > 1e-3 ({100.0 * big.mean():.0f} % of the bins), {float(d.max()):.2e} everywhere")
+    assert eb <= 1e-4, what
+    assert float(d.max()) <= 1e-3, what
 
 
 def _wav(golden):
@@ -23,12 +36,9 @@ def test_mel_front_end_golden(golden, tag, pp):
 
     y, y2 = _wav(golden)
     out = M.extract_mel_features(y.cuda(), pp).cpu().numpy()
-    ref = golden[f"mel_{tag}_extract"]
-    assert out.shape == ref.shape
-    assert np.abs(out - ref).max() <= 1e-3
+    _check_logmel(out, golden[f"mel_{tag}_extract"], f"extract_mel_features {tag} vs reference")
     out = M.mel_spectrogram_torch(y2.cuda(), pp).cpu().numpy()
-    assert out.shape == golden[f"mel_{tag}_melspec_b2"].shape
-    assert np.abs(out - golden[f"mel_{tag}_melspec_b2"]).max() <= 1e-3
+    _check_logmel(out, golden[f"mel_{tag}_melspec_b2"], f"mel_spectrogram_torch {tag} vs reference")
     lin = M.extract_linear_features(y.cuda(), pp).cpu().numpy()
     ref = golden[f"mel_{tag}_linear"]
     assert lin.shape == ref.shape
@@ -49,7 +59,7 @@ def test_tacotron_stft_golden(golden, tag, pp):
     _, y2 = _wav(golden)
     taco = TacotronSTFT(pp.n_fft, pp.hop_size, pp.win_size, pp.n_mel, pp.sample_rate, pp.fmin, pp.fmax).cuda()
     mel, energy = taco.mel_spectrogram(y2.cuda())
-    assert np.abs(mel.cpu().numpy() - golden[f"taco_{tag}_mel"]).max() <= 1e-3
+    _check_logmel(mel.cpu().numpy(), golden[f"taco_{tag}_mel"], f"TacotronSTFT {tag} vs reference")
     ref_e = golden[f"taco_{tag}_energy"]
     assert np.abs(energy.cpu().numpy() - ref_e).max() <= 2e-5 * max(1.0, ref_e.max())
     mag, phase = taco.stft_fn.transform(y2.cuda())
@@ -67,8 +77,53 @@ def test_mel_vs_oracle_seeded(B, L):
     y = (torch.rand(B, L, generator=g) * 2 - 1) * 0.8
     ref = vo.mel_spectrogram_torch(y, pp)
     out = M.mel_spectrogram_torch(y.cuda(), pp).cpu()
-    assert out.shape == ref.shape
-    assert (out - ref).abs().max().item() <= 1e-3
+    _check_logmel(out.numpy(), ref.numpy(), f"seeded B={B} L={L} vs oracle")
+
+
+@pytest.mark.parametrize("F", [2, 31, 32, 33, 65, 257])
+def test_mel_frame_counts_around_the_32_frame_tile(F):
+    """The n_fft = 1024 kernel works on tiles of 32 frames (8 waves x 4): frame counts on both sides of the tile
+    and wave boundaries, every output (mel, magnitude, real, imaginary) against the fp64 DFT of the oracle."""
+    from amphion_amd.utils import mel as M
+
+    pp = vo.preprocess_22k()
+    L = F * 256
+    g = torch.Generator().manual_seed(F)
+    y = (torch.rand(2, L, generator=g) * 2 - 1) * 0.9
+    _check_logmel(M.mel_spectrogram_torch(y.cuda(), pp).cpu().numpy(), vo.mel_spectrogram_torch(y, pp).numpy(), f"F={F}")
+    la, ph, re, im = (t.cpu().double() for t in M.amplitude_phase_spectrum(y.cuda(), pp))
+    # fp64 reference of the framed, windowed real DFT
+    pad = (pp.n_fft - pp.hop_size) // 2
+    yp = torch.nn.functional.pad(y.double().unsqueeze(1), (pad, pad), mode="reflect").squeeze(1)
+    X = torch.stft(yp, pp.n_fft, hop_length=pp.hop_size, win_length=pp.win_size, window=torch.hann_window(pp.win_size, dtype=torch.float64),
+                   center=False, return_complex=True)
+    scale = float(X.abs().max())
+    assert re.shape == X.real.shape
+    er, ei = float((re - X.real).abs().max()), float((im - X.imag).abs().max())
+    print(f"[mel] F={F}: spectrum max |err| re {er:.2e} im {ei:.2e} (scale {scale:.1f})")
+    assert er <= 2e-6 * scale and ei <= 2e-6 * scale
+
+
+def test_mel_bands_equal_the_dense_basis_sum():
+    """amp_mel_desc.mel_bands_dev only skips exact zeros of the filterbank: with and without it the log-mel agrees to
+    summation-order rounding, and a dense (non-triangular) basis without bands is summed over all 513 bins."""
+    import ctypes
+
+    from amphion_amd import _lib
+    from amphion_amd.utils import mel as M
+
+    pp = vo.preprocess_22k()
+    g = torch.Generator().manual_seed(9)
+    y = ((torch.rand(2, 256 * 40, generator=g) * 2 - 1) * 0.7).cuda()
+    basis, window = M._basis_and_window(pp, y.device)
+    ref = M.mel_spectrogram_torch(y, pp)
+    out = M._run(y, pp, n_mel=pp.n_mel, pad_mode=0, mag_eps=1e-6, log_clip=1e-5, basis=basis.clone(), window=window)["mel"]   # a copy: no band table
+    assert (out - ref).abs().max().item() <= 2e-6
+    dense = (torch.rand(7, 513, generator=g) * 0.01).cuda()
+    lin = M._run(y, pp, n_mel=0, pad_mode=0, mag_eps=1e-9, log_clip=0.0, want=("mag",), window=window)["mag"]
+    got = M._run(y, pp, n_mel=7, pad_mode=0, mag_eps=1e-9, log_clip=0.0, basis=dense, window=window)["mel"]
+    want = torch.einsum("mk,bkf->bmf", dense.double(), lin.double())
+    assert (got.double() - want).abs().max().item() <= 1e-5 * float(want.abs().max())
 
 
 def test_mel_small_nfft_and_window_shorter_than_fft():
@@ -81,8 +136,7 @@ def test_mel_small_nfft_and_window_shorter_than_fft():
     y = (torch.rand(2, 4000, generator=g) * 2 - 1) * 0.5
     ref = vo.mel_spectrogram_torch(y, pp)
     out = M.mel_spectrogram_torch(y.cuda(), pp).cpu()
-    assert out.shape == ref.shape
-    assert (out - ref).abs().max().item() <= 1e-3
+    _check_logmel(out.numpy(), ref.numpy(), "n_fft 512 / win 400 (generic radix-2 kernel) vs oracle")
 
 
 def test_mel_errors():
@@ -151,7 +205,7 @@ def test_ragged_mel_batch_equals_per_utterance(tmp_path):
         solo = extract_mel_features(w.cuda().unsqueeze(0), pp)
         assert m.shape == solo.shape and torch.equal(m, solo)
         ref = vo.extract_mel_features(w.unsqueeze(0), pp)
-        assert (m.cpu() - ref).abs().max().item() <= 1e-3
+        _check_logmel(m.cpu().numpy(), ref.numpy(), f"ragged batch item of {w.shape[0]} samples vs oracle")
 
     pp2 = NS(**vars(pp), extract_mel=True, extract_audio=True, extract_energy=True, energy_extract_mode="from_mel",
              extract_amplitude_phase=False, mel_dir="mels", audio_dir="audios", energy_dir="energys")
@@ -165,3 +219,23 @@ def test_ragged_mel_batch_equals_per_utterance(tmp_path):
         assert ma.dtype == np.float32 and ma.ndim == 2 and ma.shape[0] == 80 and np.array_equal(ma, mb)
         assert np.array_equal(np.load(tmp_path / "a" / "audios" / (u["Uid"] + ".npy")), w.numpy())
         assert np.load(tmp_path / "b" / "energys" / (u["Uid"] + ".npy")).shape == (ma.shape[1],)
+
+
+def test_out_of_range_audio_is_reported_without_stalling(capsys):
+    """utils/mel.py:21-24 prints when the audio leaves [-1, 1]; here the notice comes from a later call / an explicit
+    flush (the min / max are read back asynchronously)."""
+    from amphion_amd.utils import mel as M
+
+    pp = vo.preprocess_22k()
+    y = torch.zeros(1, 4096).cuda()
+    y[0, 100] = 1.5
+    y[0, 200] = -2.0
+    M.flush_range_warnings()
+    capsys.readouterr()
+    M.extract_mel_features(y, pp)
+    M.flush_range_warnings()
+    out = capsys.readouterr().out
+    assert "max value is" in out and "1.5" in out and "min value is" in out and "-2.0" in out
+    M.extract_mel_features(y * 0.1, pp)
+    M.flush_range_warnings()
+    assert capsys.readouterr().out == ""

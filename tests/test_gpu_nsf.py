@@ -36,3 +36,20 @@ def test_nsfhifigan_golden(tag):
     assert np.array_equal(y, y0)
     out = vocoder_inference(cfg, m, mel, f0s=f0, device="cuda")     # the reference wrapper's f0 branch (:30-36)
     assert np.abs(out.numpy() - ref[:, 0]).max() <= 1e-4
+
+
+def test_short_f0_is_refused():
+    """The reference crops the waveform to the f0 length when f0 has fewer frames than the mel (nsfhifigan.py:267-269);
+    that crop is not built: the drop-in raises instead of returning audio of a different length."""
+    from amphion_amd.models.vocoders.gan.generator.nsfhifigan import NSFHiFiGAN
+
+    cfg = NS(preprocess=NS(n_mel=80, sample_rate=22050, hop_size=256, extract_amplitude_phase=False),
+             model=NS(nsfhifigan=NS(**HP)))
+    m = NSFHiFiGAN(cfg)
+    m.load_state_dict(synth.synth_state_dict(synth.nsfhifigan_param_shapes(80, HP), 99, g_gain=0.6))
+    m = m.cuda().eval()
+    mel = torch.randn(1, cfg.preprocess.n_mel, 12).cuda()
+    with pytest.raises(ValueError, match="f0"):
+        m(mel, torch.zeros(1, 9).cuda())
+    m(mel, torch.zeros(1, 12).cuda())
+    m(mel, torch.zeros(1, 15).cuda())       # longer f0: the reference crops x_source, not x -- same output

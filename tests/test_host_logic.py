@@ -139,6 +139,29 @@ def test_signature_tracks_parameter_changes():
     assert m.hop_factor == 256
 
 
+def test_per_forward_change_detection_without_the_tree_walk():
+    """_amp_unchanged() (what every forward checks instead of the full signature) sees in-place updates, re-allocated
+    storage and re-registered Parameter objects."""
+    m, sd = _model()
+    m._amp_snap = m._amp_snapshot()
+    assert m._amp_unchanged()
+    with torch.no_grad():
+        m.conv_post.bias.add_(1.0)                      # optimizer step / copy_: version bump
+    assert not m._amp_unchanged()
+    m._amp_snap = m._amp_snapshot()
+    m.load_state_dict(sd)                               # in-place copy_ into every tensor
+    assert not m._amp_unchanged()
+    m._amp_snap = m._amp_snapshot()
+    m.double()                                          # _apply: new storage behind the same Parameter objects
+    assert not m._amp_unchanged()
+    m.float()
+    m._amp_snap = m._amp_snapshot()
+    m.conv_post.bias = torch.nn.Parameter(m.conv_post.bias.detach().clone())   # a new Parameter object
+    assert not m._amp_unchanged()
+    m._amp_snap = m._amp_snapshot()
+    assert m._amp_unchanged()
+
+
 def test_pad_mels_to_tensors_matches_reference_semantics():
     from amphion_amd.utils.util import pad_mels_to_tensors
 
@@ -216,3 +239,22 @@ def test_generator_is_inference_only():
         m2 = HiFiGAN(NS(preprocess=NS(n_mel=8), model=NS(hifigan=NS(**hp)))).eval()
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             m2(torch.zeros(1, 8, 4))
+
+
+def test_bench_relaunch_command_and_cli_guards():
+    """`python bench.py --gpus N` outside a launcher re-executes itself through torch.distributed.run on 127.0.0.1 with
+    N processes (the driver's own launch line); without a GPU it exits with a message, not a traceback."""
+    import importlib.util
+    import subprocess
+    import sys
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cmd = bench.relaunch_command(["--gpus", "4", "--steps", "3"], 4)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "ROCm device" in (r.stderr + r.stdout) and "Traceback" not in r.stderr

@@ -79,6 +79,25 @@ def test_hook_patches_reference_registries():
     assert "PATCHED True" in r.stdout, r.stdout + r.stderr
 
 
+def test_hook_patches_generator_classes_for_direct_importers():
+    # models/tts/vits/vits.py:20 and models/tts/jets/jets.py:23 import the generator CLASSES, not the registries
+    code = (
+        "from models.vocoders.gan.generator.hifigan import HiFiGAN, HiFiGAN_vits;"
+        "import models.vocoders.gan.generator.hifigan as rh, models.vocoders.gan.generator.bigvgan as rb;"
+        "assert HiFiGAN.__module__.startswith('amphion_amd') and HiFiGAN_vits.__module__.startswith('amphion_amd');"
+        "assert rb.BigVGAN.__module__.startswith('amphion_amd');"
+        "assert rh._reference_HiFiGAN.__module__ == 'models.vocoders.gan.generator.hifigan';"
+        "import models.vocoders.vocoder_inference as m;"
+        "assert m._vocoders['hifigan'] is HiFiGAN;"
+        "print('CLASSES PATCHED')"
+    )
+    env = dict(os.environ)
+    env["WORK_DIR"] = REF
+    env["PYTHONPATH"] = os.pathsep.join([os.path.join(ROOT, "amphion_amd", "integration"), os.path.join(ROOT, "tests", "shims"), ROOT, REF])
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=REF, timeout=300)
+    assert "CLASSES PATCHED" in r.stdout, r.stdout + r.stderr
+
+
 def test_hook_patches_codec_registries_too():
     # models/codec/codec_inference.py:39-75 holds its own copy of the three registries
     code = (
