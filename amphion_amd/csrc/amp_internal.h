@@ -64,6 +64,7 @@ struct PairArgs {
     int tiles_per_item;        // per-tile kernel (pair_f16x3.hip): ceil(T / NT)
     int strip_len;             // strip kernel (pair_strip_f16x3.hip): output columns per workgroup ...
     int strips_per_item;       // ... and workgroups per batch item, ceil(T / strip_len)
+    int wide;                  // strip kernel: 1 = the 8-wave, double-width variant (one workgroup per CU)
     int stagger;               // experiment: start delay of de-phased workgroups, in s_sleep(127) units (0 = none)
     int stagger_mode;          // 1: second-slot workgroups (blockIdx >> 8 odd) wait `stagger`; 2: (blockIdx >> 3) & 7 eighths of it
     int dil;
@@ -94,7 +95,7 @@ hipError_t launch_conv_f16x3(const ConvPlan& plan, const ConvArgs& a, hipStream_
 int pair_tile(int k, int C, int dil);
 hipError_t launch_pair(int k, const PairArgs& a, hipStream_t stream);
 // strip-mined fused pair (pair_strip_f16x3.hip): columns per step for (C, k, dilation), 0 = not covered
-int strip_step(int k, int C, int dil, int* wg_per_cu);
+int strip_step(int k, int C, int dil, int wide, int* wg_per_cu);
 hipError_t launch_strip(int k, const PairArgs& a, hipStream_t stream);
 
 // conv_post: y[b,0,t] = tanh( bias + sum_i sum_j w[i][j] * act_in(x[b,i,t+j-pad]) )   (Cout == 1)

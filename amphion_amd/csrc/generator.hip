@@ -192,21 +192,21 @@ hipError_t launch_pair(int k, const PairArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
-int strip_step_kt3(int, int, int*);
-int strip_step_kt5(int, int, int*);
-int strip_step_kt7(int, int, int*);
-int strip_step_kt11(int, int, int*);
+int strip_step_kt3(int, int, int, int*);
+int strip_step_kt5(int, int, int, int*);
+int strip_step_kt7(int, int, int, int*);
+int strip_step_kt11(int, int, int, int*);
 hipError_t launch_strip_kt3(const PairArgs&, hipStream_t);
 hipError_t launch_strip_kt5(const PairArgs&, hipStream_t);
 hipError_t launch_strip_kt7(const PairArgs&, hipStream_t);
 hipError_t launch_strip_kt11(const PairArgs&, hipStream_t);
 
-int strip_step(int k, int C, int dil, int* wg) {
+int strip_step(int k, int C, int dil, int wide, int* wg) {
     switch (k) {
-        case 3: return strip_step_kt3(C, dil, wg);
-        case 5: return strip_step_kt5(C, dil, wg);
-        case 7: return strip_step_kt7(C, dil, wg);
-        case 11: return strip_step_kt11(C, dil, wg);
+        case 3: return strip_step_kt3(C, dil, wide, wg);
+        case 5: return strip_step_kt5(C, dil, wide, wg);
+        case 7: return strip_step_kt7(C, dil, wide, wg);
+        case 11: return strip_step_kt11(C, dil, wide, wg);
     }
     return 0;
 }
@@ -231,18 +231,33 @@ static bool fuse_pairs_enabled() {
     return g_fuse_pairs != 0;
 }
 
-// AMP_PAIR_STRIP=1 / amp_set_pair_strips(1) runs the fused pairs on the strip-mined kernel (pair_strip_f16x3.hip)
-// instead of the per-tile kernel (pair_f16x3.hip).  Bit-identical results; measured on MI355X (profiles/r2_c_*,
-// r2_d_*): it removes the k - 1 seam columns per tile but loses the free load balancing and phase mixing of 12 000
-// independent tiles -- 33.9 vs 31.9 ms per config-2 step -- so it is OFF by default (kept as the bitwise cross-check
-// of tests/test_gpu_pair.py and as the only fused form for C = 256).
-static int g_pair_strips = -1;
-static bool pair_strips_enabled() {
-    if (g_pair_strips < 0) {
+// Which fused-pair kernel a (C, k) pair runs.  Results are bit-identical either way (tests/test_gpu_pair.py); the choice
+// is measured (profiles/r2_cd_strip_kernel.txt, r2_j_strip_policy.txt): the strip-mined kernel (pair_strip_f16x3.hip)
+// removes the k - 1 seam columns and most of the halo re-staging but gives up the free load balancing of 12 000
+// independent tiles.  In the forward it wins 1.5 % on the k = 11, C = 128 pairs (2 093 -> 2 061 us) and loses
+// everywhere else, so the policy is the per-tile kernel for every shape it covers.
+//   amp_set_pair_strips(-1) / AMP_PAIR_STRIP unset: the measured policy below;  0: per-tile kernel everywhere
+//   (round 1);  1: strips wherever they are built (incl. C = 256, which has no per-tile form).
+struct StripChoice { bool use; int wide; int steps; };   // steps = 0: the planner sizes the strips
+static int g_pair_strips = -2;
+static StripChoice strip_choice(int C, int k) {
+    if (g_pair_strips == -2) {
         const char* e = getenv("AMP_PAIR_STRIP");
-        g_pair_strips = (e && !strcmp(e, "1")) ? 1 : 0;
+        g_pair_strips = !e ? -1 : (!strcmp(e, "1") ? 1 : (!strcmp(e, "0") ? 0 : -1));
     }
-    return g_pair_strips != 0;
+    if (g_pair_strips == 0) return {false, 0, 0};
+    if (g_pair_strips == 1) return {true, 0, 0};
+    static const int k11 = [] { const char* e = getenv("AMP_STRIP_K11"); return e ? atoi(e) : 0; }();   // experiment switch, default 0
+    if (C == 128 && k == 11) {
+        switch (k11) {
+            case 1: return {true, 0, 0};    // narrow strips, planner
+            case 2: return {true, 1, 1};    // wide tiles
+            case 3: return {true, 1, 2};    // wide, 2 steps
+            case 4: return {true, 1, 0};    // wide, planner
+            default: return {false, 0, 0};
+        }
+    }
+    return {false, 0, 0};
 }
 
 // Strip plan: `spi` workgroups per item, each walking ceil((L + k - 1) / n1) steps of n1 columns.  The chip holds
@@ -463,7 +478,8 @@ static bool pair_supported(const amp_conv* c1, const amp_conv* c2) {
     if (c1->k != c2->k || c2->dilation != 1 || c1->k != c1->KT) return false;
     if (c1->padding != (c1->k - 1) / 2 * c1->dilation || c2->padding != (c2->k - 1) / 2) return false;
     if (!c1->bias_dev || !c2->bias_dev) return false;
-    if (pair_strips_enabled() && strip_step(c1->k, c1->cin, c1->dilation, nullptr) > 0) return true;
+    const StripChoice sc = strip_choice(c1->cin, c1->k);
+    if (sc.use && strip_step(c1->k, c1->cin, c1->dilation, sc.wide, nullptr) > 0) return true;
     return pair_tile(c1->k, c1->cin, c1->dilation) > 0;
 }
 
@@ -482,11 +498,14 @@ static int pair_run(const amp_conv* c1, const amp_conv* c2, const float* x, int 
     a.lens = lens; a.len_mul = len_mul;
     a.range_flag = range_flag_for_current_device();
     int wg = 2;
-    const int n1 = pair_strips_enabled() ? strip_step(c1->k, c1->cin, c1->dilation, &wg) : 0;
+    const StripChoice sc = strip_choice(c1->cin, c1->k);
+    const int n1 = sc.use ? strip_step(c1->k, c1->cin, c1->dilation, sc.wide, &wg) : 0;
     if (n1 > 0) {
+        a.wide = sc.wide;
         strip_plan(B, T, n1, c1->k - 1, wg, &a.strip_len, &a.strips_per_item);
-        { const char* e = getenv("AMP_STRIP_STEPS"); if (e && atoi(e) > 0) { a.strip_len = atoi(e) * n1 - (c1->k - 1); a.strips_per_item = (T + a.strip_len - 1) / a.strip_len; } }
-        { const char* e = getenv("AMP_STRIP_SPI_MUL"); if (e && atoi(e) > 1) { a.strips_per_item *= atoi(e); a.strip_len = (T + a.strips_per_item - 1) / a.strips_per_item; } }
+        int steps = sc.steps;
+        { const char* e = getenv("AMP_STRIP_STEPS"); if (e && atoi(e) > 0) steps = atoi(e); }
+        if (steps > 0 && steps * n1 - (c1->k - 1) < T) { a.strip_len = steps * n1 - (c1->k - 1); a.strips_per_item = (T + a.strip_len - 1) / a.strip_len; }
         { const char* e = getenv("AMP_STRIP_STAGGER"); a.stagger = e ? atoi(e) : 0; e = getenv("AMP_STRIP_STAGGER_MODE"); a.stagger_mode = e ? atoi(e) : 1; }
         AMP_HIP(launch_strip(c1->k, a, stream));
         return AMP_OK;
@@ -546,7 +565,15 @@ struct amp_gen {
     };
     std::vector<ProfSlot> prof;          // empty = profiling off
     size_t prof_count = 0;               // forwards recorded so far
+    // concurrent resblocks (BigVGAN): side streams for resblocks 1 .. n_kernels-1, fork / accumulate-order events
+    int n_side = 0;
+    hipStream_t side[AMP_MAX_KERNELS] = {};
+    hipEvent_t ev_fork = nullptr;
+    hipEvent_t ev_last[AMP_MAX_KERNELS] = {};
     ~amp_gen() {
+        for (int i = 0; i < n_side; ++i) if (side[i]) (void)hipStreamDestroy(side[i]);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        for (auto e : ev_last) if (e) (void)hipEventDestroy(e);
         for (float* p : dev_allocs) (void)hipFree(p);
         for (auto& p : prof) {
             if (p.ev_begin) (void)hipEventDestroy(p.ev_begin);
@@ -815,6 +842,15 @@ int amp_gen_finalize(amp_gen* g) {
         if ((rc = upload(g, w.data(), w.size(), &g->post_w_dev)) != AMP_OK) return rc;
         if (bias) if ((rc = upload(g, bias, 1, &g->post_b_dev)) != AMP_OK) return rc;
     }
+    {
+        const char* e = getenv("AMP_BIGVGAN_STREAMS");
+        const bool want = g->d.arch == AMP_ARCH_BIGVGAN && g->d.n_kernels > 1 && e && !strcmp(e, "1");
+        if (want) {
+            AMP_HIP(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
+            for (int j = 0; j < g->d.n_kernels; ++j) AMP_HIP(hipEventCreateWithFlags(&g->ev_last[j], hipEventDisableTiming));
+            for (int j = 0; j + 1 < g->d.n_kernels; ++j) { AMP_HIP(hipStreamCreateWithFlags(&g->side[j], hipStreamNonBlocking)); g->n_side = j + 1; }
+        }
+    }
     g->w.clear();  // host copies no longer needed
     g->finalized = true;
     return AMP_OK;
@@ -833,7 +869,17 @@ static size_t gen_buf_elems(const amp_gen* g, int B, int T) {
     return (mx + 63) & ~(size_t)63;
 }
 
-static int gen_num_bufs(const amp_gen* g) { return g->d.arch == AMP_ARCH_BIGVGAN ? 6 : 5; }
+// BigVGAN's forward alternates MFMA-bound convs with VALU-bound anti-aliased activations (a third of its time):
+// the n_kernels resblocks of a stage are independent until they accumulate into the MRF sum, so each runs on its
+// own stream (own R / TMP / ACT scratch) and the activation waves of one can fill the VALU slots under the conv waves
+// of another (they fit beside them: 64 VGPRs next to 2 x 223).  Opt-in with AMP_BIGVGAN_STREAMS=1: on MI355X the
+// kernels do overlap (rocprofv3: act1d launches 132 -> 250 us, convs 380 -> 820 us while co-resident) but the forward
+// takes the same 28.1 ms (profiles/r2_i_bigvgan_streams.txt) -- the package power limit, not issue slots, is the bound.
+static bool gen_concurrent(const amp_gen* g) { return g->n_side > 0; }
+static int gen_num_bufs(const amp_gen* g) {
+    if (gen_concurrent(g)) return 3 + 3 * g->d.n_kernels;
+    return g->d.arch == AMP_ARCH_BIGVGAN ? 6 : 5;
+}
 
 // Optional depth-first batch grouping: a group of items runs through the WHOLE generator before the
 // next one starts, with a working set (the scratch tensors of its largest stage) bounded by
@@ -867,7 +913,7 @@ size_t amp_gen_workspace_bytes(const amp_gen* g, int B, int T) {
 }
 
 int amp_set_pair_strips(int on) {
-    if (on != 0 && on != 1) { set_error("amp_set_pair_strips: %d", on); return AMP_ERR_INVALID; }
+    if (on < -1 || on > 1) { set_error("amp_set_pair_strips: %d", on); return AMP_ERR_INVALID; }
     g_pair_strips = on;
     return AMP_OK;
 }
@@ -953,6 +999,7 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
     float* R = base + 3 * be;   // running x inside a resblock
     float* TMP = base + 4 * be; // xt between the two convs of a pair
     float* ACT = big ? base + 5 * be : nullptr;  // anti-aliased activation output
+    const bool conc = gen_concurrent(g);         // BigVGAN: the resblocks of a stage on separate streams (buffers 3 + 3 j ..)
     float* CB = base + (size_t)gen_num_bufs(g) * be;  // cond(g): [B, C0]
     const float slope = 0.1f;  // LRELU_SLOPE hifigan.py:14
 
@@ -971,43 +1018,61 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
         t *= d.upsample_rates[i];
         lm *= d.upsample_rates[i];
         if (ev_mrf) AMP_HIP(hipEventRecord(ev_mrf[2 * i], st));
+        if (conc) AMP_HIP(hipEventRecord(g->ev_fork, st));
         for (int j = 0; j < nk; ++j) {
-            if (ev_rb) AMP_HIP(hipEventRecord(ev_rb[(size_t)i * (nk + 1) + j], st));
+            // BigVGAN with concurrent resblocks: resblock j runs on its own stream with its own R / TMP / ACT buffers
+            // (they all read U); only the last conv of each touches XS, and those are chained j-1 -> j by events
+            hipStream_t sj = st;
+            float* R_ = R;
+            float* TMP_ = TMP;
+            float* ACT_ = ACT;
+            if (conc) {
+                R_ = base + (size_t)(3 + 3 * j) * be;
+                TMP_ = R_ + be;
+                ACT_ = TMP_ + be;
+                if (j > 0) {
+                    sj = g->side[j - 1];
+                    AMP_HIP(hipStreamWaitEvent(sj, g->ev_fork, 0));
+                }
+            }
+            if (ev_rb && !conc) AMP_HIP(hipEventRecord(ev_rb[(size_t)i * (nk + 1) + j], sj));
             const ResBlock& rb = g->rbs[(size_t)i * nk + j];
             const int nd = (int)rb.dil.size();
             const int mode_last = (nk == 1) ? 0 : (j == 0 ? 0 : (j == nk - 1 ? 2 : 1));
             const float* cur = U;
             for (int p = 0; p < nd; ++p) {
                 const bool last = p == nd - 1;
+                // every launch of the last pair / conv comes after the previous resblock's accumulation into XS
+                if (conc && last && j > 0) AMP_HIP(hipStreamWaitEvent(sj, g->ev_last[j - 1], 0));
                 if (d.resblock_type == 1) {
                     if (!big && pair_supported(rb.c1[p].get(), rb.c2[p].get())) {
-                        // the whole pair in one kernel; the output ping-pongs R <-> TMP (never in place:
+                        // the whole pair in one kernel; the output ping-pongs R_ <-> TMP_ (never in place:
                         // other tiles still read the input's halo)
-                        float* dst = last ? XS : (cur == R ? TMP : R);
-                        AMP_RC(pair_run(rb.c1[p].get(), rb.c2[p].get(), cur, B, t, slope, dst, last ? mode_last : 0, (float)nk, st, lens, lm));
+                        float* dst = last ? XS : (cur == R_ ? TMP_ : R_);
+                        AMP_RC(pair_run(rb.c1[p].get(), rb.c2[p].get(), cur, B, t, slope, dst, last ? mode_last : 0, (float)nk, sj, lens, lm));
                         cur = dst;
                     } else if (!big) {
                         // xt = lrelu(c1(lrelu(x))) ; x = c2(xt) + x        hifigan.py:93-100
-                        if (cur == TMP) {  // previous pair was fused into TMP: keep the unfused ping-pong legal
-                            AMP_HIP(hipMemcpyAsync(R, TMP, (size_t)B * C * t * sizeof(float), hipMemcpyDeviceToDevice, st));
-                            cur = R;
+                        if (cur == TMP_) {  // previous pair was fused into TMP_: keep the unfused ping-pong legal
+                            AMP_HIP(hipMemcpyAsync(R_, TMP_, (size_t)B * C * t * sizeof(float), hipMemcpyDeviceToDevice, sj));
+                            cur = R_;
                         }
-                        AMP_RC(conv_run(rb.c1[p].get(), cur, B, t, slope, nullptr, slope, TMP, 0, 1.f, st, 0, lens, lm));
-                        if (!last) { AMP_RC(conv_run(rb.c2[p].get(), TMP, B, t, 1.f, cur, 1.f, R, 0, 1.f, st, 0, lens, lm)); cur = R; }
-                        else AMP_RC(conv_run(rb.c2[p].get(), TMP, B, t, 1.f, cur, 1.f, XS, mode_last, (float)nk, st, 0, lens, lm));
+                        AMP_RC(conv_run(rb.c1[p].get(), cur, B, t, slope, nullptr, slope, TMP_, 0, 1.f, sj, 0, lens, lm));
+                        if (!last) { AMP_RC(conv_run(rb.c2[p].get(), TMP_, B, t, 1.f, cur, 1.f, R_, 0, 1.f, sj, 0, lens, lm)); cur = R_; }
+                        else AMP_RC(conv_run(rb.c2[p].get(), TMP_, B, t, 1.f, cur, 1.f, XS, mode_last, (float)nk, sj, 0, lens, lm));
                     } else {
                         // xt = c2(a2(c1(a1(x)))) ; x = xt + x              bigvgan.py:137-146
                         const ActParams& a1 = rb.acts[2 * p];
                         const ActParams& a2 = rb.acts[2 * p + 1];
-                        AMP_HIP(launch_act1d(cur, ACT, B, C, t, a1.a_dev, a1.invb_dev, a1.fu_dev, a1.fd_dev, lens, lm, st));
-                        if (cur == TMP) {  // a previous pair was fused into TMP: keep the unfused ping-pong legal
-                            AMP_HIP(hipMemcpyAsync(R, TMP, (size_t)B * C * t * sizeof(float), hipMemcpyDeviceToDevice, st));
-                            cur = R;
+                        AMP_HIP(launch_act1d(cur, ACT_, B, C, t, a1.a_dev, a1.invb_dev, a1.fu_dev, a1.fd_dev, lens, lm, sj));
+                        if (cur == TMP_) {  // a previous pair was fused into TMP_: keep the unfused ping-pong legal
+                            AMP_HIP(hipMemcpyAsync(R_, TMP_, (size_t)B * C * t * sizeof(float), hipMemcpyDeviceToDevice, sj));
+                            cur = R_;
                         }
-                        AMP_RC(conv_run(rb.c1[p].get(), ACT, B, t, 1.f, nullptr, 1.f, TMP, 0, 1.f, st, 0, lens, lm));
-                        AMP_HIP(launch_act1d(TMP, ACT, B, C, t, a2.a_dev, a2.invb_dev, a2.fu_dev, a2.fd_dev, lens, lm, st));
-                        if (!last) { AMP_RC(conv_run(rb.c2[p].get(), ACT, B, t, 1.f, cur, 1.f, R, 0, 1.f, st, 0, lens, lm)); cur = R; }
-                        else AMP_RC(conv_run(rb.c2[p].get(), ACT, B, t, 1.f, cur, 1.f, XS, mode_last, (float)nk, st, 0, lens, lm));
+                        AMP_RC(conv_run(rb.c1[p].get(), ACT_, B, t, 1.f, nullptr, 1.f, TMP_, 0, 1.f, sj, 0, lens, lm));
+                        AMP_HIP(launch_act1d(TMP_, ACT_, B, C, t, a2.a_dev, a2.invb_dev, a2.fu_dev, a2.fd_dev, lens, lm, sj));
+                        if (!last) { AMP_RC(conv_run(rb.c2[p].get(), ACT_, B, t, 1.f, cur, 1.f, R_, 0, 1.f, sj, 0, lens, lm)); cur = R_; }
+                        else AMP_RC(conv_run(rb.c2[p].get(), ACT_, B, t, 1.f, cur, 1.f, XS, mode_last, (float)nk, sj, 0, lens, lm));
                     }
                 } else {
                     // x = c(act(x)) + x                                    hifigan.py:140-145, bigvgan.py:218-224
@@ -1015,21 +1080,23 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
                     float sl = slope;
                     if (big) {
                         const ActParams& a1 = rb.acts[p];
-                        AMP_HIP(launch_act1d(cur, ACT, B, C, t, a1.a_dev, a1.invb_dev, a1.fu_dev, a1.fd_dev, lens, lm, st));
-                        in = ACT;
+                        AMP_HIP(launch_act1d(cur, ACT_, B, C, t, a1.a_dev, a1.invb_dev, a1.fu_dev, a1.fd_dev, lens, lm, sj));
+                        in = ACT_;
                         sl = 1.f;
                     }
                     if (!last) {
                         // the conv reads a halo of `in`; never write the tensor it is reading
-                        float* dst = (in == cur && cur == R) ? TMP : R;
-                        AMP_RC(conv_run(rb.c1[p].get(), in, B, t, sl, cur, 1.f, dst, 0, 1.f, st, 0, lens, lm));
+                        float* dst = (in == cur && cur == R_) ? TMP_ : R_;
+                        AMP_RC(conv_run(rb.c1[p].get(), in, B, t, sl, cur, 1.f, dst, 0, 1.f, sj, 0, lens, lm));
                         cur = dst;
                     } else {
-                        AMP_RC(conv_run(rb.c1[p].get(), in, B, t, sl, cur, 1.f, XS, mode_last, (float)nk, st, 0, lens, lm));
+                        AMP_RC(conv_run(rb.c1[p].get(), in, B, t, sl, cur, 1.f, XS, mode_last, (float)nk, sj, 0, lens, lm));
                     }
                 }
             }
+            if (conc) AMP_HIP(hipEventRecord(g->ev_last[j], sj));
         }
+        if (conc) AMP_HIP(hipStreamWaitEvent(st, g->ev_last[nk - 1], 0));   // join: the chain j-1 -> j orders every side stream before this
         if (ev_rb) AMP_HIP(hipEventRecord(ev_rb[(size_t)i * (nk + 1) + nk], st));
         if (ev_mrf) AMP_HIP(hipEventRecord(ev_mrf[2 * i + 1], st));
         float* tmp = X; X = XS; XS = tmp;  // x = xs / num_kernels

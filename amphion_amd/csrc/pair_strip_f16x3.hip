@@ -377,24 +377,18 @@ static hipError_t launch_strip_one(const PairArgs& a, hipStream_t stream) {
 #define AMP_CAT2(a, b) a##b
 #define AMP_CAT(a, b) AMP_CAT2(a, b)
 
-// AMP_STRIP_WIDE=1 (experiment): 8-wave workgroups with twice the step width, one per CU -- waves (wm, 0) and (wm, 1)
-// fetch the same A fragments (the second hits L1), the k - 1 seam columns and the dilated halo are paid once per 2 x
-// the columns.
-static bool strip_wide() {
-    static const bool on = [] { const char* e = getenv("AMP_STRIP_WIDE"); return e && !strcmp(e, "1"); }();
-    return on;
-}
-
 // Step width (xt columns = output columns per step) for C channels, or 0 when (C, KT, dilation) is not covered;
 // *wg_per_cu = resident workgroups per CU (LDS / register bound), used by the host to size the strips.
-int AMP_CAT(strip_step_kt, AMP_KT)(int C, int dil, int* wg_per_cu) {
+// wide = 1: 8-wave workgroups with twice the step width, one per CU -- waves (wm, 0) and (wm, 1) fetch the same A
+// fragments (the second hits L1), and the k - 1 seam columns / the dilated halo are paid once per 2 x the columns.
+int AMP_CAT(strip_step_kt, AMP_KT)(int C, int dil, int wide, int* wg_per_cu) {
     constexpr int KT = AMP_KT;
     const int span = (KT - 1) * dil;   // staged halo = 2 * h1
     int n1 = 0, wg = 2;
     if (C == 256) { n1 = (96 + span <= 256) ? 96 : 0; wg = 1; }
-    else if (strip_wide() && C == 128) { n1 = (192 + span <= 256) ? 192 : 0; wg = 1; }
-    else if (strip_wide() && C == 64) { n1 = (256 + span <= 384) ? 256 : 0; wg = 1; }
-    else if (strip_wide() && C == 32) { n1 = (512 + span <= 640) ? 512 : 0; wg = 1; }
+    else if (wide && C == 128) { n1 = (192 + span <= 256) ? 192 : 0; wg = 1; }
+    else if (wide && C == 64) { n1 = (256 + span <= 384) ? 256 : 0; wg = 1; }
+    else if (wide && C == 32) { n1 = (512 + span <= 640) ? 512 : 0; wg = 1; }
     else if (C == 128) n1 = (96 + span <= 192) ? 96 : 0;
     else if (C == 64) n1 = (128 + span <= 192) ? 128 : 0;
     else if (C == 32) n1 = (256 + span <= 320) ? 256 : 0;
@@ -406,7 +400,7 @@ hipError_t AMP_CAT(launch_strip_kt, AMP_KT)(const PairArgs& a, hipStream_t strea
     constexpr int KT = AMP_KT;
     const int span = (KT - 1) * a.dil;
     if (a.C == 256) return launch_strip_one<KT, 8, 1, 3, 256>(a, stream);
-    if (strip_wide()) {
+    if (a.wide) {
         if (a.C == 128) return launch_strip_one<KT, 4, 2, 3, 256>(a, stream);
         if (a.C == 64) return launch_strip_one<KT, 2, 4, 2, 384>(a, stream);
         if (a.C == 32) return launch_strip_one<KT, 1, 8, 2, 640>(a, stream);

@@ -131,10 +131,10 @@ int amp_set_group_mb(int megabytes);
  * fp32 MFMA kernels have the reference's range). */
 int amp_range_check(void* stream);
 
-/* Fused ResBlock pairs (hifigan.py:93-100) run the per-tile kernel -- 0, the default -- or the strip-mined kernel (a
- * workgroup walks a strip of one utterance and carries conv2's halo in LDS; also covers C = 256) -- 1; also the
- * environment variable AMP_PAIR_STRIP.  Results are bit-identical (tests/test_gpu_pair.py); a tuning / cross-check
- * switch. */
+/* Fused ResBlock pairs (hifigan.py:93-100) have two kernels with bit-identical results (tests/test_gpu_pair.py): the
+ * per-tile kernel and the strip-mined kernel (a workgroup walks a strip of one utterance and carries conv2's halo in
+ * LDS; also covers C = 256).  -1 (default; AMP_PAIR_STRIP unset): the measured per-shape policy; 0: per-tile
+ * everywhere; 1: strips wherever they exist.  A tuning / cross-check switch. */
 int amp_set_pair_strips(int on);
 
 /* Replaces HiFiGAN.forward (hifigan.py:203-219), BigVGAN.forward (bigvgan.py:313-331) and

@@ -66,7 +66,7 @@ def strips():
     def use(on):
         _lib.check(_lib.lib().amp_set_pair_strips(1 if on else 0))
     yield use
-    _lib.check(_lib.lib().amp_set_pair_strips(0))
+    _lib.check(_lib.lib().amp_set_pair_strips(-1))
 
 
 @pytest.mark.parametrize("C,k,d,B,T", [c for c in PAIR_CASES if c[0] <= 128] + [c for c in STRIP_CASES if c[0] <= 128])

@@ -55,7 +55,7 @@ def main():
                 for h in hs:
                     L.amp_conv_destroy(h)
         del x, y
-    L.amp_set_pair_strips(1)
+    L.amp_set_pair_strips(-1)
 
 
 if __name__ == "__main__":
