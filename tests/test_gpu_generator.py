@@ -110,3 +110,20 @@ def test_cpu_input_raises():
     m, _ = _hifigan(vo.hifigan_v1_hp(), 80, 1234)
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 80, 4))
+
+
+def test_jets_waveform_decoder_golden():
+    """JETS (models/tts/jets/jets.py:454-458,619) decodes with the registry's HiFiGAN built from the recipe config with
+    n_mel = attention_dim = 256, called on the up-sampled hidden states: golden vectors of the REAL reference class
+    (tests/golden/make_golden_jets.py)."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_jets.npz"))
+    m, sd = _hifigan(vo.hifigan_recipe_hp(), 256, 2024)
+    z = torch.from_numpy(g["z"])
+    with torch.no_grad():
+        y = m(z.cuda()).cpu().numpy()
+    assert y.shape == g["wav"].shape
+    assert np.abs(y - g["wav"]).max() <= TOL
+    ref = vo.hifigan_forward(sd, vo.hifigan_recipe_hp(), z, dtype=torch.float64).numpy()
+    assert np.abs(y - ref).max() <= TOL

@@ -122,3 +122,18 @@ def test_mel_front_end(golden, tag, pp):
     mel, energy = vo.taco_mel_spectrogram(y2, pp.n_fft, pp.hop_size, pp.win_size, pp.n_mel, pp.sample_rate, pp.fmin, pp.fmax)
     assert np.abs(mel.numpy() - golden[f"taco_{tag}_mel"]).max() <= 2e-4
     assert np.abs(energy.numpy() - golden[f"taco_{tag}_energy"]).max() <= 2e-4 * max(1.0, float(energy.max()))
+
+
+def test_oracle_jets_waveform_decoder():
+    """The oracle on the JETS decoder architecture (jets.py:454-458: recipe HiFi-GAN, n_mel = attention_dim = 256)
+    against golden vectors of the real reference class (tests/golden/make_golden_jets.py)."""
+    import json
+
+    g = np.load(os.path.join(HERE, "golden", "golden_jets.npz"))
+    hp = vo.hifigan_recipe_hp()
+    shapes = synth.hifigan_param_shapes(256, hp)
+    with open(os.path.join(HERE, "golden", "keys_hifigan_jets.json")) as f:
+        assert [(k, tuple(v)) for k, v in json.load(f)] == [(k, tuple(v)) for k, v in shapes.items()]
+    sd = synth.synth_state_dict(shapes, 2024, g_gain=1.0)
+    y = vo.hifigan_forward(sd, hp, torch.from_numpy(g["z"])).numpy()
+    assert np.abs(y - g["wav"]).max() <= 2e-6
