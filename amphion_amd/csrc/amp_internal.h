@@ -143,8 +143,8 @@ void set_error(const char* fmt, ...);
 // The f16x3 kernels stage fp32 activations as hi + lo f16 pairs after an exact x16: anything beyond |x| = 4094 (or
 // non-finite) cannot be represented.  They OR 1 into this per-device word when that happens (range_guard.hip).
 unsigned* range_flag_for_current_device();
-// true when `v` (already scaled) does not fit the f16 operand range
-__device__ __forceinline__ bool f16_range_bad(float v) { return !(__builtin_fabsf(v) <= 65504.f); }
+// (the kernels keep the running maximum of |staged value|: one v_max_f32 per element; a NaN operand is not flagged --
+// it propagates to the output exactly as it does through the fp32 reference)
 
 // v = hi + lo with hi = f16(v), lo = f16(v - hi): the split-f16 operand form of the f16x3 kernels.
 // The empty asm makes `v` opaque: under HIP's default -ffp-contract=fast hipcc otherwise folds the

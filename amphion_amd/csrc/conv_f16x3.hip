@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
     // lose its vmcnt bookkeeping), stage_store applies the zero padding as a select, then leaky_relu,
     // the x16 scaling and the hi/lo split.  4*S is a multiple of 256 and S of 64: every thread has
     // exactly NST items and an item's quad is wave-uniform.
-    bool range_bad = false;      // any staged operand outside the f16 range (reported through a.range_flag)
+    float range_max = 0.f;       // largest |staged operand| (x16 applied): beyond 65504 it left the f16 range (a.range_flag)
     float xs[NST][4];
     auto stage_load = [&](int chunk) {
 #pragma unroll
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
             for (int e = 0; e < 4; ++e) {
                 float v = (tok && (ch0 + e) < a.Cin) ? xs[it][e] : 0.f;
                 v = v * (v > 0.f ? kpos : kneg);
-                range_bad |= f16_range_bad(v);
+                range_max = __builtin_fmaxf(range_max, __builtin_fabsf(v));
                 split_f16(v, fh.h[e], fl.h[e]);
             }
             // uint2 index inside a plane: ((octet * S + col) * 2 + half)
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
         __syncthreads();
     }
 
-    if (a.range_flag && __any(range_bad) && lane == 0) atomicOr(a.range_flag, 1u);
+    if (a.range_flag && __any(range_max > 65504.f) && lane == 0) atomicOr(a.range_flag, 1u);
 
     // ---- epilogue: undo the operand scaling, MRF mean, activation-on-store, (polyphase) scatter ----
     const float slope_out = a.slope_out;

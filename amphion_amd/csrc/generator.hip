@@ -247,17 +247,23 @@ static StripChoice strip_choice(int C, int k) {
     }
     if (g_pair_strips == 0) return {false, 0, 0};
     if (g_pair_strips == 1) return {true, 0, 0};
-    static const int k11 = [] { const char* e = getenv("AMP_STRIP_K11"); return e ? atoi(e) : 0; }();   // experiment switch, default 0
-    if (C == 128 && k == 11) {
-        switch (k11) {
-            case 1: return {true, 0, 0};    // narrow strips, planner
-            case 2: return {true, 1, 1};    // wide tiles
-            case 3: return {true, 1, 2};    // wide, 2 steps
-            case 4: return {true, 1, 0};    // wide, planner
-            default: return {false, 0, 0};
-        }
+    // experiment switches (default 0 = per-tile kernel): AMP_STRIP_K11 for the k = 11, C = 128 pairs only,
+    // AMP_STRIP_C128 for every C = 128 pair.  1 narrow strips, planner | 2 wide tiles | 3 wide, 2 steps | 4 wide, planner |
+    // 5 / 6 / 7: the 4-wave 2 x 2-blocked variant (64 rows x 96 columns per wave, one workgroup per CU) as tiles /
+    // 2 steps / planner
+    static const int k11 = [] { const char* e = getenv("AMP_STRIP_K11"); return e ? atoi(e) : 0; }();
+    static const int c128 = [] { const char* e = getenv("AMP_STRIP_C128"); return e ? atoi(e) : 0; }();
+    const int v = (C == 128 && c128) ? c128 : ((C == 128 && k == 11) ? k11 : 0);
+    switch (v) {
+        case 1: return {true, 0, 0};
+        case 2: return {true, 1, 1};
+        case 3: return {true, 1, 2};
+        case 4: return {true, 1, 0};
+        case 5: return {true, 2, 1};
+        case 6: return {true, 2, 2};
+        case 7: return {true, 2, 0};
+        default: return {false, 0, 0};
     }
-    return {false, 0, 0};
 }
 
 // Strip plan: `spi` workgroups per item, each walking ceil((L + k - 1) / n1) steps of n1 columns.  The chip holds

