@@ -78,6 +78,7 @@ _SIGNATURES = {
     "amp_set_group_mb": (c_int, [c_int]),
     "amp_set_pair_strips": (c_int, [c_int]),
     "amp_range_check": (c_int, [c_void_p]),
+    "amp_gen_range_check": (c_int, [c_void_p, c_void_p]),
     "amp_gen_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "amp_gen_forward_ragged": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "amp_gen_set_profiling": (c_int, [c_void_p, c_int]),
@@ -136,6 +137,11 @@ def lib():
                 f"{LIB_PATH} not found: build it with `python -m amphion_amd.build` "
                 "(the HIP path has no CPU fallback)"
             )
+        # torch's own libamdhip64 must be the HIP runtime of the process: loading this library first would pull in
+        # /opt/rocm's copy, and the two runtimes do not see each other's devices or allocations ("no HIP device visible"
+        # from a process that imported this module before torch)
+        import torch  # noqa: F401
+
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)
@@ -167,9 +173,10 @@ AMP_ERR_RANGE = -6
 
 
 def range_check(device=None):
-    """Synchronise the current stream of ``device`` and raise ``AmpError`` (status AMP_ERR_RANGE) if any f16x3 launch
-    since the last check staged an activation beyond the split-f16 operand range (|x| > 4094 or non-finite): the
-    output of that launch is not the fp32 reference's (``amp_range_check``)."""
+    """Synchronise the current stream of ``device`` and raise ``AmpError`` (status AMP_ERR_RANGE) if an OP-LEVEL f16x3
+    launch (``amp_conv_forward``, ``amp_pair_forward``) since the last check staged an activation beyond the split-f16
+    operand range (|x| > 4094 or infinite): the output of that launch is not the fp32 reference's
+    (``amp_range_check``).  Generators have their own flag: ``generator.check_range()``."""
     import torch
 
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)

@@ -58,35 +58,48 @@ static const int kSupportedKT[] = {1, 2, 3, 5, 7, 11};
 // ---- f16 operand-range guard -------------------------------------------------------------------------------------
 // The f16x3 kernels OR 1 into a per-device word when a staged operand does not fit the split-f16 form (|x| > 4094
 // after the exact x16, or non-finite): the fp32 reference has no such cliff, so the result of that launch is NOT the
-// reference's.  amp_gen_forward copies the word to pinned host memory behind its last kernel (no synchronisation) and
-// the NEXT call on that device that finds the copy complete returns AMP_ERR_RANGE; amp_range_check() synchronises and
-// reports immediately.  Both clear the word.
+// reference's.  A generator handle has its OWN word: amp_gen_forward copies it to pinned host memory behind its last
+// kernel (no synchronisation) and the NEXT forward of that handle that finds the copy complete returns AMP_ERR_RANGE;
+// amp_gen_range_check() synchronises and reports immediately.  Op-level launches (amp_conv_forward, amp_pair_forward)
+// report to one word per device, read by amp_range_check().  Every report clears its word.
 struct RangeGuard {
     unsigned* dev = nullptr;       // device word the kernels write
     unsigned* host = nullptr;      // pinned mirror
     hipEvent_t ev = nullptr;
     bool pending = false;          // an async copy of `dev` is in flight / unread
 };
-static RangeGuard g_guard[64];
+static RangeGuard g_guard[64];                    // op-level launches (amp_conv_forward, amp_pair_forward, ...): one word per device
+static thread_local unsigned* tl_range_flag = nullptr;   // set while an amp_gen forward is launching: that handle's own word
+
+static bool guard_init(RangeGuard& g) {
+    if (g.dev) return true;
+    if (hipMalloc(&g.dev, sizeof(unsigned)) != hipSuccess) { g.dev = nullptr; return false; }
+    if (hipMemset(g.dev, 0, sizeof(unsigned)) != hipSuccess || hipHostMalloc(&g.host, sizeof(unsigned)) != hipSuccess ||
+        hipEventCreateWithFlags(&g.ev, hipEventDisableTiming) != hipSuccess) {
+        (void)hipFree(g.dev);
+        g.dev = nullptr;
+        return false;
+    }
+    *g.host = 0;
+    return true;
+}
+
+static void guard_free(RangeGuard& g) {
+    if (g.dev) (void)hipFree(g.dev);
+    if (g.host) (void)hipHostFree(g.host);
+    if (g.ev) (void)hipEventDestroy(g.ev);
+    g = RangeGuard{};
+}
 
 static RangeGuard* guard_for_current_device() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    RangeGuard& g = g_guard[dev];
-    if (!g.dev) {
-        if (hipMalloc(&g.dev, sizeof(unsigned)) != hipSuccess) { g.dev = nullptr; return nullptr; }
-        if (hipMemset(g.dev, 0, sizeof(unsigned)) != hipSuccess || hipHostMalloc(&g.host, sizeof(unsigned)) != hipSuccess ||
-            hipEventCreateWithFlags(&g.ev, hipEventDisableTiming) != hipSuccess) {
-            (void)hipFree(g.dev);
-            g.dev = nullptr;
-            return nullptr;
-        }
-        *g.host = 0;
-    }
-    return &g;
+    return guard_init(g_guard[dev]) ? &g_guard[dev] : nullptr;
 }
 
+// the word the f16x3 kernels of the launch being set up report to
 unsigned* range_flag_for_current_device() {
+    if (tl_range_flag) return tl_range_flag;
     RangeGuard* g = guard_for_current_device();
     return g ? g->dev : nullptr;
 }
@@ -97,13 +110,12 @@ static bool stream_is_capturing(hipStream_t st) {
 }
 
 static const char kRangeMsg[] =
-    "an activation left the split-f16 operand range of the f16x3 kernels (|x| > 4094 or non-finite) in a previous "
-    "launch on this device: its output is not the fp32 reference's; re-run with amp_set_precision(AMP_PRECISION_F32)";
+    "an activation left the split-f16 operand range of the f16x3 kernels (|x| > 4094 or infinite) in a previous "
+    "launch: its output is not the fp32 reference's; re-run with amp_set_precision(AMP_PRECISION_F32)";
 
 // non-blocking: reports (and clears) a flag whose copy has already landed
-static int range_poll(hipStream_t st) {
-    RangeGuard* g = guard_for_current_device();
-    if (!g || !g->pending || stream_is_capturing(st)) return AMP_OK;
+static int range_poll(RangeGuard* g, hipStream_t st) {
+    if (!g || !g->dev || !g->pending || stream_is_capturing(st)) return AMP_OK;
     if (hipEventQuery(g->ev) != hipSuccess) return AMP_OK;       // still in flight
     g->pending = false;
     if (*g->host == 0) return AMP_OK;
@@ -114,13 +126,27 @@ static int range_poll(hipStream_t st) {
 }
 
 // enqueue the copy of the flag behind everything launched so far on `st`
-static int range_publish(hipStream_t st) {
-    RangeGuard* g = guard_for_current_device();
-    if (!g || stream_is_capturing(st)) return AMP_OK;
+static int range_publish(RangeGuard* g, hipStream_t st) {
+    if (!g || !g->dev || stream_is_capturing(st)) return AMP_OK;
     AMP_HIP(hipMemcpyAsync(g->host, g->dev, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     AMP_HIP(hipEventRecord(g->ev, st));
     g->pending = true;
     return AMP_OK;
+}
+
+// synchronising check of one guard
+static int range_check_sync(RangeGuard* g, hipStream_t st, const char* who) {
+    if (!g || !g->dev) return AMP_OK;
+    if (stream_is_capturing(st)) { set_error("%s: the stream is capturing", who); return AMP_ERR_STATE; }
+    unsigned v = 0;
+    AMP_HIP(hipMemcpyAsync(&v, g->dev, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    AMP_HIP(hipStreamSynchronize(st));
+    g->pending = false;
+    *g->host = 0;
+    if (v == 0) return AMP_OK;
+    AMP_HIP(hipMemsetAsync(g->dev, 0, sizeof(unsigned), st));
+    set_error("%s", kRangeMsg);
+    return AMP_ERR_RANGE;
 }
 
 // Process-wide default for handles created from now on: AMP_PRECISION=f32|f16x3, amp_set_precision().
@@ -571,12 +597,14 @@ struct amp_gen {
     };
     std::vector<ProfSlot> prof;          // empty = profiling off
     size_t prof_count = 0;               // forwards recorded so far
+    RangeGuard guard;                    // this handle's f16 operand-range word (allocated by finalize on its device)
     // concurrent resblocks (BigVGAN): side streams for resblocks 1 .. n_kernels-1, fork / accumulate-order events
     int n_side = 0;
     hipStream_t side[AMP_MAX_KERNELS] = {};
     hipEvent_t ev_fork = nullptr;
     hipEvent_t ev_last[AMP_MAX_KERNELS] = {};
     ~amp_gen() {
+        guard_free(guard);
         for (int i = 0; i < n_side; ++i) if (side[i]) (void)hipStreamDestroy(side[i]);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         for (auto e : ev_last) if (e) (void)hipEventDestroy(e);
@@ -857,6 +885,7 @@ int amp_gen_finalize(amp_gen* g) {
             for (int j = 0; j + 1 < g->d.n_kernels; ++j) { AMP_HIP(hipStreamCreateWithFlags(&g->side[j], hipStreamNonBlocking)); g->n_side = j + 1; }
         }
     }
+    if (!guard_init(g->guard)) { set_error("amp_gen_finalize: cannot allocate the range-guard word"); return AMP_ERR_HIP; }
     g->w.clear();  // host copies no longer needed
     g->finalized = true;
     return AMP_OK;
@@ -1130,7 +1159,8 @@ int amp_gen_forward_ragged(amp_gen* g, const float* mel_dev, const float* cond_d
     if (workspace_bytes < amp_gen_workspace_bytes(g, B, T)) { set_error("amp_gen_forward: workspace too small (%zu < %zu)", workspace_bytes, amp_gen_workspace_bytes(g, B, T)); return AMP_ERR_INVALID; }
     if (cond_dev && !g->cond) { set_error("amp_gen_forward: cond given but gin_channels == 0"); return AMP_ERR_INVALID; }
     hipStream_t st = (hipStream_t)stream_;
-    AMP_RC(range_poll(st));            // a previous forward left the f16 operand range: say so now
+    AMP_RC(range_poll(&g->guard, st)); // a previous forward of this handle left the f16 operand range: say so now
+    struct FlagScope { FlagScope(unsigned* p) { tl_range_flag = p; } ~FlagScope() { tl_range_flag = nullptr; } } flag_scope(g->guard.dev);
     const amp_gen_desc& d = g->d;
     const int G = gen_group_items(g, B, T);
     const int ngroups = (B + G - 1) / G;
@@ -1164,24 +1194,17 @@ int amp_gen_forward_ragged(amp_gen* g, const float* mel_dev, const float* cond_d
                                  ps ? ps->ev_rb.data() + (size_t)d.n_stages * (d.n_kernels + 1) * gi : nullptr));
     }
     if (ps) { AMP_HIP(hipEventRecord(ps->ev_end, st)); ps->valid = true; ++g->prof_count; }
-    AMP_RC(range_publish(st));
+    AMP_RC(range_publish(&g->guard, st));
     return AMP_OK;
 }
 
 int amp_range_check(void* stream_) {
-    hipStream_t st = (hipStream_t)stream_;
-    RangeGuard* g = guard_for_current_device();
-    if (!g) return AMP_OK;             // nothing has run on this device yet
-    if (stream_is_capturing(st)) { set_error("amp_range_check: the stream is capturing"); return AMP_ERR_STATE; }
-    unsigned v = 0;
-    AMP_HIP(hipMemcpyAsync(&v, g->dev, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-    AMP_HIP(hipStreamSynchronize(st));
-    g->pending = false;
-    *g->host = 0;
-    if (v == 0) return AMP_OK;
-    AMP_HIP(hipMemsetAsync(g->dev, 0, sizeof(unsigned), st));
-    set_error("%s", kRangeMsg);
-    return AMP_ERR_RANGE;
+    return range_check_sync(guard_for_current_device(), (hipStream_t)stream_, "amp_range_check");
+}
+
+int amp_gen_range_check(amp_gen* g, void* stream_) {
+    if (!g) { set_error("amp_gen_range_check: null handle"); return AMP_ERR_INVALID; }
+    return range_check_sync(&g->guard, (hipStream_t)stream_, "amp_gen_range_check");
 }
 
 void amp_gen_destroy(amp_gen* g) { delete g; }

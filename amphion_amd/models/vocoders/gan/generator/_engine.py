@@ -290,7 +290,11 @@ class HipGenerator(nn.Module):
         staged an activation outside the split-f16 operand range (|x| > 4094 or non-finite; the fp32 reference has no
         such limit).  A later forward reports the same without synchronising.  ``forward_exact_range`` is the
         self-healing form."""
-        _lib.range_check(next(self.parameters()).device)
+        if self._amp_handle is None:
+            return
+        dev = next(self.parameters()).device
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().amp_gen_range_check(self._amp_handle, _lib.current_stream_ptr(dev)))
 
     def forward_exact_range(self, x, g=None, lengths=None):
         """Forward with the fp32 reference's operand range: runs the f16x3 kernels, checks the range flag (one

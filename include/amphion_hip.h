@@ -122,14 +122,17 @@ size_t amp_gen_workspace_bytes(const amp_gen* g, int B, int T);
 int amp_set_group_mb(int megabytes);
 
 /* Operand-range guard of the f16x3 arithmetic.  Activations are staged as hi + lo f16 pairs after an exact x16, so
- * |x| up to 4094 is representable; the fp32 reference (F.conv1d) has no such limit.  Every f16x3 kernel sets a
- * per-device flag when a staged value is larger or not finite -- the output of that launch is then NOT the
- * reference's (inf / NaN).  amp_range_check synchronises `stream` and returns AMP_ERR_RANGE if any launch on the
- * current device since the last check was affected (and clears the flag), AMP_OK otherwise.  amp_gen_forward reports
- * the same condition WITHOUT synchronising: a call that finds the flag of an earlier, finished forward set returns
- * AMP_ERR_RANGE instead of running.  Remedy: amp_set_precision(AMP_PRECISION_F32) and rebuild the handle (the exact
- * fp32 MFMA kernels have the reference's range). */
+ * |x| up to 4094 is representable; the fp32 reference (F.conv1d) has no such limit.  Every f16x3 kernel raises a flag
+ * when a staged value is larger (or infinite) -- the output of that launch is then NOT the reference's (inf / NaN).
+ * A generator handle owns its flag: amp_gen_range_check synchronises `stream` and returns AMP_ERR_RANGE if a forward of
+ * `g` since the last check was affected (and clears the flag); amp_gen_forward reports the same condition WITHOUT
+ * synchronising: a call that finds the flag of an earlier, finished forward of the same handle set returns
+ * AMP_ERR_RANGE instead of running.  amp_range_check does the synchronising check for the op-level entry points
+ * (amp_conv_forward, amp_pair_forward, ...), which share one flag per device.  Remedy: amp_set_precision(
+ * AMP_PRECISION_F32) and rebuild the handle (the exact fp32 MFMA kernels have the reference's range).  A NaN input is
+ * not flagged: it propagates to the output as it does through the reference. */
 int amp_range_check(void* stream);
+int amp_gen_range_check(amp_gen* g, void* stream);
 
 /* Fused ResBlock pairs (hifigan.py:93-100) have two kernels with bit-identical results (tests/test_gpu_pair.py): the
  * per-tile kernel and the strip-mined kernel (a workgroup walks a strip of one utterance and carries conv2's halo in

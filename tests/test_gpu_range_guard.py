@@ -141,3 +141,23 @@ def test_in_range_inputs_never_flag():
         for seed in range(3):
             m(synth.synth_mel(2, 80, 20, seed=seed).cuda())
     _lib.range_check()
+
+
+def test_op_level_and_generator_flags_do_not_mix():
+    """Op-level launches report to the per-device word (amp_range_check), a generator to its own (check_range / the lazy
+    refusal): an out-of-range amp_conv_forward must not make an unrelated generator refuse its next forward."""
+    from amphion_amd import _lib
+    from hip_helpers import conv_forward
+
+    m, _, _, _ = _hifigan()
+    w = _rand(64, 64, 3, seed=1, scale=0.1)
+    x = _rand(1, 64, 50, seed=2)
+    x[0, 0, 10] = 1e5
+    conv_forward(w, None, x, padding=1)                   # raises the device word
+    with torch.no_grad():
+        for seed in range(3):
+            m(synth.synth_mel(1, 80, 12, seed=seed).cuda())
+            torch.cuda.synchronize()
+    m.check_range()                                       # the generator's own word is clean
+    with pytest.raises(_lib.AmpError):
+        _lib.range_check()                                # the op-level word still holds the conv's report

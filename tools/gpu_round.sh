@@ -11,7 +11,7 @@ REPO=$PWD
 python -c "import torch; print(torch.cuda.get_device_name(0))" > $OUT/device.txt 2>&1
 NW=${PYTEST_N:-0}
 if [ "$NW" != "0" ]; then XD="-n $NW"; else XD=""; fi
-( timeout 1500 python -m pytest tests -m gpu -q $XD 2>&1 | tail -40 ) > $OUT/pytest_gpu.txt
+( timeout 1500 python -m pytest tests -m gpu -x -q $XD 2>&1 | tail -40 ) > $OUT/pytest_gpu.txt   # -x, one process: what the driver runs at round end
 tail -5 $OUT/pytest_gpu.txt
 ( timeout 600 python bench.py --steps 10 --warmup 3 2> $OUT/bench.err | tail -1 ) > $OUT/bench.json
 cat $OUT/bench.json
@@ -21,7 +21,7 @@ cat $OUT/bench.json
 ( timeout 300 python bench.py --steps 10 --warmup 3 --precision f32 --no-cpu-baseline 2> $OUT/bench_f32.err | tail -1 ) > $OUT/bench_f32.json
 ( timeout 400 python tools/bench_configs.py --reps 10 > $OUT/other_configs.jsonl 2> $OUT/other_configs.err )
 cat $OUT/other_configs.jsonl
-for N in 1 4; do ( AMP_ACT1D_TILES=$N timeout 200 python tools/bench_configs.py --only c3 --reps 10 2>/dev/null | tail -1 ) > $OUT/c3_tiles$N.json; echo "tiles $N: $(cat $OUT/c3_tiles$N.json)"; done
+( timeout 120 python __graft_entry__.py --smoke 2>&1 | tail -2 ) > $OUT/smoke.txt; cat $OUT/smoke.txt
 if [ "$FULL" = "1" ]; then
   ( timeout 600 python tools/conv_bench.py > $OUT/conv_bench.csv 2> $OUT/conv_bench.err )
   # SQ counter pass over one bench step (MFMA busy / stall split per kernel)
