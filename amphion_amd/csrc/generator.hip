@@ -736,7 +736,17 @@ int amp_gen_set_weight(amp_gen* g, const char* ref_key, const float* data_host, 
         set_error("amp_gen_set_weight: '%s' has shape (%s) expected (%s)", ref_key, got.c_str(), want.c_str());
         return AMP_ERR_INVALID;
     }
-    t.data.assign(data_host, data_host + t.numel());
+    // `data_host` may also be a DEVICE pointer (a parameter that already lives on the GPU): copied back here, once,
+    // instead of through a host tensor the caller would have to materialise first
+    hipPointerAttribute_t attr{};
+    const bool on_device = hipPointerGetAttributes(&attr, data_host) == hipSuccess && attr.type == hipMemoryTypeDevice;
+    if (!on_device) (void)hipGetLastError();          // a plain host pointer is not an error
+    if (on_device) {
+        t.data.resize(t.numel());
+        AMP_HIP(hipMemcpy(t.data.data(), data_host, t.numel() * sizeof(float), hipMemcpyDeviceToHost));
+    } else {
+        t.data.assign(data_host, data_host + t.numel());
+    }
     g->w[key] = std::move(t);
     return AMP_OK;
 }

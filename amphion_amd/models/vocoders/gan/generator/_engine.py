@@ -214,7 +214,7 @@ class HipGenerator(nn.Module):
         prev_prec = L.amp_get_precision()
         try:
             for key, t in self._amp_weights():
-                c = t.detach().to("cpu", torch.float32).contiguous()
+                c = t.detach().to(torch.float32).contiguous()      # host or device: amp_gen_set_weight takes either
                 shape = (ctypes.c_int64 * c.dim())(*c.shape)
                 _lib.check(L.amp_gen_set_weight(h, key.encode(), ctypes.c_void_p(c.data_ptr()), shape, c.dim()))
             with torch.cuda.device(device):

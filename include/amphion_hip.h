@@ -104,7 +104,8 @@ int amp_gen_create(const amp_gen_desc* desc, amp_gen** out);
 /* Replaces load_state_dict for one tensor (vocoder_inference.py:270-332).  `ref_key` is the
  * reference state_dict key: "...weight_g"/"...weight_v" pairs or folded
  * "...weight", "...bias", Snake "...act.alpha"/"...act.beta", "...filter" buffers.  The data is
- * copied from host memory.  Unknown keys are rejected (AMP_ERR_INVALID). */
+ * copied; `data_host` may be a host pointer or a device pointer of the current context (fp32, contiguous).
+ * Unknown keys are rejected (AMP_ERR_INVALID). */
 int amp_gen_set_weight(amp_gen* g, const char* ref_key, const float* data_host, const int64_t* shape, int ndim);
 
 /* Folds weight-norm (w = g*v/||v||, torch.nn.utils.weight_norm; hifigan.py:23,157,176,199),

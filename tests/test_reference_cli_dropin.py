@@ -1,8 +1,9 @@
 """The unmodified reference CLI (bins/vocoder/inference.py) must resolve `hifigan` to the MI355X
 generator through the registry hook.  Runs only where /root/reference exists (the build container);
 there is no GPU there, so the run is expected to reach OUR forward and stop at its "no CPU fallback"
-error -- which is exactly the evidence that the substitution happened.  With a GPU the same command
-completes (tests/test_gpu_cli.py covers the pieces that can travel)."""
+error -- which is exactly the evidence that the substitution happened.  The GPU boxes have no reference tree, so the
+loop the CLI runs (VocoderInference.inference, vocoder_inference.py:334-374) is exercised there through its mirror
+`inference_batches` on the 16 real clips of BASELINE configs[0]: tests/test_gpu_c1_clips.py."""
 import json
 import os
 import subprocess
