@@ -70,10 +70,85 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict_
     }
 }
 
+// Streaming form for rows that are 16-B aligned (T % 4 == 0: every tensor of a generator forward): no LDS, no barrier.
+// A lane owns 4 consecutive outputs and fetches, per input channel, the three aligned float4 around them (the
+// neighbouring lanes' copies come out of L1); 8 channels = 24 loads are in flight before the first is used.  Per
+// output the channels and taps are accumulated in the order of conv_post_kernel, so both give the same bits.  The
+// weights are wave-uniform (scalar loads).
+template <int K>
+__global__ __launch_bounds__(256) void conv_post_stream_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, float* __restrict__ y,
+                                                                int Cin, int T, float slope_in, int apply_tanh,
+                                                                const int* __restrict__ lens, int len_mul) {
+    constexpr int PAD = (K - 1) / 2;
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * CP_TT + 4 * (int)threadIdx.x;      // first of this lane's 4 outputs
+    if (t >= T) return;
+    int Tv = T;
+    if (lens) { const int l = lens[b] * len_mul; Tv = l < Tv ? l : Tv; }
+    const float* xb = x + (size_t)b * Cin * T;
+    const float b0 = bias ? bias[0] : 0.f;
+    float acc[4] = {b0, b0, b0, b0};
+    // clamped (always in-row) addresses of the left / right neighbours; their values are zeroed below when out of range
+    const int tl = t >= 4 ? t - 4 : t;
+    const int tr = t + 4 < T ? t + 4 : t;
+    const bool lok = t >= 4, rok = t + 4 < T;
+    const bool inner = lok && (t + 8 <= Tv);                      // all 12 positions valid: no per-element masks
+    for (int c0 = 0; c0 < Cin; c0 += 8) {
+        float4 vl[8], vc[8], vr[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int ch = c0 + r < Cin ? c0 + r : Cin - 1;       // scalar clamp: loads stay unconditional
+            const float* row = xb + (size_t)ch * T;
+            vl[r] = *reinterpret_cast<const float4*>(row + tl);
+            vc[r] = *reinterpret_cast<const float4*>(row + t);
+            vr[r] = *reinterpret_cast<const float4*>(row + tr);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (c0 + r < Cin) {                                   // wave-uniform
+                float v[12] = {vl[r].x, vl[r].y, vl[r].z, vl[r].w, vc[r].x, vc[r].y, vc[r].z, vc[r].w,
+                               vr[r].x, vr[r].y, vr[r].z, vr[r].w};
+                if (!inner) {
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) {
+                        const int ti = t - 4 + i;
+                        const bool ok = (i >= 4 || lok) && (i < 8 || rok) && ti < Tv;
+                        v[i] = ok ? v[i] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int i = 4 - PAD; i < 8 + PAD; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * slope_in;
+                const float* wr = w + (size_t)(c0 + r) * K;
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const float wj = wr[j];
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) acc[o] = fmaf(wj, v[4 - PAD + o + j], acc[o]);
+                }
+            }
+        }
+    }
+    float4 o4;
+    o4.x = apply_tanh ? tanhf(acc[0]) : acc[0];
+    o4.y = apply_tanh ? tanhf(acc[1]) : acc[1];
+    o4.z = apply_tanh ? tanhf(acc[2]) : acc[2];
+    o4.w = apply_tanh ? tanhf(acc[3]) : acc[3];
+    *reinterpret_cast<float4*>(y + (size_t)b * T + t) = o4;
+}
+
 hipError_t launch_conv_post(const float* x, const float* w_dev, const float* bias_dev, float* y, int B, int Cin,
                             int T, int K, float slope_in, int apply_tanh, const int* lens, int len_mul,
                             hipStream_t stream) {
     if (K > 9 || K < 1 || (K & 1) == 0) return hipErrorInvalidValue;
+    const bool aligned = (T & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+    if (aligned && (K == 7 || K == 3 || K == 5)) {
+        dim3 grid((unsigned)((T + CP_TT - 1) / CP_TT), (unsigned)B);
+        if (K == 7) hipLaunchKernelGGL(conv_post_stream_kernel<7>, grid, dim3(256), 0, stream, x, w_dev, bias_dev, y, Cin, T, slope_in, apply_tanh, lens, len_mul);
+        else if (K == 5) hipLaunchKernelGGL(conv_post_stream_kernel<5>, grid, dim3(256), 0, stream, x, w_dev, bias_dev, y, Cin, T, slope_in, apply_tanh, lens, len_mul);
+        else hipLaunchKernelGGL(conv_post_stream_kernel<3>, grid, dim3(256), 0, stream, x, w_dev, bias_dev, y, Cin, T, slope_in, apply_tanh, lens, len_mul);
+        return hipGetLastError();
+    }
     const size_t lds = (size_t)(8 * CP_S + Cin * K) * sizeof(float);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     dim3 grid((unsigned)((T + CP_TT - 1) / CP_TT), (unsigned)B);
