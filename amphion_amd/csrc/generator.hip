@@ -260,8 +260,9 @@ static bool fuse_pairs_enabled() {
 // Which fused-pair kernel a (C, k) pair runs.  Results are bit-identical either way (tests/test_gpu_pair.py); the choice
 // is measured (profiles/r2_cd_strip_kernel.txt, r2_j_strip_policy.txt): the strip-mined kernel (pair_strip_f16x3.hip)
 // removes the k - 1 seam columns and most of the halo re-staging but gives up the free load balancing of 12 000
-// independent tiles.  In the forward it wins 1.5 % on the k = 11, C = 128 pairs (2 093 -> 2 061 us) and loses
-// everywhere else, so the policy is the per-tile kernel for every shape it covers.
+// independent tiles: in its 4-wave form it wins 1.5 % on the k = 11, C = 128 pairs and loses everywhere else.  Its
+// 2 x 2-blocked form (a wave owns 64 rows x 96 columns, one workgroup per CU, 512 registers: half the LDS reads per
+// MFMA) wins 2-5 % for k >= 7 at C = 128 -- the policy at the end of strip_choice().
 //   amp_set_pair_strips(-1) / AMP_PAIR_STRIP unset: the measured policy below;  0: per-tile kernel everywhere
 //   (round 1);  1: strips wherever they are built (incl. C = 256, which has no per-tile form).
 struct StripChoice { bool use; int wide; int steps; };   // steps = 0: the planner sizes the strips
@@ -273,14 +274,15 @@ static StripChoice strip_choice(int C, int k) {
     }
     if (g_pair_strips == 0) return {false, 0, 0};
     if (g_pair_strips == 1) return {true, 0, 0};
-    // experiment switches (default 0 = per-tile kernel): AMP_STRIP_K11 for the k = 11, C = 128 pairs only,
+    // experiment switches (unset = the policy below; 0 = per-tile kernel): AMP_STRIP_K11 for the k = 11, C = 128 pairs only,
     // AMP_STRIP_C128 for every C = 128 pair.  1 narrow strips, planner | 2 wide tiles | 3 wide, 2 steps | 4 wide, planner |
     // 5 / 6 / 7: the 4-wave 2 x 2-blocked variant (64 rows x 96 columns per wave, one workgroup per CU) as tiles /
     // 2 steps / planner
-    static const int k11 = [] { const char* e = getenv("AMP_STRIP_K11"); return e ? atoi(e) : 0; }();
-    static const int c128 = [] { const char* e = getenv("AMP_STRIP_C128"); return e ? atoi(e) : 0; }();
-    const int v = (C == 128 && c128) ? c128 : ((C == 128 && k == 11) ? k11 : 0);
+    static const int k11 = [] { const char* e = getenv("AMP_STRIP_K11"); return e ? atoi(e) : -1; }();
+    static const int c128 = [] { const char* e = getenv("AMP_STRIP_C128"); return e ? atoi(e) : -1; }();
+    const int v = (C == 128 && c128 >= 0) ? c128 : ((C == 128 && k == 11 && k11 >= 0) ? k11 : -1);
     switch (v) {
+        case 0: return {false, 0, 0};
         case 1: return {true, 0, 0};
         case 2: return {true, 1, 1};
         case 3: return {true, 1, 2};
@@ -288,8 +290,13 @@ static StripChoice strip_choice(int C, int k) {
         case 5: return {true, 2, 1};
         case 6: return {true, 2, 2};
         case 7: return {true, 2, 0};
-        default: return {false, 0, 0};
+        default: break;
     }
+    // measured policy (profiles/r2_o_policy.txt, rocprofv3 per-kernel averages inside the forward, config 2): the
+    // 2 x 2-blocked 4-wave variant in strips of two steps wins at C = 128 for k = 11 (2 122 -> 2 024 us) and k = 7
+    // (1 372 -> 1 321 us) and loses for k = 3 (684 -> 748 us); every other shape stays on the per-tile kernel
+    if (C == 128 && (k == 7 || k == 11)) return {true, 2, 2};
+    return {false, 0, 0};
 }
 
 // Strip plan: `spi` workgroups per item, each walking ceil((L + k - 1) / n1) steps of n1 columns.  The chip holds
@@ -538,6 +545,14 @@ static int pair_run(const amp_conv* c1, const amp_conv* c2, const float* x, int 
         int steps = sc.steps;
         { const char* e = getenv("AMP_STRIP_STEPS"); if (e && atoi(e) > 0) steps = atoi(e); }
         if (steps > 0 && steps * n1 - (c1->k - 1) < T) { a.strip_len = steps * n1 - (c1->k - 1); a.strips_per_item = (T + a.strip_len - 1) / a.strip_len; }
+        // one workgroup per CU: a grid that cannot fill the chip twice over (a single utterance) is better served by the
+        // 4x as many independent tiles of the per-tile kernel (same bits)
+        if (g_pair_strips == -1 && sc.wide == 2 && (long long)B * a.strips_per_item < 512 && pair_tile(c1->k, c1->cin, c1->dilation) > 0) {
+            const int NT = pair_tile(c1->k, c1->cin, c1->dilation);
+            a.tiles_per_item = (T + NT - 1) / NT;
+            AMP_HIP(launch_pair(c1->k, a, stream));
+            return AMP_OK;
+        }
         { const char* e = getenv("AMP_STRIP_STAGGER"); a.stagger = e ? atoi(e) : 0; e = getenv("AMP_STRIP_STAGGER_MODE"); a.stagger_mode = e ? atoi(e) : 1; }
         AMP_HIP(launch_strip(c1->k, a, stream));
         return AMP_OK;

@@ -318,8 +318,11 @@ def main():
         dom_s = (sum(dom_ms) / len(dom_ms)) * 1e-3 / dom_launches
         dom_tflops = dom_flop / dom_s / 1e12
         traffic = None
-        strips = os.environ.get("AMP_PAIR_STRIP") == "1"      # default policy: the per-tile kernel
-        kname = ("pair_strip_kernel<11, 4, 1, 3, *>" if strips else "pair_f16x3_kernel<11, 4, 1, 3, 192>") if fused else "conv_mfma_kernel<11, 4, 1, 8, 64>"
+        # which fused-pair kernel the k = 11, C = 128 pairs run (generator.hip: strip_choice): the measured default is the
+        # 2 x 2-blocked strip kernel; AMP_PAIR_STRIP=0 the per-tile kernel of round 1, =1 the 4-wave strips
+        sel = os.environ.get("AMP_PAIR_STRIP")
+        pair_name = {"0": "pair_f16x3_kernel<11, 4, 1, 3, 192>", "1": "pair_strip_kernel<11, 4, 1, 3, *>"}.get(sel, "pair_strip_kernel<11, 2, 2, 3, 256, 2>")
+        kname = pair_name if fused else "conv_mfma_kernel<11, 4, 1, 8, 64>"
         if fused and os.path.exists(PROFILE_TRAFFIC_CSV):              # PMC pass of an EARLIER run of this command (static)
             tr = [float(line.rsplit(",", 1)[1]) * float(line.rsplit(",", 6)[1]) for line in open(PROFILE_TRAFFIC_CSV)
                   if kname.split("*")[0] in line]
