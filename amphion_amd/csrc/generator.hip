@@ -280,7 +280,8 @@ static StripChoice strip_choice(int C, int k) {
     // 2 steps / planner
     static const int k11 = [] { const char* e = getenv("AMP_STRIP_K11"); return e ? atoi(e) : -1; }();
     static const int c128 = [] { const char* e = getenv("AMP_STRIP_C128"); return e ? atoi(e) : -1; }();
-    const int v = (C == 128 && c128 >= 0) ? c128 : ((C == 128 && k == 11 && k11 >= 0) ? k11 : -1);
+    static const int c64 = [] { const char* e = getenv("AMP_STRIP_C64"); return e ? atoi(e) : -1; }();   // same codes, C = 64
+    const int v = (C == 128 && c128 >= 0) ? c128 : ((C == 64 && c64 >= 0) ? c64 : ((C == 128 && k == 11 && k11 >= 0) ? k11 : -1));
     switch (v) {
         case 0: return {false, 0, 0};
         case 1: return {true, 0, 0};

@@ -407,6 +407,7 @@ int AMP_CAT(strip_step_kt, AMP_KT)(int C, int dil, int wide, int* wg_per_cu) {
     int n1 = 0, wg = 2;
     if (C == 256) { n1 = (96 + span <= 256) ? 96 : 0; wg = 1; }
     else if (wide == 2 && C == 128) { n1 = (192 + span <= 256) ? 192 : 0; wg = 1; }   // 4 waves x (64 rows x 96 columns)
+    else if (wide == 2 && C == 64) { n1 = (256 + span <= 320) ? 256 : 0; wg = 1; }    // 4 waves x (64 rows x 64 columns)
     else if (wide && C == 128) { n1 = (192 + span <= 256) ? 192 : 0; wg = 1; }
     else if (wide && C == 64) { n1 = (256 + span <= 384) ? 256 : 0; wg = 1; }
     else if (wide && C == 32) { n1 = (512 + span <= 640) ? 512 : 0; wg = 1; }
@@ -422,6 +423,7 @@ hipError_t AMP_CAT(launch_strip_kt, AMP_KT)(const PairArgs& a, hipStream_t strea
     const int span = (KT - 1) * a.dil;
     if (a.C == 256) return launch_strip_one<KT, 8, 1, 3, 256>(a, stream);
     if (a.wide == 2 && a.C == 128) return launch_strip_one<KT, 2, 2, 3, 256, 2>(a, stream);
+    if (a.wide == 2 && a.C == 64) return launch_strip_one<KT, 1, 4, 2, 320, 2>(a, stream);
     if (a.wide) {
         if (a.C == 128) return launch_strip_one<KT, 4, 2, 3, 256>(a, stream);
         if (a.C == 64) return launch_strip_one<KT, 2, 4, 2, 384>(a, stream);

@@ -86,7 +86,7 @@ def test_strip_kernel_equals_tile_kernel_bitwise(C, k, d, B, T, strips):
     assert torch.equal(y_strip, y_tile)
 
 
-@pytest.mark.parametrize("C,k,d,B,T", [c for c in PAIR_CASES + STRIP_CASES if c[0] == 128])
+@pytest.mark.parametrize("C,k,d,B,T", [c for c in PAIR_CASES + STRIP_CASES if c[0] in (64, 128)])
 def test_policy_kernel_equals_tile_kernel_bitwise(C, k, d, B, T, strips):
     """Whatever kernel the per-shape policy picks (amp_set_pair_strips(-1): the default table, or an experiment variant
     selected with AMP_STRIP_C128 / AMP_STRIP_K11 -- wide 8-wave tiles, the 2 x 2-blocked 4-wave variant, ...) gives the
