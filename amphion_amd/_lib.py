@@ -109,6 +109,10 @@ _SIGNATURES = {
     "amp_conv_set_option": (c_int, [c_void_p, c_int, c_int]),
     "amp_pair_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
     "amp_conv_destroy": (None, [c_void_p]),
+    "amp_set_small_conv": (c_int, [c_int]),
+    "amp_conv_create_gated": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, POINTER(c_void_p)]),
+    "amp_wn_forward": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_int, c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_int, c_int,
+                               c_void_p, c_void_p, c_void_p]),
     "amp_wn_gate": (c_int, [c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_int, c_int, c_int, c_void_p]),
     "amp_wn_accumulate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "amp_sequence_mask": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

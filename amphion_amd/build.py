@@ -21,6 +21,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 CONV_TAPS = (1, 2, 3, 5, 7, 11)
 PAIR_TAPS = (3, 5, 7, 11)
+SMALL_TAPS = (1, 3, 5)
 
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC, "-Wall",
          "-Wno-unused-function"]
@@ -32,6 +33,8 @@ def _units():
     for kt in CONV_TAPS:
         units.append(("conv_mfma.hip", f"conv_mfma_kt{kt}.o", [f"-DAMP_KT={kt}"]))
         units.append(("conv_f16x3.hip", f"conv_f16x3_kt{kt}.o", [f"-DAMP_KT={kt}"]))
+    for kt in SMALL_TAPS:
+        units.append(("conv_small_f16x3.hip", f"conv_small_f16x3_kt{kt}.o", [f"-DAMP_KT={kt}"]))
     for kt in PAIR_TAPS:
         units.append(("pair_f16x3.hip", f"pair_f16x3_kt{kt}.o", [f"-DAMP_KT={kt}"]))
         units.append(("pair_strip_f16x3.hip", f"pair_strip_f16x3_kt{kt}.o", [f"-DAMP_KT={kt}"]))

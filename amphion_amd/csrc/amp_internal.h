@@ -49,6 +49,14 @@ struct ConvArgs {
     unsigned* range_flag;       // f16x3: set to 1 when a staged operand leaves the f16 range (|x| * 16 > 65504) or is not finite
     int pad_reflect;            // 1: out-of-range columns mirror (nn.ReflectionPad1d + unpadded conv, melgan.py:39,56,92)
     int tanh_out;               // 1: tanh on store (melgan.py:94)
+    // ---- conv_small_f16x3.hip only (frame-rate convs; the other kernels ignore these) ----
+    int Mpad;                   // rows of the packed weight (M rounded up to the pack's row group)
+    const float* gate_cond;     // EPI_GATE: additive condition per (item, ORIGINAL row) or nullptr (WN's g_l, modules.py:135-139)
+    long long gate_cond_bs;     //           its batch stride in elements
+    int wn_H;                   // EPI_GATE / EPI_WNACC: hidden channels H
+    float* wn_x;                // EPI_WNACC: x [B, H, T], updated in place: x = (x + rs[:H]) * mask
+    float* wn_out;              //            output [B, H, T]: (+)= rs[H:] (last layer: (+)= rs)
+    int wn_first, wn_last;      //            first layer starts `output` from zero; last layer has H rows only
 };
 
 // Arguments of the fused ResBlock-pair kernel (pair_f16x3.hip):
@@ -91,6 +99,9 @@ struct ConvPlan {
 bool choose_plan(int ntaps, int M, int halo_total, int Tq, ConvPlan* plan);
 hipError_t launch_conv(const ConvPlan& plan, const ConvArgs& a, hipStream_t stream);        // exact f32 MFMA
 hipError_t launch_conv_f16x3(const ConvPlan& plan, const ConvArgs& a, hipStream_t stream);  // split-f16 MFMA
+// frame-rate convs (conv_small_f16x3.hip): whole-K staging; epi 0 standard, 1 gate, 2 WN accumulate; ni 2 | 4
+constexpr int kSmallConvMaxChunks = 16;
+hipError_t launch_conv_small(int KT, int ni, int epi, const ConvArgs& a, hipStream_t stream);
 // fused pair: output columns per workgroup for (C, k, dilation), 0 = not covered; launch
 int pair_tile(int k, int C, int dil);
 hipError_t launch_pair(int k, const PairArgs& a, hipStream_t stream);

@@ -330,6 +330,30 @@ static bool small_tiles_enabled() {
     return on;
 }
 
+hipError_t launch_conv_small_kt1(int, int, const ConvArgs&, hipStream_t);
+hipError_t launch_conv_small_kt3(int, int, const ConvArgs&, hipStream_t);
+hipError_t launch_conv_small_kt5(int, int, const ConvArgs&, hipStream_t);
+hipError_t launch_conv_small(int KT, int ni, int epi, const ConvArgs& a, hipStream_t s) {
+    switch (KT) {
+        case 1: return launch_conv_small_kt1(ni, epi, a, s);
+        case 3: return launch_conv_small_kt3(ni, epi, a, s);
+        case 5: return launch_conv_small_kt5(ni, epi, a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// Frame-rate convs (K = Cin * k short, grids of a few hundred workgroups) run on conv_small_f16x3.hip: whole-K
+// staging, one memory latency instead of one per chunk (same bits as conv_f16x3.hip).  AMP_SMALL_CONV=0 /
+// amp_set_small_conv(0) keeps them on the pipelined kernel (A/B switch, tests/test_gpu_conv.py).
+static int g_small_conv = -1;
+static bool small_conv_enabled() {
+    if (g_small_conv < 0) {
+        const char* e = getenv("AMP_SMALL_CONV");
+        g_small_conv = (e && !strcmp(e, "0")) ? 0 : 1;
+    }
+    return g_small_conv != 0;
+}
+
 hipError_t launch_conv_f16x3(const ConvPlan& p, const ConvArgs& a, hipStream_t s) {
     switch (p.KT) {
         case 1: return launch_conv_h_kt1(p, a, s);
@@ -356,6 +380,8 @@ struct amp_conv {
     int nchunks = 0;
     int precision = PREC_F32;  // arithmetic of the contraction, fixed at build time
     int pad_reflect = 0, tanh_out = 0;  // amp_conv_set_option
+    int gated_H = 0;           // > 0: rows packed for the gate epilogue of conv_small_f16x3.hip (amp_conv_create_gated)
+    int Mpad = 0;              // rows of the packed weight
     float wscale = 1.f;        // f16x3: power of two applied to the packed weights
     ConvPlan plan{};
     void* wp_dev = nullptr;
@@ -402,6 +428,7 @@ static int conv_build(amp_conv* c, const float* w, const float* bias) {
     if (c->precision == PREC_F16X3) c->plan.NI = 4;  // conv_f16x3.hip keeps 4 accumulator tiles per wave
     const int Mg = c->plan.Mgroup();
     const int Mpad = ((c->M + Mg - 1) / Mg) * Mg;
+    c->Mpad = Mpad;
     const int nmb = Mpad / 32;
     const int cin = c->cin, cout = c->cout, k = c->k, up = c->up;
     // W'[m, i, g]: the GEMM-view weight (polyphase rows for a transposed conv), 0 outside
@@ -467,6 +494,22 @@ static int conv_out_len(const amp_conv* c, int T) {
     return (T - 1) * c->stride - 2 * c->padding + c->k;
 }
 
+// conv_small_f16x3.hip covers: Conv1d (no polyphase rows), zero padding, 128-row workgroups, k in {1, 3, 5}, Cin <= 256,
+// receptive field <= 64 columns
+static bool small_conv_static_ok(const amp_conv* c) {
+    return c->precision == PREC_F16X3 && !c->transposed && !c->pad_reflect && c->plan.WM == 4 &&
+           (c->KT == 1 || c->KT == 3 || c->KT == 5) && c->nchunks <= kSmallConvMaxChunks && c->halo_left + c->halo_right <= 64;
+}
+static bool small_conv_covers(const amp_conv* c) { return small_conv_enabled() && small_conv_static_ok(c); }
+// tile width of the whole-K kernel in 32-column units: 128 x 32 tiles (two workgroups per CU) when the receptive field
+// fits their 32-column halo, else 128 x 64.  AMP_SMALL_NI=1|2 forces one (A/B switch; 1 only where it fits).
+static int small_conv_ni(const amp_conv* c) {
+    static const int forced = [] { const char* e = getenv("AMP_SMALL_NI"); return e ? atoi(e) : 0; }();
+    const bool fits1 = c->halo_left + c->halo_right <= 32;
+    if (forced == 2 || !fits1) return 2;
+    return 1;
+}
+
 // mode 0: y = v, 1: y += v, 2: y = (y + v) / div
 static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope_in, const float* res, float slope_out,
                     float* y, int mode, float div, hipStream_t stream, long long xbs = 0, const int* lens = nullptr,
@@ -497,13 +540,23 @@ static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope
         set_error("amp_conv_forward: reflection padding %d needs more than %d input samples", c->halo_left > c->halo_right ? c->halo_left : c->halo_right, T);
         return AMP_ERR_INVALID;
     }
+    if (c->gated_H) { set_error("amp_conv_forward: a gated conv (amp_conv_create_gated) only runs inside amp_wn_forward"); return AMP_ERR_STATE; }
     if (c->precision == PREC_F32) {
         a.acc_scale = a.inv_scale = 1.f;
         AMP_HIP(launch_conv(plan, a, stream));
     } else {
         a.acc_scale = 16.f * c->wscale;
         a.inv_scale = 1.f / a.acc_scale;
-        AMP_HIP(launch_conv_f16x3(plan, a, stream));
+        if (plan.NI == 2 && small_conv_covers(c)) {
+            // a small grid of a short contraction: the whole-K kernel (128 x 32 or 128 x 64 tiles, same bits)
+            const int ni = small_conv_ni(c);
+            a.Mpad = c->Mpad;
+            a.tiles_per_item = (a.Tq + 32 * ni - 1) / (32 * ni);
+            a.wd = 32 * ni + c->halo_left + c->halo_right;
+            AMP_HIP(launch_conv_small(c->KT, ni, 0, a, stream));
+        } else {
+            AMP_HIP(launch_conv_f16x3(plan, a, stream));
+        }
     }
     return AMP_OK;
 }
@@ -1245,6 +1298,93 @@ int amp_conv_create(int transposed, int cin, int cout, int k, int stride, int di
     int rc = conv_build(c.get(), weight_host, bias_host);
     if (rc != AMP_OK) return rc;
     *out = c.release();
+    return AMP_OK;
+}
+
+int amp_set_small_conv(int on) {
+    g_small_conv = on ? 1 : 0;
+    return AMP_OK;
+}
+
+// WN.in_layers[i] with its 2H rows packed for the gate epilogue: packed row 32*mb + i + 4*hi + 8*(2u + s) holds original
+// row s*H + 16*mb + i + 4*hi + 8*u (s = 0: tanh half, 1: sigmoid half), so that the MFMA C layout hands one lane both
+// pre-activations of a channel (conv_small_f16x3.hip, EPI_GATE).
+int amp_conv_create_gated(int hidden, int k, int dilation, int padding, const float* weight_host, const float* bias_host,
+                          amp_conv** out) {
+    if (!weight_host || !out) { set_error("amp_conv_create_gated: null argument"); return AMP_ERR_INVALID; }
+    if (amp_device_count() <= 0) { set_error("amp_conv_create_gated: no HIP device visible (the HIP path has no CPU fallback)"); return AMP_ERR_HIP; }
+    if (hidden <= 0 || hidden % 32 != 0) { set_error("amp_conv_create_gated: hidden=%d must be a multiple of 32", hidden); return AMP_ERR_UNSUPPORTED; }
+    if (default_precision() != PREC_F16X3) { set_error("amp_conv_create_gated: the fused WN layer exists for the f16x3 arithmetic only"); return AMP_ERR_UNSUPPORTED; }
+    const int H = hidden, M = 2 * H;
+    const size_t rowlen = (size_t)H * k;
+    std::vector<float> wperm((size_t)M * rowlen), bperm((size_t)M, 0.f);
+    for (int p = 0; p < M; ++p) {
+        const int mb = p >> 5, rho = p & 31;
+        const int i = rho & 3, hi = (rho >> 2) & 1, jj = rho >> 3, s = jj & 1, u = jj >> 1;
+        const int orow = s * H + 16 * mb + i + 4 * hi + 8 * u;
+        memcpy(&wperm[(size_t)p * rowlen], &weight_host[(size_t)orow * rowlen], rowlen * sizeof(float));
+        if (bias_host) bperm[p] = bias_host[orow];
+    }
+    auto c = std::make_unique<amp_conv>();
+    c->transposed = 0; c->cin = H; c->cout = M; c->k = k; c->stride = 1; c->dilation = dilation; c->padding = padding;
+    int rc = conv_build(c.get(), wperm.data(), bperm.data());   // the gate epilogue reads the bias unconditionally (zeros when absent)
+    if (rc != AMP_OK) return rc;
+    if (!small_conv_static_ok(c.get()) || conv_out_len(c.get(), 64) != 64) {
+        set_error("amp_conv_create_gated: H=%d k=%d dilation=%d padding=%d is outside the fused WN kernel (k in {1,3,5}, H <= 256, 'same' padding, (k-1)*dilation <= 64)", H, k, dilation, padding);
+        return AMP_ERR_UNSUPPORTED;
+    }
+    c->gated_H = H;
+    *out = c.release();
+    return AMP_OK;
+}
+
+// Common ConvArgs of a conv_small launch over [B, cin, T] -> T output columns, tiles of 32 * ni columns.
+static void small_args(const amp_conv* c, const float* x, int B, int T, const int* lens, int ni, ConvArgs* a) {
+    *a = ConvArgs{};
+    a->x = x; a->wp = c->wp_dev; a->bias = c->bias_dev;
+    a->B = B; a->Cin = c->cin; a->Tin = T; a->xbs = (long long)c->cin * T; a->nchunks = c->nchunks; a->M = c->M; a->Mpad = c->Mpad;
+    a->Tq = T; a->tiles_per_item = (T + 32 * ni - 1) / (32 * ni);
+    a->off0 = c->off0; a->dstep = c->dstep; a->halo_left = c->halo_left; a->wd = 32 * ni + c->halo_left + c->halo_right;
+    a->Cout = c->cout; a->Tout = T; a->up = 1; a->up_pad = 0;
+    a->slope_in = 1.f; a->slope_out = 1.f; a->mode = 0; a->div = 1.f;
+    a->lens = lens; a->len_mul = 1;
+    a->acc_scale = 16.f * c->wscale; a->inv_scale = 1.f / a->acc_scale;
+    a->range_flag = range_flag_for_current_device();
+}
+
+int amp_wn_forward(const amp_conv* const* in_layers, const amp_conv* const* res_skip_layers, int n_layers, float* x_dev,
+                   const float* cond_dev, long long cond_batch_stride, const int32_t* lens_dev, int B, int T,
+                   float* acts_ws_dev, float* out_dev, void* stream_) {
+    if (!in_layers || !res_skip_layers || n_layers <= 0 || !x_dev || !acts_ws_dev || !out_dev || B <= 0 || T <= 0) {
+        set_error("amp_wn_forward: bad argument");
+        return AMP_ERR_INVALID;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    const int H = in_layers[0] ? in_layers[0]->gated_H : 0;
+    for (int i = 0; i < n_layers; ++i) {
+        const amp_conv* ci = in_layers[i];
+        const amp_conv* cr = res_skip_layers[i];
+        if (!ci || !cr) { set_error("amp_wn_forward: null layer %d", i); return AMP_ERR_INVALID; }
+        const int rs_out = i < n_layers - 1 ? 2 * H : H;
+        if (!ci->gated_H || ci->gated_H != H || cr->k != 1 || cr->cin != H || cr->cout != rs_out || cr->gated_H ||
+            !small_conv_static_ok(cr) || cr->tanh_out || ci->tanh_out || !cr->bias_dev || !ci->bias_dev) {
+            set_error("amp_wn_forward: layer %d is not an (amp_conv_create_gated in-layer, 1x1 %d -> %d res_skip) pair", i, H, rs_out);
+            return AMP_ERR_INVALID;
+        }
+    }
+    for (int i = 0; i < n_layers; ++i) {
+        ConvArgs a;
+        const int ni_in = small_conv_ni(in_layers[i]), ni_rs = small_conv_ni(res_skip_layers[i]);
+        small_args(in_layers[i], x_dev, B, T, nullptr, ni_in, &a);        // in_layers[i](x) + g_l -> tanh * sigmoid (x is masked by the update below / the caller)
+        a.y = acts_ws_dev; a.wn_H = H;
+        a.gate_cond = cond_dev ? cond_dev + (size_t)i * 2 * H : nullptr;
+        a.gate_cond_bs = cond_batch_stride;
+        AMP_HIP(launch_conv_small(in_layers[i]->KT, ni_in, 1, a, stream));
+        small_args(res_skip_layers[i], acts_ws_dev, B, T, nullptr, ni_rs, &a);   // res_skip(acts) -> x, output
+        a.lens = lens_dev;                                                // the mask of the x update (acts is read densely)
+        a.wn_H = H; a.wn_x = x_dev; a.wn_out = out_dev; a.wn_first = i == 0; a.wn_last = i == n_layers - 1;
+        AMP_HIP(launch_conv_small(1, ni_rs, 2, a, stream));
+    }
     return AMP_OK;
 }
 

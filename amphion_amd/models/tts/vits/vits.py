@@ -33,6 +33,8 @@ class ResidualCouplingBlock(nn.Module):
 
     def forward(self, x, x_lengths=None, g=None, reverse=False):
         """vits.py:105-112.  ``x_lengths`` replaces the dense ``x_mask``."""
+        if x_lengths is not None:
+            x_lengths = hip_ops.lens_tensor(x_lengths, x.device)   # once: every flow reuses the device tensor
         if not reverse:
             for flow in self.flows:
                 x, _ = flow(x, x_lengths, g=g, reverse=reverse)
@@ -64,7 +66,7 @@ class PosteriorEncoder(nn.Module):
         lens = hip_ops.lens_tensor(x_lengths, x.device)
         h = self.pre(x)
         hip_ops.sequence_mask_(h, lens)
-        h = self.enc(h, x_lengths, g=g)
+        h = self.enc(h, lens, g=g)
         stats = self.proj(h)
         hip_ops.sequence_mask_(stats, lens)
         m, logs = torch.split(stats, self.out_channels, dim=1)
@@ -91,10 +93,10 @@ class SynthesizerTrnDecodePath(nn.Module):
 
     def reconstruct(self, y, y_lengths, g_src=None, g_tgt=None, noise=None):
         """voice_conversion topology (vits.py:371-379): enc_q -> flow -> flow(reverse) -> dec."""
-        z, m_q, logs_q, y_mask = self.enc_q(y, y_lengths, g=g_src, noise=noise)
-        z_p = self.flow(z, y_lengths, g=g_src)
-        z_hat = self.flow(z_p, y_lengths, g=g_tgt, reverse=True)
-        lens = hip_ops.lens_tensor(y_lengths, z_hat.device)
+        lens = hip_ops.lens_tensor(y_lengths, _lib.require_device_tensor(y, "y").device)
+        z, m_q, logs_q, y_mask = self.enc_q(y, lens, g=g_src, noise=noise)
+        z_p = self.flow(z, lens, g=g_src)
+        z_hat = self.flow(z_p, lens, g=g_tgt, reverse=True)
         o_hat = self.dec(hip_ops.sequence_mask_(z_hat.clone(), lens), g=g_tgt)
         return o_hat, y_mask, (z, z_p, z_hat)
 
@@ -188,9 +190,9 @@ class SynthesizerTrn(nn.Module):
         dev = next(self.parameters()).device
         g_src = self.emb_g(torch.as_tensor(sid_src).to(dev)).unsqueeze(-1).detach().contiguous()
         g_tgt = self.emb_g(torch.as_tensor(sid_tgt).to(dev)).unsqueeze(-1).detach().contiguous()
-        z, m_q, logs_q, y_mask = self.enc_q(y, y_lengths, g=g_src)
-        z_p = self.flow(z, y_lengths, g=g_src)
-        z_hat = self.flow(z_p, y_lengths, g=g_tgt, reverse=True)
-        lens = hip_ops.lens_tensor(y_lengths, z_hat.device)
+        lens = hip_ops.lens_tensor(y_lengths, dev)
+        z, m_q, logs_q, y_mask = self.enc_q(y, lens, g=g_src)
+        z_p = self.flow(z, lens, g=g_src)
+        z_hat = self.flow(z_p, lens, g=g_tgt, reverse=True)
         o_hat = self.dec(hip_ops.sequence_mask_(z_hat.clone(), lens), g=g_tgt)
         return o_hat, y_mask, (z, z_p, z_hat)

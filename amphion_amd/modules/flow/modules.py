@@ -7,6 +7,8 @@ convs + the element-wise kernels of amp_wn_gate / amp_wn_accumulate / amp_coupli
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -29,6 +31,8 @@ class WN(nn.Module):
         self.n_layers = n_layers
         self.gin_channels = gin_channels
         self.p_dropout = p_dropout
+        # False (or AMP_WN_FUSED=0): always the four unfused launches per layer -- cross-check / A-B switch
+        self.fused = os.environ.get("AMP_WN_FUSED", "1") != "0"
         self.in_layers = nn.ModuleList()
         self.res_skip_layers = nn.ModuleList()
         if gin_channels != 0:
@@ -50,8 +54,13 @@ class WN(nn.Module):
         cond = None
         if g is not None:
             cond = self.cond_layer(_lib.require_device_tensor(g, "g"))  # [B, 2H*n_layers, 1]
-        x_in = torch.empty((B, 2 * H, T), dtype=torch.float32, device=x.device)
         acts = torch.empty_like(x)
+        # fused path (f16x3): in_layers[i] + gate in one launch, res_skip_layers[i] + residual / skip update in another
+        if self.fused and hip_ops.wn_fused(self.in_layers, self.res_skip_layers, x, cond, lens, output, acts):
+            if lens is not None:
+                hip_ops.sequence_mask_(output, lens)
+            return output
+        x_in = torch.empty((B, 2 * H, T), dtype=torch.float32, device=x.device)
         for i in range(self.n_layers):
             self.in_layers[i](x, out=x_in)
             g_l = cond[:, i * 2 * H:, 0] if cond is not None else None
@@ -110,7 +119,7 @@ class ResidualCouplingLayer(nn.Module):
         h = self.pre(x, x_batch_stride=C * T, T=T)  # x0 = x[:, :half]
         if lens is not None:
             hip_ops.sequence_mask_(h, lens)
-        h = self.enc(h, x_lengths, g=g)
+        h = self.enc(h, lens, g=g)     # the device tensor: no second host -> device copy of the lengths
         m = self.post(h)
         if lens is not None:
             hip_ops.sequence_mask_(m, lens)

@@ -55,6 +55,27 @@ class HipConv1d(ConvParams):
         self._h, self._fin, self._sig = h, weakref.finalize(self, _destroy_conv, h.value), sig
         return h
 
+    def _ensure_gated(self, device):
+        """A second handle with the 2H rows packed for the gate epilogue of the fused WN layer
+        (``amp_conv_create_gated``); None when this conv / arithmetic is outside what that kernel covers."""
+        sig = tuple((n, p.data_ptr(), p._version) for n, p in self.named_parameters()) + (str(device), _lib.get_precision())
+        if getattr(self, "_sig_g", None) == sig:
+            return self._hg
+        if getattr(self, "_fin_g", None) is not None:
+            self._fin_g()
+        self._hg, self._fin_g, self._sig_g = None, None, sig
+        if (_lib.get_precision() != "f16x3" or self.transposed or self.cout != 2 * self.cin or self.cin % 32 or self.cin > 256 or self.cout <= 64
+                or self.k not in (1, 3, 5) or self.stride != 1 or 2 * self.padding != self.dilation * (self.k - 1)
+                or (self.k - 1) * self.dilation > 64 or self.pad_mode != "zeros" or self.tanh):
+            return None
+        w = self.folded_weight().detach().to("cpu", torch.float32).contiguous()
+        b = self.bias.detach().to("cpu", torch.float32).contiguous() if self.bias is not None else None
+        h = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(_lib.lib().amp_conv_create_gated(self.cin, self.k, self.dilation, self.padding, _ptr(w), _ptr(b), ctypes.byref(h)))
+        self._hg, self._fin_g = h, weakref.finalize(self, _destroy_conv, h.value)
+        return h
+
     def forward(self, x, *, slope_in=1.0, res=None, slope_out=1.0, out=None, x_batch_stride=None, T=None):
         """x [B, cin, T] (or a channel slice of a wider tensor when ``x_batch_stride`` is given)."""
         x = _lib.require_device_tensor(x, "conv input") if x_batch_stride is None else x
@@ -81,6 +102,33 @@ def lens_tensor(lengths, device):
     if lengths is None:
         return None
     return torch.as_tensor(lengths).to(device=device, dtype=torch.int32).contiguous()
+
+
+def wn_fused(in_layers, res_skip_layers, x, cond, lens, out, acts):
+    """The whole WN stack on the fused kernels (``amp_wn_forward``): two launches per layer.  ``x`` is modified.
+    Returns False (nothing launched) when a layer is outside what the fused kernels cover -- the caller then runs the
+    unfused ops."""
+    dev = x.device
+    n = len(in_layers)
+    H = x.shape[1]
+    hi, hr = [], []
+    for i in range(n):
+        rs = res_skip_layers[i]
+        if rs.k != 1 or rs.cin != H or rs.cout != (2 * H if i < n - 1 else H) or rs.bias is None or rs.transposed or rs.tanh or rs.pad_mode != "zeros":
+            return False
+        g = in_layers[i]._ensure_gated(dev)
+        if g is None:
+            return False
+        hi.append(g.value)
+        hr.append(rs._ensure(dev).value)
+    B, _, T = x.shape
+    arr_i = (ctypes.c_void_p * n)(*hi)
+    arr_r = (ctypes.c_void_p * n)(*hr)
+    bs = cond.stride(0) if cond is not None else 0
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().amp_wn_forward(arr_i, arr_r, n, _ptr(x), _ptr(cond), bs, _ptr(lens), B, T, _ptr(acts), _ptr(out),
+                                             _lib.current_stream_ptr(dev)))
+    return True
 
 
 def wn_gate(a, cond, out):

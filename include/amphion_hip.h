@@ -286,6 +286,32 @@ int amp_pair_forward(const amp_conv* c1, const amp_conv* c2, const float* x_dev,
 
 void amp_conv_destroy(amp_conv* c);
 
+/* Frame-rate convs (short contraction, small grid: the convs around the VITS decoder) run on a kernel that stages the
+ * whole K extent of its input tile at once (csrc/conv_small_f16x3.hip; same bits as the pipelined kernel).  0 keeps
+ * them on the pipelined kernel -- an A/B and cross-check switch, also AMP_SMALL_CONV=0 in the environment. */
+int amp_set_small_conv(int on);
+
+/* ---- WN (modules/flow/modules.py:74-151), fused: two launches per layer ---- */
+
+/* WN.in_layers[i] = Conv1d(H, 2H, k, dilation, padding) (modules.py:106-114) built for the gate epilogue: the kernel
+ * forms fused_add_tanh_sigmoid_multiply (utils/util.py:602-609) in registers and writes [B, H, T].  weight_host
+ * [2H, H, k] FOLDED (weight_norm applied), bias_host [2H].  Covered: H a multiple of 32 and <= 256, k in {1, 3, 5},
+ * 'same' padding, (k-1)*dilation <= 64, f16x3 arithmetic; otherwise AMP_ERR_UNSUPPORTED (run the unfused ops).
+ * The handle only runs inside amp_wn_forward. */
+int amp_conv_create_gated(int hidden, int k, int dilation, int padding, const float* weight_host, const float* bias_host,
+                          amp_conv** out);
+
+/* WN.forward (modules/flow/modules.py:126-151) without the final `* x_mask`:
+ *   for i: acts = tanh((in_i(x) + g_i)[:H]) * sigmoid((in_i(x) + g_i)[H:]);  rs = res_skip_i(acts)
+ *          i < n-1: x = (x + rs[:H]) * mask, output += rs[H:];   i == n-1: output += rs
+ * in_layers[i]: amp_conv_create_gated handles; res_skip_layers[i]: amp_conv_create 1x1 convs (H -> 2H, last H -> H).
+ * x_dev [B, H, T] is the caller's working copy and is MODIFIED; cond_dev = cond_layer(g) [B, 2H*n_layers] (element
+ * (b, r) at cond_dev[b*cond_batch_stride + r]) or NULL; lens_dev int32 [B] or NULL; acts_ws_dev scratch [B, H, T];
+ * out_dev [B, H, T] (written, not read). */
+int amp_wn_forward(const amp_conv* const* in_layers, const amp_conv* const* res_skip_layers, int n_layers, float* x_dev,
+                   const float* cond_dev, long long cond_batch_stride, const int32_t* lens_dev, int B, int T,
+                   float* acts_ws_dev, float* out_dev, void* stream);
+
 /* ---- VITS posterior encoder + flow (config 5): element-wise pieces between the convs ---- */
 
 /* fused_add_tanh_sigmoid_multiply (utils/util.py:602-609) as called by WN.forward

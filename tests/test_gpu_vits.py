@@ -79,3 +79,33 @@ def test_config5_end_to_end_vs_oracle():
     assert (z_hat.cpu() - rzh).abs().max().item() <= TOL
     assert tuple(o.shape) == (3, 1, 37 * 256)
     assert (o.cpu() - ro).abs().max().item() <= TOL
+
+
+@pytest.mark.parametrize("gin,n_layers,k,rate", [(0, 4, 5, 1), (256, 16, 5, 1), (0, 3, 3, 2), (64, 2, 1, 1)])
+def test_wn_fused_vs_unfused_and_oracle(gin, n_layers, k, rate, conv_precision):
+    """The fused WN layer (in-conv + gate, res_skip + residual / skip update: amp_wn_forward) against the four unfused
+    launches per layer on the same module, and against the oracle's WN (modules/flow/modules.py:126-151) -- ragged
+    lengths, with and without the speaker condition."""
+    from amphion_amd.modules.flow.modules import WN
+
+    H, B, T = 192, 3, 83
+    wn = WN(H, k, rate, n_layers, gin_channels=gin)
+    from collections import OrderedDict
+
+    sd_p = synth.synth_state_dict(synth.wn_param_shapes(OrderedDict(), "enc", H, k, n_layers, gin), 99, g_gain=0.5)
+    sd = {n[len("enc."):]: v for n, v in sd_p.items()}
+    wn.load_state_dict(sd)
+    wn = wn.cuda().eval()
+    gen = torch.Generator().manual_seed(5)
+    lens = torch.tensor([83, 40, 7])
+    mask = (torch.arange(T)[None, :] < lens[:, None]).float()[:, None, :]
+    x = torch.randn(B, H, T, generator=gen) * mask
+    g = torch.randn(B, gin, 1, generator=gen) if gin else None
+    with torch.no_grad():
+        y_f = wn(x.cuda(), lens, g=g.cuda() if gin else None)
+        wn.fused = False
+        y_u = wn(x.cuda(), lens, g=g.cuda() if gin else None)
+        ref = vo.wn_forward(sd_p, "enc", x, mask, n_layers, H, k, rate, torch.float32, g=g)
+    assert (y_u.cpu() - ref).abs().max().item() <= TOL
+    assert (y_f.cpu() - ref).abs().max().item() <= TOL
+    assert (y_f - y_u).abs().max().item() <= 2e-5
