@@ -225,6 +225,14 @@ __device__ __forceinline__ void snake_sin2_pk4(const f32x2 (&x)[4], f32x2 (&out)
     }
 }
 
+// LDS position of Snake value i.  Lanes write / read `sl` as float4 at a stride of 8 floats (32 B): every such access
+// is a 2-way bank conflict (ds_read_b128 serves 16-lane groups {0-3, 12-15, 20-27}, ... over 64 banks, ds_write_b128
+// 8 contiguous lanes over 32; rocprofv3, visit U: 56 % of the kernel's LDS cycles were conflict cycles).  Flipping the
+// low bit of the float4 index with the parity of its bits 3 and 4 makes all seven accesses of a tile conflict-free
+// (enumerated over the hardware's lane groups, tests/experiments/act1d_swizzle.py).
+__device__ __forceinline__ int sl_pos4(int j4) { return j4 ^ (((j4 >> 3) ^ (j4 >> 4)) & 1); }     // float4 index
+__device__ __forceinline__ int sl_pos(int i) { return (sl_pos4(i >> 2) << 2) | (i & 3); }         // float index
+
 // NTILE consecutive tiles per workgroup.  When all of them lie inside the row, their windows are requested at
 // kernel entry by straight-line code (no register is renamed while its load is pending); otherwise a rolled loop
 // with the next tile's window in flight.  First / last / ragged tiles stage a clamped window and then run the same
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(256) void act1d_kernel(const float* __restrict__ x,
                                                     int len_mul) {
     // staged window xl[i] = x[clamp(t0 - 8 + i)], i < A1_TT + 16 (starts 8 before the tile: 16-B aligned rows)
     __shared__ __attribute__((aligned(16))) float xl[A1_TT + 16];
-    __shared__ __attribute__((aligned(16))) float sl[2 * A1_TT + 12];
+    __shared__ __attribute__((aligned(16))) float sl[2 * A1_TT + 16];   // swizzled (sl_pos): whole float4 pairs
     __shared__ float ful[12];                      // up taps for the one-value-at-a-time paths: indexed by parity
     const int tid = threadIdx.x;
     const int ntiles = (T + A1_TT - 1) / A1_TT;   // T = row stride (padded length)
@@ -318,18 +326,18 @@ __global__ __launch_bounds__(256) void act1d_kernel(const float* __restrict__ x,
             snake_sin2_pk4(xa, sv);
 #pragma unroll
             for (int q = 0; q < 4; ++q) sv[q] = pk_fma(pk_splat(invb), sv[q], uv[q]);
-            *reinterpret_cast<float4*>(&sl[8 * tid]) = make_float4(sv[0].x, sv[0].y, sv[1].x, sv[1].y);
-            *reinterpret_cast<float4*>(&sl[8 * tid + 4]) = make_float4(sv[2].x, sv[2].y, sv[3].x, sv[3].y);
+            *reinterpret_cast<float4*>(&sl[4 * sl_pos4(2 * tid)]) = make_float4(sv[0].x, sv[0].y, sv[1].x, sv[1].y);
+            *reinterpret_cast<float4*>(&sl[4 * sl_pos4(2 * tid + 1)]) = make_float4(sv[2].x, sv[2].y, sv[3].x, sv[3].y);
             if (__builtin_expect(big > 1.0e5f, 0)) {
                 // beyond the fast range reduction: redo this lane's eight values one at a time through
                 // snake_sin2 (libm sine above 1e5, the identical operation sequence below it)
 #pragma nounroll
-                for (int e = 0; e < 8; ++e) sl[8 * tid + e] = snake_scalar(8 * tid + e);
+                for (int e = 0; e < 8; ++e) sl[sl_pos(8 * tid + e)] = snake_scalar(8 * tid + e);
             }
             // the 10 values past the 2048 (the down filter's right halo): one lane each in the last wave
             if (tid >= 256 - 10) {
                 const int i = 2 * A1_TT + (tid - (256 - 10));
-                sl[i] = snake_scalar(i);
+                sl[sl_pos(i)] = snake_scalar(i);
             }
         }
         if (!interior) {
@@ -338,18 +346,18 @@ __global__ __launch_bounds__(256) void act1d_kernel(const float* __restrict__ x,
             __syncthreads();
             const int ilo = 5 - 2 * t0;                       // i of n = 0
             const int ihi = twoT + 4 - 2 * t0;                // i of n = 2*Tv - 1  (>= 6: t0 < Tv)
-            const float slo = sl[ilo > 0 ? ilo : 0];
-            const float shi = sl[ihi < 2 * A1_TT + 9 ? ihi : 2 * A1_TT + 9];
+            const float slo = sl[sl_pos(ilo > 0 ? ilo : 0)];
+            const float shi = sl[sl_pos(ihi < 2 * A1_TT + 9 ? ihi : 2 * A1_TT + 9)];
             __syncthreads();
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int i = 8 * tid + e;
-                if (i < ilo) sl[i] = slo;
-                else if (i > ihi) sl[i] = shi;
+                if (i < ilo) sl[sl_pos(i)] = slo;
+                else if (i > ihi) sl[sl_pos(i)] = shi;
             }
             if (tid >= 256 - 10) {
                 const int i = 2 * A1_TT + (tid - (256 - 10));
-                if (i > ihi) sl[i] = shi;
+                if (i > ihi) sl[sl_pos(i)] = shi;
             }
         }
         __syncthreads();
@@ -358,7 +366,7 @@ __global__ __launch_bounds__(256) void act1d_kernel(const float* __restrict__ x,
             f32x2 sw[10];
 #pragma unroll
             for (int v = 0; v < 5; ++v) {
-                const float4 q = *reinterpret_cast<const float4*>(&sl[2 * k0 + 4 * v]);
+                const float4 q = *reinterpret_cast<const float4*>(&sl[4 * sl_pos4(2 * tid + v)]);
                 sw[2 * v] = (f32x2){q.x, q.y};
                 sw[2 * v + 1] = (f32x2){q.z, q.w};
             }
@@ -383,7 +391,10 @@ __global__ __launch_bounds__(256) void act1d_kernel(const float* __restrict__ x,
     };
 
     // do all NTILE tiles of this workgroup exist and lie inside the row (block-uniform)?
-    const bool all_interior = tile_first + NTILE <= ntiles && is_interior(tile_first * A1_TT) &&
+    // NTILE >= 8: always the rolled loop -- a workgroup lives long enough (8+ tiles) for its start-up (scalar loads of
+    // the taps, the first window's latency: 40 % of a 2-tile workgroup's life, visit U) to stop mattering, with the
+    // next window always in flight
+    const bool all_interior = NTILE <= 4 && tile_first + NTILE <= ntiles && is_interior(tile_first * A1_TT) &&
                               is_interior((tile_first + NTILE - 1) * A1_TT);
     if (all_interior) {
         // straight-line path: every window requested now, by every lane (lanes >= 4 repeat the halo address of
@@ -429,10 +440,21 @@ static hipError_t launch_act1d_n(const float* x, float* y, int B, int C, int T, 
 hipError_t launch_act1d(const float* x, float* y, int B, int C, int T, const float* a_dev, const float* invb_dev,
                         const float* filt_up12, const float* filt_dn12, const int* lens, int len_mul,
                         hipStream_t stream) {
-    // tiles per workgroup: 2 unless AMP_ACT1D_TILES says 1 or 4 (tuning knob for tools/bench_configs.py)
-    static const int ntile = [] { const char* e = getenv("AMP_ACT1D_TILES"); return e ? atoi(e) : 2; }();
+    // tiles per workgroup.  Measured on C3 (profiles/r2_uv_act1d.txt): 2 tiles (straight-line, both windows requested at
+    // entry) 141 us per launch on average, rolled strips of 8 / 16 / 32 tiles 125.5 / 122.6 / 125.8 us: long-lived
+    // workgroups stop paying their start-up 32 768 times per launch.  Strips need a grid that still fills the chip
+    // (2 048 workgroup slots), so small launches (single utterances) keep short ones.  AMP_ACT1D_TILES forces a value.
+    static const int forced = [] { const char* e = getenv("AMP_ACT1D_TILES"); return e ? atoi(e) : 0; }();
+    int ntile = forced;
+    if (ntile == 0) {
+        const long long total = (long long)B * C * ((T + A1_TT - 1) / A1_TT);
+        ntile = total >= 16 * 4096 ? 16 : (total >= 8 * 4096 ? 8 : 2);
+    }
     if (ntile == 1) return launch_act1d_n<1>(x, y, B, C, T, a_dev, invb_dev, filt_up12, filt_dn12, lens, len_mul, stream);
     if (ntile == 4) return launch_act1d_n<4>(x, y, B, C, T, a_dev, invb_dev, filt_up12, filt_dn12, lens, len_mul, stream);
+    if (ntile == 8) return launch_act1d_n<8>(x, y, B, C, T, a_dev, invb_dev, filt_up12, filt_dn12, lens, len_mul, stream);
+    if (ntile == 16) return launch_act1d_n<16>(x, y, B, C, T, a_dev, invb_dev, filt_up12, filt_dn12, lens, len_mul, stream);
+    if (ntile == 32) return launch_act1d_n<32>(x, y, B, C, T, a_dev, invb_dev, filt_up12, filt_dn12, lens, len_mul, stream);
     return launch_act1d_n<2>(x, y, B, C, T, a_dev, invb_dev, filt_up12, filt_dn12, lens, len_mul, stream);
 }
 
