@@ -83,6 +83,23 @@ def test_conv_create_refuses_without_device():
     assert "no CPU fallback" in str(ei.value)
 
 
+def test_fused_wn_entry_points_validate_without_device():
+    """amp_conv_create_gated / amp_wn_forward (the fused WN layer): argument checks and the no-GPU refusal."""
+    L = _lib.lib()
+    w = torch.zeros(2 * 64, 64, 5)
+    b = torch.zeros(2 * 64)
+    h = ctypes.c_void_p()
+    if L.amp_device_count() == 0:
+        with pytest.raises(_lib.AmpError) as ei:
+            _lib.check(L.amp_conv_create_gated(64, 5, 1, 2, ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(b.data_ptr()), ctypes.byref(h)))
+        assert "no CPU fallback" in str(ei.value)
+    with pytest.raises(_lib.AmpError):
+        _lib.check(L.amp_conv_create_gated(64, 5, 1, 2, None, None, ctypes.byref(h)))          # null weight
+    with pytest.raises(_lib.AmpError):
+        _lib.check(L.amp_wn_forward(None, None, 0, None, None, 0, None, 1, 8, None, None, None))  # nothing to run
+    assert L.amp_set_small_conv(1) == 0
+
+
 def test_mel_num_frames():
     L = _lib.lib()
     d = _lib.amp_mel_desc(1024, 1024, 256, 80, 0, 1e-9, 1e-5)
