@@ -57,6 +57,11 @@ struct ConvArgs {
     float* wn_x;                // EPI_WNACC: x [B, H, T], updated in place: x = (x + rs[:H]) * mask
     float* wn_out;              //            output [B, H, T]: (+)= rs[H:] (last layer: (+)= rs)
     int wn_first, wn_last;      //            first layer starts `output` from zero; last layer has H rows only
+    // ---- conv_f16x3.hip, ACT variant: Activation1d applied to the conv's output in the epilogue (bigvgan.py:141-143) ----
+    const float* act_a;         // [Cout] alpha (exp'ed when logscale)
+    const float* act_invb;      // [Cout] 1 / (beta + 1e-9)
+    const float* act_fu;        // 12 up-sampling taps
+    const float* act_fd;        // 12 down-sampling taps
 };
 
 // Arguments of the fused ResBlock-pair kernel (pair_f16x3.hip):
@@ -99,6 +104,8 @@ struct ConvPlan {
 bool choose_plan(int ntaps, int M, int halo_total, int Tq, ConvPlan* plan);
 hipError_t launch_conv(const ConvPlan& plan, const ConvArgs& a, hipStream_t stream);        // exact f32 MFMA
 hipError_t launch_conv_f16x3(const ConvPlan& plan, const ConvArgs& a, hipStream_t stream);  // split-f16 MFMA
+// the same kernel with Activation1d fused behind it (a.act_*): tiles advance by NT - 16 columns; full-width tiles only
+hipError_t launch_conv_f16x3_act(const ConvPlan& plan, const ConvArgs& a, hipStream_t stream);
 // frame-rate convs (conv_small_f16x3.hip): whole-K staging; epi 0 standard, 1 gate, 2 WN accumulate; ni 2 | 4
 constexpr int kSmallConvMaxChunks = 16;
 hipError_t launch_conv_small(int KT, int ni, int epi, const ConvArgs& a, hipStream_t stream);

@@ -24,6 +24,7 @@
 //
 // This file is compiled once per tap count:  -DAMP_KT=<1|2|3|5|7|11>.
 #include "amp_internal.h"
+#include "act1d_math.h"
 
 #ifndef AMP_KT
 #error "compile with -DAMP_KT=<taps>"
@@ -45,9 +46,16 @@ union Frag {
 // counted s_waitcnt vmcnt(N) the compiler derives depends (loads return in order).
 #define AMP_PIN_VMEM() __builtin_amdgcn_sched_barrier(0x386)
 
-template <int KT, int WM, int WN, int NI, int HALO>
+// ACT = 1: Activation1d (anti-aliased Snake, act1d_math.h) applied to the conv's output before it leaves the CU --
+// AMPBlock's `xt = a2(c1(xt))` (bigvgan.py:141-143) in one launch: the output tile goes to LDS instead of HBM, the
+// activation runs on it exactly as act1d_kernel does on a staged window (same operation sequence: bit-identical to
+// conv + act1d), and only the activated values are written.  The activation needs 5 conv outputs either side of a
+// sample, so tiles advance by AT = NT - 16 columns and the margin is computed twice (14 % more MFMAs at NT = 128) --
+// against one full read and one full write of the tensor saved.
+template <int KT, int WM, int WN, int NI, int HALO, int ACT = 0>
 __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
     constexpr int NT = 32 * NI * WN;           // output columns per workgroup
+    constexpr int AT = NT - 16;                // ACT: activation outputs per workgroup
     constexpr int S = NT + HALO;               // staged columns
     constexpr int NST = (4 * S) / 256;         // staging items (column x channel quad) per thread
     constexpr int BUF = 4 * S;                 // uint4 per LDS buffer: [plane hi|lo][octet h][S]
@@ -66,18 +74,25 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
     const int bx = (nbx & 7) == 0 ? (int)(blockIdx.x & 7) * (nbx >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int item = bx / a.tiles_per_item;
     const int tile = bx - item * a.tiles_per_item;
-    const int q0 = tile * NT;
+    const int q0 = ACT ? tile * AT - 8 : tile * NT;
     const int mb = blockIdx.y * WM + wm;       // 32-row block of W'
 
     // accumulators start from (bias + residual + running MRF sum) * acc_scale, see conv_mfma.hip
     const int up = a.up;
     const int qw = q0 + wn * (32 * NI) + l31;
-    const bool fast = (up == 1) && (mb * 32 + 32 <= a.M) && (q0 + wn * (32 * NI) + 32 * NI <= a.Tq);
+    const bool fast = !ACT && (up == 1) && (mb * 32 + 32 <= a.M) && (q0 + wn * (32 * NI) + 32 * NI <= a.Tq);
     const size_t wave_base = ((size_t)item * a.Cout + (size_t)mb * 32) * a.Tout;  // uniform
     const int lane_off = (4 * hi) * a.Tout + qw;                                  // per lane
     const float asc = a.acc_scale;
     f32x16 acc[NI];
-    if (fast) {
+    if constexpr (ACT) {                      // bias only (host: no residual, no MRF mode, M a multiple of the row group)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float bv = a.bias[mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi];
+#pragma unroll
+            for (int t = 0; t < NI; ++t) acc[t][r] = bv;
+        }
+    } else if (fast) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int rowc = (r & 3) + 8 * (r >> 2);
@@ -256,6 +271,137 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
 
     if (a.range_flag && __any(range_max > 65504.f) && lane == 0) atomicOr(a.range_flag, 1u);
 
+    if constexpr (ACT) {
+        // ---- fused Activation1d epilogue ----
+        constexpr int ROWS = 32 * WM;              // rows of the tile; ROWS * NT = 16 384 values = 16 passes of 1 024
+        constexpr int RP = 1024 / NT;              // rows per pass (a lane owns 4 consecutive columns of one row)
+        constexpr int SROW = 2 * NT;               // Snake values per row
+        float* yl = reinterpret_cast<float*>(smem4);        // [ROWS][NT] conv output (the staging buffers are dead:
+        float* sb = yl + ROWS * NT;                         //  the K loop ended on a barrier); [RP][SROW] + 16 pad
+        if (q0 + 8 >= Tv) return;                  // nothing valid in this tile (ragged batch); block-uniform
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+#pragma unroll
+            for (int t = 0; t < NI; ++t) yl[row * NT + wn * (32 * NI) + 32 * t + l31] = acc[t][r] * a.inv_scale;
+        }
+        __syncthreads();
+        // UpSample1d replicate-pads ITS INPUT (resample.py:36-45): conv outputs left of sample 0 / right of the
+        // utterance's last sample are copies of that sample
+        const bool edge = (q0 < 0) || (q0 + NT > Tv);
+        if (edge) {
+            const int clo = q0 < 0 ? -q0 : 0;
+            int chi = Tv - 1 - q0;
+            chi = chi > NT - 1 ? NT - 1 : chi;
+            for (int idx = tid; idx < ROWS * NT; idx += 256) {
+                const int row = idx / NT, col = idx - row * NT;
+                if (col < clo) yl[idx] = yl[row * NT + clo];
+                else if (col > chi) yl[idx] = yl[row * NT + chi];
+            }
+            __syncthreads();
+        }
+        float fu2[12], fdr[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) { fu2[k] = 2.f * a.act_fu[k]; fdr[k] = a.act_fd[k]; }
+        const int rip = (4 * tid) / NT;            // row inside a pass
+        const int col = 4 * tid - rip * NT;        // first of this lane's 4 columns
+        const int cg = col >> 2;
+        const bool lane_ok = (cg >= 2) && (cg <= NT / 4 - 3);
+        const int tq = q0 + col;                   // output sample of column `col`
+        float* srow = sb + rip * SROW;
+        const int twoT = 2 * Tv;
+        const bool vec_rows = (a.Tout & 3) == 0;
+        for (int pass = 0; pass < 16; ++pass) {
+            const int row = pass * RP + rip;
+            const int ch = blockIdx.y * ROWS + row;
+            const float aa = a.act_a[ch], invb = a.act_invb[ch];
+            // this lane's 12-value window y[col - 8 .. col + 3] (lanes cg < 2 read a wrong window: their outputs,
+            // and those that would need their Snake values, lie in the tile's margin)
+            const float* yw = yl + row * NT + (col >= 8 ? col - 8 : 0);
+            const float4 w0 = *reinterpret_cast<const float4*>(yw);
+            const float4 w1 = *reinterpret_cast<const float4*>(yw + 4);
+            const float4 w2 = *reinterpret_cast<const float4*>(yw + 8);
+            const float xw[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+            f32x2 uv[4], xa[4], sv[4];
+            float big = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int top = q + 8;
+                f32x2 u = pk_splat(0.f);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) u = pk_fma(pk_splat(xw[top - k]), (f32x2){fu2[2 * k], fu2[2 * k + 1]}, u);
+                uv[q] = u;
+                xa[q] = u * aa;
+                big = fmaxf(big, fmaxf(fabsf(xa[q].x), fabsf(xa[q].y)));
+            }
+            snake_sin2_pk4(xa, sv);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sv[q] = pk_fma(pk_splat(invb), sv[q], uv[q]);
+            if (__builtin_expect(big > 1.0e5f, 0)) {
+                // beyond the fast range reduction: the eight values one at a time through snake_sin2 (libm sine above
+                // 1e5, the identical operation sequence below it), as act1d_kernel does
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int top = ((e + 10) >> 1) + 3, par = e & 1;
+                    float u = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) u = fmaf(xw[top - k], fu2[par + 2 * k], u);
+                    const float s1 = fmaf(invb, snake_sin2(u * aa), u);
+                    if (par) sv[e >> 1].y = s1; else sv[e >> 1].x = s1;
+                }
+            }
+            *reinterpret_cast<float4*>(&srow[4 * sl_pos4(2 * cg)]) = make_float4(sv[0].x, sv[0].y, sv[1].x, sv[1].y);
+            *reinterpret_cast<float4*>(&srow[4 * sl_pos4(2 * cg + 1)]) = make_float4(sv[2].x, sv[2].y, sv[3].x, sv[3].y);
+            __syncthreads();
+            if (edge) {
+                // DownSample1d pads the SNAKE OUTPUT by replication (filter.py:92-99): values whose n = 2*q0 + i - 5 lies
+                // outside [0, 2*Tv - 1] are copies of the first / last valid one
+                const int ilo = 5 - 2 * q0;
+                const int ihi = twoT + 4 - 2 * q0;
+                const float slo = srow[sl_pos(ilo > 0 ? (ilo < SROW - 1 ? ilo : SROW - 1) : 0)];
+                const float shi = srow[sl_pos(ihi < SROW - 1 ? (ihi > 0 ? ihi : 0) : SROW - 1)];
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int i = 8 * cg + e;
+                    if (i < ilo) srow[sl_pos(i)] = slo;
+                    else if (i > ihi) srow[sl_pos(i)] = shi;
+                }
+                __syncthreads();
+            }
+            {
+                f32x2 sw[10];
+#pragma unroll
+                for (int v = 0; v < 5; ++v) {
+                    const float4 q4 = *reinterpret_cast<const float4*>(&srow[4 * sl_pos4(2 * cg + v)]);
+                    sw[2 * v] = (f32x2){q4.x, q4.y};
+                    sw[2 * v + 1] = (f32x2){q4.z, q4.w};
+                }
+                float4 o;
+                float* op = &o.x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    f32x2 ac2 = pk_splat(0.f);
+#pragma unroll
+                    for (int m = 0; m < 6; ++m) ac2 = pk_fma((f32x2){fdr[2 * m], fdr[2 * m + 1]}, sw[e + m], ac2);
+                    op[e] = ac2.x + ac2.y;
+                }
+                if (lane_ok && tq < Tv) {
+                    float* yo = a.y + ((size_t)item * a.Cout + ch) * a.Tout + tq;
+                    if (vec_rows && tq + 4 <= Tv) {
+                        *reinterpret_cast<float4*>(yo) = o;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (tq + e < Tv) yo[e] = op[e];
+                    }
+                }
+            }
+            __syncthreads();   // `sb` is rewritten by the next pass
+        }
+        return;
+    }
+
     // ---- epilogue: undo the operand scaling, MRF mean, activation-on-store, (polyphase) scatter ----
     const float slope_out = a.slope_out;
     const bool exact_div = a.mode == 2;  // x = xs / num_kernels is a true division (hifigan.py:214)
@@ -379,8 +525,46 @@ static hipError_t launch_one_h(const ConvArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// ACT variant: full-width tiles; LDS = the [32 * WM][NT] fp32 output tile + one pass of Snake values
+template <int KT, int WM, int WN, int HALO>
+static hipError_t launch_one_h_act(const ConvArgs& a, hipStream_t stream) {
+    constexpr int NI = 4;
+    constexpr int NT = 32 * NI * WN;
+    constexpr int S = NT + HALO;
+    const size_t lds_stage = (size_t)2 * 4 * S * sizeof(uint4);
+    const size_t lds_act = ((size_t)32 * WM * NT + (size_t)(1024 / NT) * 2 * NT + 16) * sizeof(float);
+    const size_t lds = lds_stage > lds_act ? lds_stage : lds_act;
+    static unsigned long long attr_set = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!((attr_set >> dev) & 1ull)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16x3_kernel<KT, WM, WN, NI, HALO, 1>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set |= 1ull << dev;
+    }
+    dim3 grid((unsigned)(a.B * a.tiles_per_item), (unsigned)((a.M + 32 * WM - 1) / (32 * WM)));
+    hipLaunchKernelGGL((conv_f16x3_kernel<KT, WM, WN, NI, HALO, 1>), grid, dim3(256), lds, stream, a);
+    return hipGetLastError();
+}
+
 #define AMP_CAT2(a, b) a##b
 #define AMP_CAT(a, b) AMP_CAT2(a, b)
+
+#if AMP_KT >= 3
+// conv + Activation1d (ACT = 1); the caller sets a.tiles_per_item for tiles advancing by p.NT() - 16 columns
+hipError_t AMP_CAT(launch_conv_h_act_kt, AMP_KT)(const ConvPlan& p, const ConvArgs& a, hipStream_t stream) {
+    constexpr int KT = AMP_KT;
+    if (p.HALO == 64) {
+        if (p.WM == 4) return launch_one_h_act<KT, 4, 1, 64>(a, stream);
+        if (p.WM == 2) return launch_one_h_act<KT, 2, 2, 64>(a, stream);
+        return launch_one_h_act<KT, 1, 4, 64>(a, stream);
+    }
+    if (p.WM == 4) return launch_one_h_act<KT, 4, 1, 128>(a, stream);
+    if (p.WM == 2) return launch_one_h_act<KT, 2, 2, 128>(a, stream);
+    return launch_one_h_act<KT, 1, 4, 128>(a, stream);
+}
+#endif
 
 hipError_t AMP_CAT(launch_conv_h_kt, AMP_KT)(const ConvPlan& p, const ConvArgs& a, hipStream_t stream) {
     constexpr int KT = AMP_KT;

@@ -330,6 +330,20 @@ static bool small_tiles_enabled() {
     return on;
 }
 
+hipError_t launch_conv_h_act_kt3(const ConvPlan&, const ConvArgs&, hipStream_t);
+hipError_t launch_conv_h_act_kt5(const ConvPlan&, const ConvArgs&, hipStream_t);
+hipError_t launch_conv_h_act_kt7(const ConvPlan&, const ConvArgs&, hipStream_t);
+hipError_t launch_conv_h_act_kt11(const ConvPlan&, const ConvArgs&, hipStream_t);
+hipError_t launch_conv_f16x3_act(const ConvPlan& p, const ConvArgs& a, hipStream_t s) {
+    switch (p.KT) {
+        case 3: return launch_conv_h_act_kt3(p, a, s);
+        case 5: return launch_conv_h_act_kt5(p, a, s);
+        case 7: return launch_conv_h_act_kt7(p, a, s);
+        case 11: return launch_conv_h_act_kt11(p, a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_conv_small_kt1(int, int, const ConvArgs&, hipStream_t);
 hipError_t launch_conv_small_kt3(int, int, const ConvArgs&, hipStream_t);
 hipError_t launch_conv_small_kt5(int, int, const ConvArgs&, hipStream_t);
@@ -561,6 +575,57 @@ static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope
     return AMP_OK;
 }
 
+// `a2(c1(x))` of an AMPBlock as ONE launch (the conv kernel's ACT variant, conv_f16x3.hip) instead of conv + act1d: same
+// bits (tests/test_gpu_bigvgan.py), one read and one write of the tensor less -- and SLOWER on MI355X (visit Y,
+// profiles/r2_y_conv_act_fused.txt: the conv launches grow by 110-145 us each, as much as the act1d launch they
+// replace, plus 14 % recomputed margin: C3 27.6 vs 26.8 ms).  The activation is VALU + LDS work that the stand-alone
+// kernel runs at 8 waves per SIMD under its own HBM stream; behind a conv it runs at 2 waves per SIMD and overlaps
+// nothing.  Off unless AMP_FUSE_ACT=1 / amp_set_fuse_act(1).
+static int g_fuse_act = -1;
+static bool fuse_act_enabled() {
+    if (g_fuse_act < 0) {
+        const char* e = getenv("AMP_FUSE_ACT");
+        g_fuse_act = (e && !strcmp(e, "1")) ? 1 : 0;
+    }
+    return g_fuse_act != 0;
+}
+
+// conv + Activation1d in one launch is built for: f16x3, Conv1d with 'same' zero padding, k in {3, 5, 7, 11}, a bias,
+// rows a multiple of the kernel's row group; the launch must be large enough for full-width tiles
+static bool conv_act_supported(const amp_conv* c, int B, int T) {
+    if (c->precision != PREC_F16X3 || c->transposed || c->pad_reflect || c->tanh_out || c->gated_H || !c->bias_dev) return false;
+    if (c->KT != c->ntaps || (c->KT != 3 && c->KT != 5 && c->KT != 7 && c->KT != 11)) return false;
+    if (c->M % c->plan.Mgroup() != 0 || conv_out_len(c, T) != T) return false;
+    ConvPlan plan = c->plan;   // NI = 4
+    const long long wgs = (long long)B * ((T + plan.NT() - 1) / plan.NT()) * (c->M / plan.Mgroup());
+    return wgs >= kSmallGridWorkgroups;
+}
+
+// y = Activation1d(conv(x) + bias): a2(c1(xt)) of AMPBlock1 (bigvgan.py:141-143).  y must not alias x.
+static int conv_act_run(const amp_conv* c, const float* x, int B, int T, const float* act_a, const float* act_invb,
+                        const float* act_fu, const float* act_fd, float* y, hipStream_t stream, const int* lens = nullptr,
+                        int len_mul = 1) {
+    if (!conv_act_supported(c, B, T)) { set_error("conv_act_run: unsupported conv / launch shape"); return AMP_ERR_UNSUPPORTED; }
+    if (x == y) { set_error("conv_act_run: x and y must not alias"); return AMP_ERR_INVALID; }
+    ConvArgs a{};
+    a.x = x; a.wp = c->wp_dev; a.bias = c->bias_dev; a.res = nullptr; a.y = y;
+    a.B = B; a.Cin = c->cin; a.Tin = T; a.xbs = (long long)c->cin * T; a.nchunks = c->nchunks; a.M = c->M;
+    a.Tq = T;
+    const ConvPlan plan = c->plan;
+    const int AT = plan.NT() - 16;
+    a.tiles_per_item = (T + AT - 1) / AT;
+    a.off0 = c->off0; a.dstep = c->dstep; a.halo_left = c->halo_left;
+    a.wd = plan.NT() + c->halo_left + c->halo_right;
+    a.Cout = c->cout; a.Tout = T; a.up = 1; a.up_pad = 0;
+    a.slope_in = 1.f; a.slope_out = 1.f; a.mode = 0; a.div = 1.f;
+    a.lens = lens; a.len_mul = len_mul;
+    a.range_flag = range_flag_for_current_device();
+    a.acc_scale = 16.f * c->wscale; a.inv_scale = 1.f / a.acc_scale;
+    a.act_a = act_a; a.act_invb = act_invb; a.act_fu = act_fu; a.act_fd = act_fd;
+    AMP_HIP(launch_conv_f16x3_act(plan, a, stream));
+    return AMP_OK;
+}
+
 // Fused ResBlock1 pair (pair_f16x3.hip): y = x + c2(lrelu(c1(lrelu(x)))).  Returns false when this
 // (channels, kernel, dilation, precision) is not covered and the caller must run the two convs.
 static bool pair_supported(const amp_conv* c1, const amp_conv* c2) {
@@ -707,6 +772,30 @@ static void expect_act(amp_gen* g, const std::string& p, int c) {
 static std::string ups_key(const amp_gen* g, int i) {
     // BigVGAN nests each upsampler in a 1-element ModuleList (bigvgan.py:261-276)
     return g->d.arch == AMP_ARCH_BIGVGAN ? "ups." + std::to_string(i) + ".0" : "ups." + std::to_string(i);
+}
+
+// Op-level convenience (tests): derive a = alpha (exp'ed when logscale) and 1 / (beta + 1e-9) on the host and upload them
+// with the two 12-tap filters: scratch = [a (C) | invb (C) | up taps (12) | down taps (12)].  The caller frees `*out`.
+static int act_params_upload(const float* alpha_dev, const float* beta_dev, int C, int logscale, const float* filt_up_host,
+                             const float* filt_down_host, float** out) {
+    std::vector<float> al(C), be(C), a(C), ib(C);
+    AMP_HIP(hipMemcpy(al.data(), alpha_dev, C * sizeof(float), hipMemcpyDeviceToHost));
+    if (beta_dev) AMP_HIP(hipMemcpy(be.data(), beta_dev, C * sizeof(float), hipMemcpyDeviceToHost));
+    for (int i = 0; i < C; ++i) {
+        float av = al[i], bv = beta_dev ? be[i] : al[i];
+        if (logscale) { av = expf(av); bv = expf(bv); }
+        a[i] = av;
+        ib[i] = 1.0f / (bv + 0.000000001f);
+    }
+    float* scratch = nullptr;
+    AMP_HIP(hipMalloc((void**)&scratch, (2 * (size_t)C + 24) * sizeof(float)));
+    hipError_t e = hipMemcpy(scratch, a.data(), C * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(scratch + C, ib.data(), C * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(scratch + 2 * C, filt_up_host, 12 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(scratch + 2 * C + 12, filt_down_host, 12 * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(scratch); set_error("act_params_upload: %s", hipGetErrorString(e)); return AMP_ERR_HIP; }
+    *out = scratch;
+    return AMP_OK;
 }
 
 extern "C" {
@@ -1183,10 +1272,17 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
                             AMP_HIP(hipMemcpyAsync(R_, TMP_, (size_t)B * C * t * sizeof(float), hipMemcpyDeviceToDevice, sj));
                             cur = R_;
                         }
-                        AMP_RC(conv_run(rb.c1[p].get(), ACT_, B, t, 1.f, nullptr, 1.f, TMP_, 0, 1.f, sj, 0, lens, lm));
-                        AMP_HIP(launch_act1d(TMP_, ACT_, B, C, t, a2.a_dev, a2.invb_dev, a2.fu_dev, a2.fd_dev, lens, lm, sj));
-                        if (!last) { AMP_RC(conv_run(rb.c2[p].get(), ACT_, B, t, 1.f, cur, 1.f, R_, 0, 1.f, sj, 0, lens, lm)); cur = R_; }
-                        else AMP_RC(conv_run(rb.c2[p].get(), ACT_, B, t, 1.f, cur, 1.f, XS, mode_last, (float)nk, sj, 0, lens, lm));
+                        const float* c2_in = ACT_;
+                        if (fuse_act_enabled() && conv_act_supported(rb.c1[p].get(), B, t)) {
+                            // a2(c1(.)) in one launch: the conv's output tile never leaves the CU un-activated
+                            AMP_RC(conv_act_run(rb.c1[p].get(), ACT_, B, t, a2.a_dev, a2.invb_dev, a2.fu_dev, a2.fd_dev, TMP_, sj, lens, lm));
+                            c2_in = TMP_;
+                        } else {
+                            AMP_RC(conv_run(rb.c1[p].get(), ACT_, B, t, 1.f, nullptr, 1.f, TMP_, 0, 1.f, sj, 0, lens, lm));
+                            AMP_HIP(launch_act1d(TMP_, ACT_, B, C, t, a2.a_dev, a2.invb_dev, a2.fu_dev, a2.fd_dev, lens, lm, sj));
+                        }
+                        if (!last) { AMP_RC(conv_run(rb.c2[p].get(), c2_in, B, t, 1.f, cur, 1.f, R_, 0, 1.f, sj, 0, lens, lm)); cur = R_; }
+                        else AMP_RC(conv_run(rb.c2[p].get(), c2_in, B, t, 1.f, cur, 1.f, XS, mode_last, (float)nk, sj, 0, lens, lm));
                     }
                 } else {
                     // x = c(act(x)) + x                                    hifigan.py:140-145, bigvgan.py:218-224
@@ -1388,6 +1484,27 @@ int amp_wn_forward(const amp_conv* const* in_layers, const amp_conv* const* res_
     return AMP_OK;
 }
 
+int amp_set_fuse_act(int on) {
+    g_fuse_act = on ? 1 : 0;
+    return AMP_OK;
+}
+
+int amp_conv_act_forward(const amp_conv* c, const float* x_dev, int B, int T, const float* alpha_dev, const float* beta_dev,
+                         int logscale, const float* filt_up_host, const float* filt_down_host, float* y_dev, void* stream) {
+    if (!c || !x_dev || !y_dev || !alpha_dev || !filt_up_host || !filt_down_host) { set_error("amp_conv_act_forward: null argument"); return AMP_ERR_INVALID; }
+    if (B <= 0 || T <= 0) { set_error("amp_conv_act_forward: B=%d T=%d", B, T); return AMP_ERR_INVALID; }
+    if (!conv_act_supported(c, B, T)) { set_error("amp_conv_act_forward: conv / launch shape outside the fused kernel (run amp_conv_forward + amp_antialias_snake)"); return AMP_ERR_UNSUPPORTED; }
+    float* scratch = nullptr;
+    const int C = c->cout;
+    int rc = act_params_upload(alpha_dev, beta_dev, C, logscale, filt_up_host, filt_down_host, &scratch);
+    if (rc != AMP_OK) return rc;
+    rc = conv_act_run(c, x_dev, B, T, scratch, scratch + C, scratch + 2 * C, scratch + 2 * C + 12, y_dev, (hipStream_t)stream);
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(scratch);
+    if (rc == AMP_OK && e != hipSuccess) { set_error("amp_conv_act_forward: %s", hipGetErrorString(e)); return AMP_ERR_HIP; }
+    return rc;
+}
+
 int amp_conv_out_len(const amp_conv* c, int T) { return c ? conv_out_len(c, T) : 0; }
 
 int amp_conv_forward(const amp_conv* c, const float* x_dev, int B, int T, float slope_in, const float* res_dev,
@@ -1551,21 +1668,10 @@ int amp_antialias_snake(const float* x_dev, int B, int C, int T, const float* al
     if (!x_dev || !y_dev || !alpha_dev || !filt_up_host || !filt_down_host) { set_error("amp_antialias_snake: null argument"); return AMP_ERR_INVALID; }
     if (B <= 0 || C <= 0 || T <= 0) { set_error("amp_antialias_snake: B=%d C=%d T=%d", B, C, T); return AMP_ERR_INVALID; }
     // op-level convenience path (tests): derive a / 1/(b+eps) on the host, synchronously.
-    std::vector<float> al(C), be(C), a(C), ib(C);
-    AMP_HIP(hipMemcpy(al.data(), alpha_dev, C * sizeof(float), hipMemcpyDeviceToHost));
-    if (beta_dev) AMP_HIP(hipMemcpy(be.data(), beta_dev, C * sizeof(float), hipMemcpyDeviceToHost));
-    for (int i = 0; i < C; ++i) {
-        float av = al[i], bv = beta_dev ? be[i] : al[i];
-        if (logscale) { av = expf(av); bv = expf(bv); }
-        a[i] = av;
-        ib[i] = 1.0f / (bv + 0.000000001f);
-    }
     float* scratch = nullptr;
-    AMP_HIP(hipMalloc((void**)&scratch, (2 * (size_t)C + 24) * sizeof(float)));
-    hipError_t e = hipMemcpy(scratch, a.data(), C * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(scratch + C, ib.data(), C * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(scratch + 2 * C, filt_up_host, 12 * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(scratch + 2 * C + 12, filt_down_host, 12 * sizeof(float), hipMemcpyHostToDevice);
+    const int rc = act_params_upload(alpha_dev, beta_dev, C, logscale, filt_up_host, filt_down_host, &scratch);
+    if (rc != AMP_OK) return rc;
+    hipError_t e = hipSuccess;
     if (e == hipSuccess) e = launch_act1d(x_dev, y_dev, B, C, T, scratch, scratch + C, scratch + 2 * C, scratch + 2 * C + 12, nullptr, 1, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     (void)hipFree(scratch);

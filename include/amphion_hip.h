@@ -346,6 +346,17 @@ int amp_antialias_snake(const float* x_dev, int B, int C, int T, const float* al
                         int logscale, const float* filt_up_host, const float* filt_down_host, float* y_dev,
                         void* stream);
 
+/* a2(c1(xt)) of an AMPBlock (bigvgan.py:141-143) in one launch: y = Activation1d(conv(x) + bias), the conv's output tile
+ * activated in LDS before it is stored (csrc/conv_f16x3.hip, ACT variant) -- bit-identical to amp_conv_forward followed by
+ * amp_antialias_snake, one read and one write of the tensor less.  Covered: f16x3 arithmetic, Conv1d with 'same' zero
+ * padding and a bias, k in {3, 5, 7, 11}, cout a multiple of 32, and a launch of at least 384 full-width tiles; anything
+ * else returns AMP_ERR_UNSUPPORTED (run the two ops).  Parameters as in amp_antialias_snake (op-level convenience:
+ * synchronises).  Measured slower than the two launches on MI355X, so amp_gen_forward uses it only after
+ * amp_set_fuse_act(1) / AMP_FUSE_ACT=1 (A/B and cross-check switch). */
+int amp_conv_act_forward(const amp_conv* c, const float* x_dev, int B, int T, const float* alpha_dev, const float* beta_dev,
+                         int logscale, const float* filt_up_host, const float* filt_down_host, float* y_dev, void* stream);
+int amp_set_fuse_act(int on);
+
 /* Mel / STFT front end descriptor: cfg.preprocess.{sample_rate,n_fft,win_size,hop_size,n_mel,fmin,fmax}. */
 typedef struct amp_mel_desc {
     int32_t n_fft;
