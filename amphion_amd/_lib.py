@@ -10,7 +10,8 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libamphion_hip.so")
+# AMP_LIB_PATH: another build of the same ABI (same-box A/B of kernel changes, tools/gpu_r2_z.sh)
+LIB_PATH = os.environ.get("AMP_LIB_PATH") or os.path.join(_HERE, "lib", "libamphion_hip.so")
 
 AMP_MAX_STAGES = 8
 AMP_MAX_KERNELS = 8

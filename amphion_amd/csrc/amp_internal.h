@@ -175,4 +175,56 @@ __device__ __forceinline__ void split_f16(float v, _Float16& h, _Float16& l) {
     l = (_Float16)(v - (float)h);
 }
 
+// ---- the same split on FOUR operands with gfx950's packed conversions ------------------------------------------------
+// Staging (and the fused pair's seam) is VALU work on a chip that runs these kernels at its power limit: per element the
+// scalar form costs select + compare + select + multiply + 3 conversions + subtract + half a pack (9.5 instructions),
+// the packed form 2 multiplies + max for the leaky ReLU and v_cvt_pk_f16_f32 / v_pk_add_f32 for the split (about 6).
+// Every value is the one split_f16 / `v * (v > 0 ? kpos : kneg)` produce:
+//   max(kpos * x, kneg * x) == x * (x > 0 ? kpos : kneg) for kneg <= kpos (slopes <= 1; the host refuses larger ones),
+//   hi = RNE f16(v), v - hi is exact in fp32, lo = RNE f16(v - hi).
+typedef float amp_f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 amp_f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split4_f16(amp_f32x2 v01, amp_f32x2 v23, uint2& h, uint2& l) {
+    asm("" : "+v"(v01));      // opaque, as in split_f16: no folding of the producing multiply into ONE of the conversions
+    asm("" : "+v"(v23));
+    const amp_f16x2 h01 = __builtin_convertvector(v01, amp_f16x2), h23 = __builtin_convertvector(v23, amp_f16x2);
+    const amp_f32x2 d01 = v01 - __builtin_convertvector(h01, amp_f32x2), d23 = v23 - __builtin_convertvector(h23, amp_f32x2);
+    const amp_f16x2 l01 = __builtin_convertvector(d01, amp_f16x2), l23 = __builtin_convertvector(d23, amp_f16x2);
+    h.x = __builtin_bit_cast(unsigned, h01); h.y = __builtin_bit_cast(unsigned, h23);
+    l.x = __builtin_bit_cast(unsigned, l01); l.y = __builtin_bit_cast(unsigned, l23);
+}
+
+// leaky-ReLU-on-load + x16 of four staged values (x already zeroed where the conv pads) -> hi / lo planes; keeps the
+// running maximum of |staged operand| for the range guard
+__device__ __forceinline__ void stage4_f16(float x0, float x1, float x2, float x3, float kpos, float kneg, float& range_max,
+                                           uint2& h, uint2& l) {
+    const amp_f32x2 x01 = {x0, x1}, x23 = {x2, x3};
+    const amp_f32x2 a01 = x01 * kpos, a23 = x23 * kpos, b01 = x01 * kneg, b23 = x23 * kneg;
+    const amp_f32x2 v01 = {__builtin_fmaxf(a01.x, b01.x), __builtin_fmaxf(a01.y, b01.y)};
+    const amp_f32x2 v23 = {__builtin_fmaxf(a23.x, b23.x), __builtin_fmaxf(a23.y, b23.y)};
+    range_max = __builtin_fmaxf(range_max, __builtin_fmaxf(__builtin_fabsf(v01.x), __builtin_fabsf(v01.y)));
+    range_max = __builtin_fmaxf(range_max, __builtin_fmaxf(__builtin_fabsf(v23.x), __builtin_fabsf(v23.y)));
+    split4_f16(v01, v23, h, l);
+}
+
+// the fused pair's seam: four conv1 accumulators -> leaky ReLU -> conv2's zero padding (`qok`) -> x16 -> hi / lo planes.
+// Same roundings as the scalar form (v = acc * isc; v = v > 0 ? v : v * slope; v = qok ? v * 16 : 0): max(v, v * slope) is
+// that leaky ReLU for slope <= 1 and the x16 is exact.
+__device__ __forceinline__ void seam4_f16(float c0, float c1, float c2, float c3, float isc, float slope, bool qok,
+                                          float& range_max, uint2& h, uint2& l) {
+    const amp_f32x2 c01 = {c0, c1}, c23 = {c2, c3};
+    const amp_f32x2 w01 = c01 * isc, w23 = c23 * isc;
+    const amp_f32x2 n01 = w01 * slope, n23 = w23 * slope;
+    amp_f32x2 v01 = {__builtin_fmaxf(w01.x, n01.x), __builtin_fmaxf(w01.y, n01.y)};
+    amp_f32x2 v23 = {__builtin_fmaxf(w23.x, n23.x), __builtin_fmaxf(w23.y, n23.y)};
+    v01 = v01 * 16.f;
+    v23 = v23 * 16.f;
+    v01.x = qok ? v01.x : 0.f; v01.y = qok ? v01.y : 0.f;
+    v23.x = qok ? v23.x : 0.f; v23.y = qok ? v23.y : 0.f;
+    range_max = __builtin_fmaxf(range_max, __builtin_fmaxf(__builtin_fabsf(v01.x), __builtin_fabsf(v01.y)));
+    range_max = __builtin_fmaxf(range_max, __builtin_fmaxf(__builtin_fabsf(v23.x), __builtin_fabsf(v23.y)));
+    split4_f16(v01, v23, h, l);
+}
+
 }  // namespace amp

@@ -200,14 +200,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
             const int t = tbase + col;
             const bool tok = (col < a.wd) && (a.pad_reflect || ((t >= 0) && (t < Tv)));
             const int ch0 = chunk * KC16 + 4 * qd;
-            union { uint2 u; _Float16 h[4]; } fh, fl;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = (tok && (ch0 + e) < a.Cin) ? xs[it][e] : 0.f;
-                v = v * (v > 0.f ? kpos : kneg);
-                range_max = __builtin_fmaxf(range_max, __builtin_fabsf(v));
-                split_f16(v, fh.h[e], fl.h[e]);
-            }
+            struct { uint2 u; } fh, fl;
+            stage4_f16((tok && (ch0 + 0) < a.Cin) ? xs[it][0] : 0.f, (tok && (ch0 + 1) < a.Cin) ? xs[it][1] : 0.f, (tok && (ch0 + 2) < a.Cin) ? xs[it][2] : 0.f, (tok && (ch0 + 3) < a.Cin) ? xs[it][3] : 0.f,
+                       kpos, kneg, range_max, fh.u, fl.u);
             // uint2 index inside a plane: ((octet * S + col) * 2 + half)
             const int o2 = (((qd >> 1) * S + col) << 1) + (qd & 1);
             dst[o2] = fh.u;

@@ -283,14 +283,9 @@ __global__ __launch_bounds__(256, (NI == 1 ? 2 : 1)) void conv_small_kernel(cons
             for (int it = 0; it < NST; ++it) {
                 const int qd = (wave * 64 + 256 * it) / S;
                 const int ch0 = c * KC16 + 4 * qd;
-                union { uint2 u; _Float16 h[4]; } fh, fl;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = (tokv[it] && (ch0 + e) < a.Cin) ? xs[c][it][e] : 0.f;
-                    v = v * (v > 0.f ? kpos : kneg);
-                    range_max = __builtin_fmaxf(range_max, __builtin_fabsf(v));
-                    split_f16(v, fh.h[e], fl.h[e]);
-                }
+                struct { uint2 u; } fh, fl;
+                stage4_f16((tokv[it] && (ch0 + 0) < a.Cin) ? xs[c][it][0] : 0.f, (tokv[it] && (ch0 + 1) < a.Cin) ? xs[c][it][1] : 0.f, (tokv[it] && (ch0 + 2) < a.Cin) ? xs[c][it][2] : 0.f, (tokv[it] && (ch0 + 3) < a.Cin) ? xs[c][it][3] : 0.f,
+                           kpos, kneg, range_max, fh.u, fl.u);
                 dst[o2v[it]] = fh.u;
                 dst[4 * S + o2v[it]] = fl.u;
             }

@@ -555,6 +555,11 @@ static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope
         return AMP_ERR_INVALID;
     }
     if (c->gated_H) { set_error("amp_conv_forward: a gated conv (amp_conv_create_gated) only runs inside amp_wn_forward"); return AMP_ERR_STATE; }
+    if (c->precision == PREC_F16X3 && slope_in > 1.f) {
+        // the f16x3 kernels form leaky_relu-on-load as max(16 x, 16 slope x) (amp_internal.h: stage4_f16)
+        set_error("amp_conv_forward: leaky_relu slope %g > 1 on the input is outside the f16x3 kernels (use AMP_PRECISION_F32)", (double)slope_in);
+        return AMP_ERR_UNSUPPORTED;
+    }
     if (c->precision == PREC_F32) {
         a.acc_scale = a.inv_scale = 1.f;
         AMP_HIP(launch_conv(plan, a, stream));
@@ -644,6 +649,7 @@ static bool pair_supported(const amp_conv* c1, const amp_conv* c2) {
 static int pair_run(const amp_conv* c1, const amp_conv* c2, const float* x, int B, int T, float slope, float* y,
                     int mode, float div, hipStream_t stream, const int* lens = nullptr, int len_mul = 1) {
     if (x == y) { set_error("pair_run: x and y must not alias"); return AMP_ERR_INVALID; }
+    if (slope > 1.f) { set_error("pair_run: leaky_relu slope %g > 1 is outside the fused pair kernels", (double)slope); return AMP_ERR_UNSUPPORTED; }
     PairArgs a{};
     a.x = x; a.y = y;
     a.wp1 = c1->wp_dev; a.bias1 = c1->bias_dev; a.wp2 = c2->wp_dev; a.bias2 = c2->bias_dev;

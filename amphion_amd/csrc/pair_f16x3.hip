@@ -134,14 +134,9 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairArgs a) {
             const int col = ibase - qd * SX + lane;
             const int t = tbase + col;
             const bool tok = (t >= 0) && (t < Tv);
-            union { uint2 u; _Float16 h[4]; } fh, fl;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = tok ? xs[it][e] : 0.f;
-                v = v * (v > 0.f ? kpos : kneg);
-                range_max = __builtin_fmaxf(range_max, __builtin_fabsf(v));
-                split_f16(v, fh.h[e], fl.h[e]);
-            }
+            struct { uint2 u; } fh, fl;
+            stage4_f16(tok ? xs[it][0] : 0.f, tok ? xs[it][1] : 0.f, tok ? xs[it][2] : 0.f, tok ? xs[it][3] : 0.f,
+                       kpos, kneg, range_max, fh.u, fl.u);
             const int o2 = (((qd >> 1) * SX + col) << 1) + (qd & 1);
             dst[o2] = fh.u;
             dst[4 * SX + o2] = fl.u;
@@ -211,15 +206,8 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairArgs a) {
             const bool qok = (q >= 0) && (q < Tv);           // conv2 zero-pads xt outside the utterance
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                union { uint2 u; _Float16 h[4]; } fh, fl;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float v = acc[t][4 * j + i] * i1;
-                    v = v > 0.f ? v : v * slope;
-                    v = qok ? v * 16.f : 0.f;
-                    range_max = __builtin_fmaxf(range_max, __builtin_fabsf(v));
-                    split_f16(v, fh.h[i], fl.h[i]);
-                }
+                struct { uint2 u; } fh, fl;
+                seam4_f16(acc[t][4 * j + 0], acc[t][4 * j + 1], acc[t][4 * j + 2], acc[t][4 * j + 3], i1, slope, qok, range_max, fh.u, fl.u);
                 // channels 32*wm + 8*j + 4*hi + i  ->  chunk 2*wm + (j >> 1), octet j & 1, half hi
                 const int o4 = (2 * wm + (j >> 1)) * XTCH + (j & 1) * XT + col;
                 xt2[(o4 << 1) + hi] = fh.u;

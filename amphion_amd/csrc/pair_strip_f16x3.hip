@@ -122,14 +122,9 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
             const int col = ibase - qd * SX + lane;
             const int t = tbase + col;
             const bool tok = (t >= 0) && (t < Tv);
-            union { uint2 u; _Float16 h[4]; } fh, fl;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = tok ? xs[it][e] : 0.f;
-                v = v * (v > 0.f ? kpos : kneg);
-                range_max = __builtin_fmaxf(range_max, __builtin_fabsf(v));
-                split_f16(v, fh.h[e], fl.h[e]);
-            }
+            struct { uint2 u; } fh, fl;
+            stage4_f16(tok ? xs[it][0] : 0.f, tok ? xs[it][1] : 0.f, tok ? xs[it][2] : 0.f, tok ? xs[it][3] : 0.f,
+                       kpos, kneg, range_max, fh.u, fl.u);
             const int o2 = (((qd >> 1) * SX + col) << 1) + (qd & 1);
             dst[o2] = fh.u;
             dst[4 * SX + o2] = fl.u;
@@ -270,15 +265,8 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
 #pragma unroll
                 for (int jm = 0; jm < 4 * MI; ++jm) {
                     const int mi = jm >> 2, j = jm & 3;
-                    union { uint2 u; _Float16 h[4]; } fh, fl;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float v = acc[mi][t][4 * j + i] * i1;
-                        v = v > 0.f ? v : v * slope;
-                        v = qok ? v * 16.f : 0.f;
-                        range_max = __builtin_fmaxf(range_max, __builtin_fabsf(v));
-                        split_f16(v, fh.h[i], fl.h[i]);
-                    }
+                    struct { uint2 u; } fh, fl;
+                    seam4_f16(acc[mi][t][4 * j + 0], acc[mi][t][4 * j + 1], acc[mi][t][4 * j + 2], acc[mi][t][4 * j + 3], i1, slope, qok, range_max, fh.u, fl.u);
                     // channels 32*(MI*wm + mi) + 8*j + 4*hi + i  ->  chunk 2*(MI*wm + mi) + (j >> 1), octet j & 1, half hi
                     const int o4 = (2 * (MI * wm + mi) + (j >> 1)) * XTCH + (j & 1) * XT + HB + col;
                     xt2[(o4 << 1) + hi] = fh.u;
