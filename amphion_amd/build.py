@@ -21,7 +21,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 CONV_TAPS = (1, 2, 3, 5, 7, 11)
 PAIR_TAPS = (3, 5, 7, 11)
-SMALL_TAPS = (1, 3, 5)
+SMALL_TAPS = (1, 3, 5, 7, 11)
 
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC, "-Wall",
          "-Wno-unused-function"]

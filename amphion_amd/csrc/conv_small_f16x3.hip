@@ -28,7 +28,8 @@
 // Tile variants: 128 rows x 32 columns with a 32-column halo (S = 64 staged columns, two workgroups per CU) or
 // 128 x 64 with a 64-column halo (S = 128, one workgroup per CU).
 //
-// Compiled once per tap count: -DAMP_KT=<1|3|5>.
+// Compiled once per tap count: -DAMP_KT=<1|3|5|7|11> (7 and 11: the C = 256 stage of a single utterance, whose 64-column
+// tiles of the pipelined kernel leave three quarters of the chip idle).
 #include "amp_internal.h"
 
 #ifndef AMP_KT
@@ -62,7 +63,7 @@ __device__ __forceinline__ float fast_sigmoid(float v) { return __frcp_rn(1.0f +
 __device__ __forceinline__ float fast_tanh(float v) { return 2.0f * fast_sigmoid(2.0f * v) - 1.0f; }
 
 template <int KT, int NI, int HALO, int EPI>
-__global__ __launch_bounds__(256, (NI == 1 ? 2 : 1)) void conv_small_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, ((NI == 1 && KT <= 5) ? 2 : 1)) void conv_small_kernel(const ConvArgs a) {   // KT >= 7: the A ring alone is 112 / 176 VGPRs
     constexpr int WM = 4;
     constexpr int NT = 32 * NI;                // output columns per workgroup
     constexpr int S = NT + HALO;               // staged columns

@@ -347,11 +347,15 @@ hipError_t launch_conv_f16x3_act(const ConvPlan& p, const ConvArgs& a, hipStream
 hipError_t launch_conv_small_kt1(int, int, const ConvArgs&, hipStream_t);
 hipError_t launch_conv_small_kt3(int, int, const ConvArgs&, hipStream_t);
 hipError_t launch_conv_small_kt5(int, int, const ConvArgs&, hipStream_t);
+hipError_t launch_conv_small_kt7(int, int, const ConvArgs&, hipStream_t);
+hipError_t launch_conv_small_kt11(int, int, const ConvArgs&, hipStream_t);
 hipError_t launch_conv_small(int KT, int ni, int epi, const ConvArgs& a, hipStream_t s) {
     switch (KT) {
         case 1: return launch_conv_small_kt1(ni, epi, a, s);
         case 3: return launch_conv_small_kt3(ni, epi, a, s);
         case 5: return launch_conv_small_kt5(ni, epi, a, s);
+        case 7: return launch_conv_small_kt7(ni, epi, a, s);
+        case 11: return launch_conv_small_kt11(ni, epi, a, s);
     }
     return hipErrorInvalidValue;
 }
@@ -508,11 +512,12 @@ static int conv_out_len(const amp_conv* c, int T) {
     return (T - 1) * c->stride - 2 * c->padding + c->k;
 }
 
-// conv_small_f16x3.hip covers: Conv1d (no polyphase rows), zero padding, 128-row workgroups, k in {1, 3, 5}, Cin <= 256,
-// receptive field <= 64 columns
+// conv_small_f16x3.hip covers: Conv1d (no polyphase rows), zero padding, 128-row workgroups, k in {1, 3, 5, 7, 11},
+// Cin <= 256, receptive field <= 64 columns
 static bool small_conv_static_ok(const amp_conv* c) {
     return c->precision == PREC_F16X3 && !c->transposed && !c->pad_reflect && c->plan.WM == 4 &&
-           (c->KT == 1 || c->KT == 3 || c->KT == 5) && c->nchunks <= kSmallConvMaxChunks && c->halo_left + c->halo_right <= 64;
+           (c->KT == 1 || c->KT == 3 || c->KT == 5 || c->KT == 7 || c->KT == 11) && c->KT == c->ntaps &&
+           c->nchunks <= kSmallConvMaxChunks && c->halo_left + c->halo_right <= 64;
 }
 static bool small_conv_covers(const amp_conv* c) { return small_conv_enabled() && small_conv_static_ok(c); }
 // tile width of the whole-K kernel in 32-column units: 128 x 32 tiles (two workgroups per CU) when the receptive field
@@ -566,7 +571,10 @@ static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope
     } else {
         a.acc_scale = 16.f * c->wscale;
         a.inv_scale = 1.f / a.acc_scale;
-        if (plan.NI == 2 && small_conv_covers(c)) {
+        // k = 7 / 11 (long contractions: the pipelined kernel is efficient per tile) only gain from the whole-K kernel's
+        // narrower tiles while the chip is badly under-filled: one 3-s utterance 1.16 -> 1.06 ms, a 10-s one 2.28 -> 2.30
+        const long long wgs_half = (long long)B * ((a.Tq + 63) / 64) * ((c->M + plan.Mgroup() - 1) / plan.Mgroup());
+        if (plan.NI == 2 && small_conv_covers(c) && (c->KT <= 5 || wgs_half <= 128)) {
             // a small grid of a short contraction: the whole-K kernel (128 x 32 or 128 x 64 tiles, same bits)
             const int ni = small_conv_ni(c);
             a.Mpad = c->Mpad;

@@ -136,6 +136,9 @@ SMALL_CASES = [
     (256, 256, 3, 2, 1, 257),    # 16 chunks, dilation 2, ragged last tile
     (100, 130, 5, 3, 2, 75),     # Cin not a multiple of 16, M not a multiple of 32
     (17, 65, 3, 1, 1, 1),        # T = 1
+    (256, 256, 11, 3, 1, 2048),  # the C = 256 stage of ONE utterance (hifigan.py:93-100 unfused): 128 x 32 tiles
+    (256, 256, 11, 5, 1, 2048),  # dilation 5: 50-column halo -> 128 x 64 tiles
+    (256, 256, 7, 1, 2, 700),
 ]
 
 
