@@ -124,51 +124,3 @@ def test_unsupported_receptive_field_is_an_error():
     w = _rand(8, 8, 11, seed=1)
     with pytest.raises(AmpError):
         conv_forward(w, None, _rand(1, 8, 64), dilation=20, padding=100)
-
-
-# ---- frame-rate convs: the whole-K kernel (csrc/conv_small_f16x3.hip) against the pipelined one -------------
-SMALL_CASES = [
-    # cin, cout, k, dilation, B, T   (grids under 384 workgroups, Cin <= 256, M > 64)
-    (192, 384, 5, 1, 2, 19),     # WN in-layer (VITS)
-    (192, 384, 1, 1, 3, 200),    # WN res_skip
-    (96, 192, 1, 1, 2, 37),      # coupling pre
-    (192, 96, 1, 1, 2, 64),      # coupling post: M not a multiple of 128
-    (256, 256, 3, 2, 1, 257),    # 16 chunks, dilation 2, ragged last tile
-    (100, 130, 5, 3, 2, 75),     # Cin not a multiple of 16, M not a multiple of 32
-    (17, 65, 3, 1, 1, 1),        # T = 1
-    (256, 256, 11, 3, 1, 2048),  # the C = 256 stage of ONE utterance (hifigan.py:93-100 unfused): 128 x 32 tiles
-    (256, 256, 11, 5, 1, 2048),  # dilation 5: 50-column halo -> 128 x 64 tiles
-    (256, 256, 7, 1, 2, 700),
-]
-
-
-@pytest.mark.parametrize("cin,cout,k,d,B,T", SMALL_CASES)
-def test_small_conv_bitwise(cin, cout, k, d, B, T, conv_precision):
-    """Same chunk / tap / (hh, hl, lh) order per output element -> the same bits as conv_f16x3.hip, with and without the
-    fused prologue / epilogue; and within the conv tolerance of the oracle."""
-    from amphion_amd import _lib
-    from hip_helpers import conv_forward
-
-    if conv_precision != "f16x3":
-        pytest.skip("the whole-K kernel exists for the f16x3 arithmetic")
-    w = _rand(cout, cin, k, seed=1, scale=(cin * k) ** -0.5)
-    b = _rand(cout, seed=2, scale=0.1)
-    x = _rand(B, cin, T, seed=3)
-    res = _rand(B, cout, T, seed=4)
-    pad = (k * d - d) // 2
-    L = _lib.lib()
-    outs = {}
-    try:
-        for on in (1, 0):
-            _lib.check(L.amp_set_small_conv(on))
-            outs[on] = (conv_forward(w, b, x, dilation=d, padding=pad),
-                        conv_forward(w, b, x, dilation=d, padding=pad, slope_in=0.1, res=res, slope_out=0.2),
-                        conv_forward(w, None, x, dilation=d, padding=pad))
-    finally:
-        _lib.check(L.amp_set_small_conv(1))
-    for a, c in zip(outs[1], outs[0]):
-        assert torch.equal(a, c)
-    ref = F.conv1d(x, w, b, dilation=d, padding=pad)
-    assert (outs[1][0] - ref).abs().max().item() <= 2e-5
-    ref = F.leaky_relu(F.conv1d(F.leaky_relu(x, 0.1), w, b, dilation=d, padding=pad) + res, 0.2)
-    assert (outs[1][1] - ref).abs().max().item() <= 2e-5
