@@ -53,6 +53,7 @@ class HipConv1d(ConvParams):
             if self.tanh:
                 _lib.check(_lib.lib().amp_conv_set_option(h, _lib.AMP_CONV_OPT_TANH, 1))
         self._h, self._fin, self._sig = h, weakref.finalize(self, _destroy_conv, h.value), sig
+        self._prec = _lib.get_precision()      # a handle keeps the arithmetic it was built with (amphion_hip.h)
         return h
 
     def _ensure_gated(self, device):
@@ -119,8 +120,11 @@ def wn_fused(in_layers, res_skip_layers, x, cond, lens, out, acts):
         g = in_layers[i]._ensure_gated(dev)
         if g is None:
             return False
+        hr_i = rs._ensure(dev)
+        if getattr(rs, "_prec", None) != "f16x3":       # a res_skip handle built while the exact-fp32 mode was selected
+            return False
         hi.append(g.value)
-        hr.append(rs._ensure(dev).value)
+        hr.append(hr_i.value)
     B, _, T = x.shape
     arr_i = (ctypes.c_void_p * n)(*hi)
     arr_r = (ctypes.c_void_p * n)(*hr)
