@@ -83,6 +83,10 @@ __global__ __launch_bounds__(256, ((NI == 1 && KT <= 5) ? 2 : 1)) void conv_smal
     const int item = bx / a.tiles_per_item;
     const int tile = bx - item * a.tiles_per_item;
     const int q0 = tile * NT;
+    // ragged batch: a tile that lies entirely beyond this utterance's valid length produces only samples the contract
+    // leaves unspecified (nothing downstream reads them: every layer takes its input as zero / replicated beyond the valid
+    // length) -- skip it.  A batch of 60..400-frame utterances is 40 % such tiles.
+    if (a.lens && a.Tout == a.Tin && (long long)q0 >= (long long)a.lens[item] * a.len_mul) return;   // block-uniform
     const int mb = blockIdx.y * WM + wave;     // 32-row block of W'
     const bool mb_ok = mb * 32 < a.Mpad;       // a wave past the packed rows only helps staging
     const int nchunks = a.nchunks;

@@ -28,6 +28,7 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict_
     const int pad = (K - 1) / 2;
     int Tv = T;  // valid columns of this item (ragged batch)
     if (lens) { const int l = lens[b] * len_mul; Tv = l < Tv ? l : Tv; }
+    if (t0 >= Tv) return;   // the whole block lies beyond the utterance (block-uniform, before any barrier)
     for (int i = tid; i < Cin * K; i += 256) wl[i] = w[i];
     float acc[4];
     const float b0 = bias ? bias[0] : 0.f;
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(256) void conv_post_stream_kernel(const float* __re
     if (t >= T) return;
     int Tv = T;
     if (lens) { const int l = lens[b] * len_mul; Tv = l < Tv ? l : Tv; }
+    if (t >= Tv) return;                                          // beyond the utterance: unspecified samples (no barrier in this kernel)
     const float* xb = x + (size_t)b * Cin * T;
     const float b0 = bias ? bias[0] : 0.f;
     float acc[4] = {b0, b0, b0, b0};

@@ -179,6 +179,7 @@ def other_configs(reps=5):
         r.update({"algorithmic_bytes": 64 * 65536 * 4 + 64 * 80 * 256 * 4, "frac_of_hbm_peak": r["algorithmic_GBps"] / PEAK_HBM_GBS})
         out["mel_front_end"] = r
         out["latency"] = [x for x in bc.lat(reps) if "hipGraph" not in x["config"]]
+        out["list_api"] = bc.lst(reps)          # synthesis_audios on 64 utterances of 60..400 frames, host to host
         torch.cuda.empty_cache()
     return out
 
