@@ -33,8 +33,9 @@ def synthesis_audios(cfg, model, mels, f0s=None, batch_size=None, fast_inference
     Default (``ragged=False``) = the reference's arithmetic: ``pad_mels_to_tensors`` zero-pads the list, in order,
     into batches of ``batch_size``; the reference then runs every (padded) item through the generator ONE AT A
     TIME and crops to ``frames * hop`` -- here each padded batch is ONE forward, which gives bit-identical audio
-    because items of a batch never interact.  (Note what that arithmetic means: an utterance shorter than its
-    batch carries the zero mel frames behind it through the network, so the last receptive field of its audio
+    because items of a batch never interact; the part of an item's zero padding that lies more than a receptive
+    field behind its last frame cannot reach the samples that are kept and is not computed.  (Note what that
+    arithmetic means: an utterance shorter than its batch carries the zero mel frames behind it through the network, so the last receptive field of its audio
     depends on the batch it was put in.)
 
     ``ragged=True``: utterances are sorted by length and run through ``forward_ragged`` -- every kernel pads at
@@ -71,7 +72,21 @@ def synthesis_audios(cfg, model, mels, f0s=None, batch_size=None, fast_inference
             for i in range(mel_batch.shape[0]):
                 f = torch.as_tensor(f0s[k + i], dtype=torch.float32).reshape(-1).cpu()
                 f0_batch[i, : f.shape[0]] = f[: mel_batch.shape[-1]]
-        out = vocoder_inference(cfg, model, mel_batch, f0s=f0_batch, device=device, fast_inference=fast_inference)
+        if (f0_batch is None and hasattr(model, "receptive_frames") and hasattr(model, "forward_ragged")
+                and not getattr(cfg.preprocess, "extract_amplitude_phase", False)):
+            # same samples, less work: item i only keeps [: frames_i * hop], and those depend on nothing further than a
+            # receptive field beyond frame frames_i -- the zero frames behind that (and everything the generator would
+            # compute from them) are skipped by running the padded batch as a ragged one with lengths frames_i + RF
+            # (tiles beyond an utterance's length exit at once).  Bit-identical to the padded forward on what is kept
+            # (tests/test_gpu_inference_api.py).
+            T = int(mel_batch.shape[-1])
+            rf = model.receptive_frames()
+            ext = [min(T, int(f) + rf) for f in mel_frame]
+            model.eval()
+            with torch.no_grad():
+                out = model.forward_ragged(mel_batch.to(device), ext).squeeze(1).cpu()
+        else:
+            out = vocoder_inference(cfg, model, mel_batch, f0s=f0_batch, device=device, fast_inference=fast_inference)
         for i in range(mel_batch.shape[0]):
             audios[k] = out[i][: int(mel_frame[i]) * hop]
             k += 1

@@ -150,3 +150,41 @@ def test_hipgraph_capture_survives_other_shapes_and_refuses_stale_weights():
     torch.cuda.synchronize()
     with torch.no_grad():
         assert torch.equal(out2, m(mel))
+
+
+@pytest.mark.parametrize("arch", ["hifigan", "bigvgan"])
+def test_list_api_skips_dead_padding_without_changing_a_bit(arch):
+    """synthesis_audios (default, the reference's pad-then-crop arithmetic) runs a padded batch as a ragged one with
+    lengths frames + receptive_frames(): what lies further behind an item's last frame cannot reach the samples that are
+    kept.  The audios equal the crops of the plain padded forward bit for bit -- also with the receptive field cut to
+    the bone (receptive_frames() - 4 would not do: checked as a sanity bound on the margin)."""
+    from amphion_amd.models.vocoders.gan.gan_vocoder_inference import synthesis_audios
+
+    if arch == "hifigan":
+        from amphion_amd.models.vocoders.gan.generator.hifigan import HiFiGAN as Net
+        hp, n_mel = vo.hifigan_v1_hp(), 80
+        sd = synth.synth_state_dict(synth.hifigan_param_shapes(n_mel, hp), 1234)
+        cfg = NS(preprocess=NS(n_mel=n_mel, hop_size=256, extract_amplitude_phase=False), model=NS(hifigan=NS(**hp)))
+    else:
+        from amphion_amd.models.vocoders.gan.generator.bigvgan import BigVGAN as Net
+        hp, n_mel = vo.bigvgan_base_hp(), 100
+        sd = synth.synth_state_dict(synth.bigvgan_param_shapes(n_mel, hp), 1234, g_gain=0.75)
+        cfg = NS(preprocess=NS(n_mel=n_mel, hop_size=256, extract_amplitude_phase=False), model=NS(bigvgan=NS(**hp)))
+    m = Net(cfg)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    Ts = [150, 31, 90, 7, 150, 64, 1, 120]
+    mels = [synth.synth_mel(1, n_mel, T, seed=40 + i)[0] for i, T in enumerate(Ts)]
+    auds = synthesis_audios(cfg, m, mels, batch_size=8)
+    batch = torch.zeros(8, n_mel, 150)
+    for i, mel in enumerate(mels):
+        batch[i, :, : Ts[i]] = mel
+    with torch.no_grad():
+        full = m(batch.cuda()).squeeze(1).cpu()
+        rf = m.receptive_frames()
+        assert 12 <= rf <= 40
+        for i, T in enumerate(Ts):
+            assert torch.equal(auds[i], full[i, : T * 256]), (arch, i, T)
+        # the margin is not generous by accident: with 4 frames the kept samples DO change
+        short = m.forward_ragged(batch.cuda(), [min(150, T + 4) for T in Ts]).squeeze(1).cpu()
+        assert any(not torch.equal(short[i, : T * 256], full[i, : T * 256]) for i, T in enumerate(Ts) if T + 4 < 150)
