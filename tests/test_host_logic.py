@@ -100,6 +100,31 @@ def test_fused_wn_entry_points_validate_without_device():
     assert L.amp_set_small_conv(1) == 0
 
 
+def test_c_abi_from_plain_c(tmp_path):
+    """include/amphion_hip.h compiles as C99 and a plain-C program links against the library and exercises the
+    no-GPU paths (tests/c/abi_smoke.c) -- the boundary is a C ABI, not a Python extension."""
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    exe = tmp_path / "abi_smoke"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-o", str(exe), "-L", libdir, "-lamphion_hip",
+                    "-Wl,-rpath," + libdir], check=True)
+    env = dict(os.environ)
+    try:
+        import torch
+        env["LD_LIBRARY_PATH"] = os.path.join(os.path.dirname(torch.__file__), "lib") + ":" + env.get("LD_LIBRARY_PATH", "")
+    except Exception:
+        pass
+    r = subprocess.run([str(exe)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "abi ok" in r.stdout
+
+
 def test_mel_num_frames():
     L = _lib.lib()
     d = _lib.amp_mel_desc(1024, 1024, 256, 80, 0, 1e-9, 1e-5)
