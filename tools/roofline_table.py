@@ -1,0 +1,68 @@
+#!/usr/bin/env python
+"""Per-kernel roofline table of the config-2 forward (HiFi-GAN V1, B = 64 x 80 x 256) from the committed profile set:
+profiles/<name>_kernel_stats.csv (rocprofv3 --kernel-trace --stats over bench.py) and <name>_hbm_traffic.csv (--pmc
+FETCH_SIZE / WRITE_SIZE passes).  Algorithmic FLOPs per launch come from the kernel's template arguments and the layer
+shapes of SURVEY.md Appendix B; peaks from MI355X_MICROARCH.md (f16 MFMA 2516.6 TFLOP/s / 3 MFMAs per term, HBM 8 TB/s).
+
+    python tools/roofline_table.py [profiles/r2] > profiles/r2_roofline_table.txt
+"""
+import csv
+import re
+import sys
+
+B, PEAK_TF, PEAK_GBS = 64, 2516.6 / 3.0, 8000.0
+STAGE = {256: 2048, 128: 16384, 64: 32768, 32: 65536}          # channels -> samples per item at that stage
+TENSOR_MB = lambda C: B * C * STAGE[C] * 4 / 1e6
+
+
+def shape(name):
+    """-> (label, algorithmic GFLOP per launch, algorithmic MB per launch (read x + write y)) or None"""
+    m = re.search(r"pair_(?:strip|f16x3)_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?>", name)
+    if m:
+        k, wm, wn = int(m.group(1)), int(m.group(2)), int(m.group(3))
+        mi = int(m.group(6) or 1) if "strip" in name else 1
+        C = 32 * wm * mi
+        if "strip" in name and wm == 8:
+            C = 256
+        return f"fused pair C={C} k={k}", 2 * 2.0 * C * C * k * STAGE[C] * B / 1e9, 2 * TENSOR_MB(C)
+    m = re.search(r"conv_f16x3_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)", name)
+    if m:
+        k, wm = int(m.group(1)), int(m.group(2))
+        if k == 2:
+            return None                                              # transposed convs: several shapes share the template
+        if wm == 4 and k in (3, 7, 11):
+            C = 256                                                  # the unfused C = 256 stage (+ conv_pre in the k = 7 line)
+            note = " (+ conv_pre's launches in the average)" if k == 7 else ""
+            return f"conv C={C} k={k} (stage 0){note}", 2.0 * C * C * k * STAGE[C] * B / 1e9, 3 * TENSOR_MB(C)
+    if "conv_post_stream" in name:
+        return "conv_post C=32 -> 1, k=7 + tanh", 2.0 * 32 * 7 * 65536 * B / 1e9, TENSOR_MB(32) + B * 65536 * 4 / 1e6
+    return None
+
+
+def main():
+    base = sys.argv[1] if len(sys.argv) > 1 else "profiles/r2"
+    stats = {r["Name"]: r for r in csv.DictReader(open(base + "_kernel_stats.csv"))}
+    traffic = {}
+    for r in csv.DictReader(l for l in open(base + "_hbm_traffic.csv") if not l.startswith("#") and l.strip()):
+        traffic[r["kernel"]] = float(r["total_MB_corrected"])
+    print(f"# per-kernel roofline, config 2 (HiFi-GAN V1, B = 64 x 80 x 256), from {base}_kernel_stats.csv / _hbm_traffic.csv")
+    print("# peak: f16x3 MFMA %.1f TFLOP/s (2516.6 / 3), HBM %.0f GB/s; 'alg MB' = read x + write y (+ residual for unfused convs)" % (PEAK_TF, PEAK_GBS))
+    print("%-52s %6s %9s %9s %8s %6s %9s %9s %8s %6s" % ("kernel", "calls", "avg us", "GFLOP", "TFLOP/s", "frac", "alg MB", "PMC MB", "GB/s", "frac"))
+    tot_us = 0.0
+    for name, r in stats.items():
+        sh = shape(name)
+        us = float(r["AverageNs"]) / 1e3
+        if sh is None:
+            continue
+        label, gflop, mb = sh
+        pmc = traffic.get(name)
+        tf = gflop / (us * 1e-6) / 1e3
+        gbs = (pmc if pmc else mb) / 1e3 / (us * 1e-6)
+        print("%-52s %6s %9.1f %9.1f %8.1f %6.3f %9.0f %9s %8.0f %6.3f" % (label, r["Calls"], us, gflop, tf, tf / PEAK_TF, mb,
+                                                                           ("%.0f" % pmc) if pmc else "-", gbs, gbs / PEAK_GBS))
+        tot_us += us * int(r["Calls"])
+    print("# the launches listed cover %.1f ms of kernel time in the profiled run" % (tot_us / 1e3))
+
+
+if __name__ == "__main__":
+    main()
