@@ -814,7 +814,7 @@ static int act_params_upload(const float* alpha_dev, const float* beta_dev, int 
 
 extern "C" {
 
-int amp_version(void) { return 100; }
+int amp_version(void) { return 120; }   // 100: round 1; 120: + amp_conv_create_gated / amp_wn_forward / amp_conv_act_forward, switches
 const char* amp_last_error(void) { return g_err; }
 
 int amp_set_precision(int precision) {

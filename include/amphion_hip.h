@@ -83,7 +83,7 @@ typedef struct amp_gen_desc {
 
 typedef struct amp_gen amp_gen;
 
-/* Library / device probes. */
+/* Library / device probes.  amp_version: 100 = round 1's surface; 120 adds the fused-WN and conv + activation entry points. */
 int amp_version(void);
 const char* amp_last_error(void);
 /* Number of HIP devices visible (0 when there is no GPU); never fails. */
