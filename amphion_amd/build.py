@@ -22,6 +22,7 @@ ARCH = "gfx950"
 CONV_TAPS = (1, 2, 3, 5, 7, 11)
 PAIR_TAPS = (3, 5, 7, 11)
 SMALL_TAPS = (1, 3, 5, 7, 11)
+BLK_TAPS = (2, 3)
 
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC, "-Wall",
          "-Wno-unused-function"]
@@ -33,6 +34,8 @@ def _units():
     for kt in CONV_TAPS:
         units.append(("conv_mfma.hip", f"conv_mfma_kt{kt}.o", [f"-DAMP_KT={kt}"]))
         units.append(("conv_f16x3.hip", f"conv_f16x3_kt{kt}.o", [f"-DAMP_KT={kt}"]))
+    for kt in BLK_TAPS:
+        units.append(("conv_blk_f16x3.hip", f"conv_blk_f16x3_kt{kt}.o", [f"-DAMP_KT={kt}"]))
     for kt in SMALL_TAPS:
         units.append(("conv_small_f16x3.hip", f"conv_small_f16x3_kt{kt}.o", [f"-DAMP_KT={kt}"]))
     for kt in PAIR_TAPS:

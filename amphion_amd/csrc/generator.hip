@@ -372,6 +372,27 @@ static bool small_conv_enabled() {
     return g_small_conv != 0;
 }
 
+// Row-blocked conv kernel (conv_blk_f16x3.hip: 64 rows per wave, 256 per workgroup) for the short tap loops -- the
+// transposed convs (2 taps per chunk) and k = 3 convs -- whose GEMM rows are a multiple of 256; same bits as
+// conv_f16x3.hip.  AMP_CONV_BLK / amp_set_conv_blk: 0 off, 1 one 16-channel chunk per staging round, 2 two chunks per
+// round where the kernel has that variant (transposed convs).
+int conv_blk_nt_kt2(int, int);
+int conv_blk_nt_kt3(int, int);
+hipError_t launch_conv_blk_kt2(int, const ConvArgs&, hipStream_t);
+hipError_t launch_conv_blk_kt3(int, const ConvArgs&, hipStream_t);
+constexpr int kConvBlkDefault = 2;
+static int g_conv_blk = -1;
+static int conv_blk_mode() {
+    if (g_conv_blk < 0) {
+        const char* e = getenv("AMP_CONV_BLK");
+        g_conv_blk = e ? atoi(e) : kConvBlkDefault;
+        if (g_conv_blk < 0 || g_conv_blk > 2) g_conv_blk = kConvBlkDefault;
+    }
+    return g_conv_blk;
+}
+// the blocked launch fills the chip only when its (half as many) workgroups still give every CU its two
+constexpr long long kConvBlkMinWorkgroups = 512;
+
 hipError_t launch_conv_f16x3(const ConvPlan& p, const ConvArgs& a, hipStream_t s) {
     switch (p.KT) {
         case 1: return launch_conv_h_kt1(p, a, s);
@@ -483,7 +504,7 @@ static int conv_build(amp_conv* c, const float* w, const float* bias) {
         int e2 = 0;
         if (wmax > 0.f) { (void)frexpf(wmax, &e2); if (ldexpf(1.f, e2 - 1) == wmax) e2 -= 1; }  // wmax <= 2^e2
         c->wscale = wmax > 0.f ? ldexpf(1.f, 13 - e2) : 1.f;
-        const size_t n16 = ((size_t)nmb * c->nchunks + 1) * c->KT * 2 * 64 * 8;  // +1 chunk: the kernel's A reload runs one chunk ahead
+        const size_t n16 = ((size_t)nmb * c->nchunks + 2) * c->KT * 2 * 64 * 8;  // + pad: the kernels' A reload runs one chunk (conv_blk_f16x3.hip: one round of up to 2 chunks) ahead
         std::vector<_Float16> wp(n16, (_Float16)0.f);
         for (int mb = 0; mb < nmb; ++mb)
             for (int ch = 0; ch < c->nchunks; ++ch)
@@ -574,7 +595,18 @@ static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope
         // k = 7 / 11 (long contractions: the pipelined kernel is efficient per tile) only gain from the whole-K kernel's
         // narrower tiles while the chip is badly under-filled: one 3-s utterance 1.16 -> 1.06 ms, a 10-s one 2.28 -> 2.30
         const long long wgs_half = (long long)B * ((a.Tq + 63) / 64) * ((c->M + plan.Mgroup() - 1) / plan.Mgroup());
-        if (plan.NI == 2 && small_conv_covers(c) && (c->KT <= 5 || wgs_half <= 128)) {
+        int blk_cm = 0, blk_nt = 0;
+        if (conv_blk_mode() > 0 && plan.NI == 4 && plan.WM == 4 && (c->KT == 2 || c->KT == 3) && c->M % 256 == 0 && !c->tanh_out) {
+            int cm = (conv_blk_mode() == 2 && c->KT == 2 && c->nchunks % 2 == 0) ? 2 : 1;
+            const int halo = c->halo_left + c->halo_right;
+            const int nt = c->KT == 2 ? conv_blk_nt_kt2(cm, halo) : conv_blk_nt_kt3(cm, halo);
+            if (nt > 0 && (long long)B * ((a.Tq + nt - 1) / nt) * (c->M / 256) >= kConvBlkMinWorkgroups) { blk_cm = cm; blk_nt = nt; }
+        }
+        if (blk_cm > 0) {
+            a.tiles_per_item = (a.Tq + blk_nt - 1) / blk_nt;
+            a.wd = blk_nt + c->halo_left + c->halo_right;
+            AMP_HIP(c->KT == 2 ? launch_conv_blk_kt2(blk_cm, a, stream) : launch_conv_blk_kt3(blk_cm, a, stream));
+        } else if (plan.NI == 2 && small_conv_covers(c) && (c->KT <= 5 || wgs_half <= 128)) {
             // a small grid of a short contraction: the whole-K kernel (128 x 32 or 128 x 64 tiles, same bits)
             const int ni = small_conv_ni(c);
             a.Mpad = c->Mpad;
@@ -814,7 +846,7 @@ static int act_params_upload(const float* alpha_dev, const float* beta_dev, int 
 
 extern "C" {
 
-int amp_version(void) { return 120; }   // 100: round 1; 120: + amp_conv_create_gated / amp_wn_forward / amp_conv_act_forward, switches
+int amp_version(void) { return 121; }   // 100: round 1; 120: + amp_conv_create_gated / amp_wn_forward / amp_conv_act_forward, switches; 121: + amp_set_conv_blk
 const char* amp_last_error(void) { return g_err; }
 
 int amp_set_precision(int precision) {
@@ -1413,6 +1445,12 @@ int amp_conv_create(int transposed, int cin, int cout, int k, int stride, int di
 
 int amp_set_small_conv(int on) {
     g_small_conv = on ? 1 : 0;
+    return AMP_OK;
+}
+
+int amp_set_conv_blk(int mode) {
+    if (mode < 0 || mode > 2) { set_error("amp_set_conv_blk: mode %d (0 off, 1 | 2 chunks per staging round)", mode); return AMP_ERR_INVALID; }
+    g_conv_blk = mode;
     return AMP_OK;
 }
 

@@ -83,7 +83,7 @@ typedef struct amp_gen_desc {
 
 typedef struct amp_gen amp_gen;
 
-/* Library / device probes.  amp_version: 100 = round 1's surface; 120 adds the fused-WN and conv + activation entry points. */
+/* Library / device probes.  amp_version: 100 = round 1's surface; 120 adds the fused-WN and conv + activation entry points, 121 amp_set_conv_blk. */
 int amp_version(void);
 const char* amp_last_error(void);
 /* Number of HIP devices visible (0 when there is no GPU); never fails. */
@@ -290,6 +290,12 @@ void amp_conv_destroy(amp_conv* c);
  * whole K extent of its input tile at once (csrc/conv_small_f16x3.hip; same bits as the pipelined kernel).  0 keeps
  * them on the pipelined kernel -- an A/B and cross-check switch, also AMP_SMALL_CONV=0 in the environment. */
 int amp_set_small_conv(int on);
+
+/* Transposed convs and k = 3 convs whose GEMM rows are a multiple of 256 (ConvTranspose1d: Cout * stride) run, on grids
+ * of 512+ workgroups, on the row-blocked kernel (csrc/conv_blk_f16x3.hip: 64 rows per wave, x staged once per 256 rows;
+ * same bits as the pipelined kernel).  mode 0 keeps them on the pipelined kernel, 1 = one 16-channel chunk per staging
+ * round, 2 = two where available (default) -- an A/B and cross-check switch, also AMP_CONV_BLK in the environment. */
+int amp_set_conv_blk(int mode);
 
 /* ---- WN (modules/flow/modules.py:74-151), fused: two launches per layer ---- */
 

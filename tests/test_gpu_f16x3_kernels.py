@@ -1,6 +1,7 @@
 """GPU parity of the kernels that exist for the f16x3 arithmetic only (run once, under f16x3): the whole-K frame-rate conv
 kernel (csrc/conv_small_f16x3.hip) against the pipelined one bit for bit, and conv + Activation1d in one launch
-(csrc/conv_f16x3.hip, ACT variant) against the two launches bit for bit."""
+(csrc/conv_f16x3.hip, ACT variant) against the two launches bit for bit, and the row-blocked kernel of the transposed /
+k = 3 convs (csrc/conv_blk_f16x3.hip) against the pipelined one bit for bit."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -67,6 +68,63 @@ def test_small_conv_bitwise(cin, cout, k, d, B, T):
     assert (outs[1][0] - ref).abs().max().item() <= 2e-5
     ref = F.leaky_relu(F.conv1d(F.leaky_relu(x, 0.1), w, b, dilation=d, padding=pad) + res, 0.2)
     assert (outs[1][1] - ref).abs().max().item() <= 2e-5
+
+
+# ---- transposed convs / k = 3 convs with M % 256 == 0 on 512+ workgroups: the row-blocked kernel ------------------------
+BLK_CASES = [
+    # transposed, cin, cout, k, stride, dilation, B, T
+    (True, 64, 32, 16, 8, 1, 24, 2100),    # M = 256, 4 chunks (two per round in mode 2), float4 polyphase stores
+    (True, 48, 64, 16, 8, 1, 24, 1000),    # M = 512: two row groups; 3 chunks (odd: one per round in either mode)
+    (True, 32, 64, 8, 4, 1, 24, 2101),     # stride 4
+    (True, 32, 128, 4, 2, 1, 24, 2100),    # stride 2: the 8-byte store path (hifigan.py's last two up-sampling layers)
+    (True, 40, 256, 6, 3, 1, 16, 1000),    # odd stride: generic scatter; Cin not a multiple of 16
+    (True, 32, 32, 15, 8, 1, 24, 2100),    # k < 2 * stride: the second tap of the last phase is zero
+    (True, 32, 32, 24, 8, 1, 24, 2690),    # k = 3 * stride: three taps -> the KT = 3 kernel with dstep = -1
+    (False, 256, 256, 3, 1, 1, 8, 8200),   # the C = 256 stage's k = 3 convs (hifigan.py:93-100), ragged last tile
+    (False, 256, 256, 3, 1, 5, 8, 8200),
+    (False, 100, 256, 3, 1, 3, 8, 8321),   # Cin not a multiple of 16
+    (False, 64, 512, 3, 1, 1, 4, 8200),    # two row groups
+]
+
+
+@pytest.mark.parametrize("tr,cin,cout,k,s,d,B,T", BLK_CASES)
+def test_blocked_conv_bitwise(tr, cin, cout, k, s, d, B, T):
+    """Same accumulator start, chunk / tap / (hh, hl, lh) order and epilogue per output element -> the same bits as
+    conv_f16x3.hip in every mode (0 pipelined, 1 one chunk per staging round, 2 two); within the conv tolerance of
+    torch's fp32 conv."""
+    from amphion_amd import _lib
+    from hip_helpers import conv_forward
+
+    w = _rand(*((cin, cout, k) if tr else (cout, cin, k)), seed=1, scale=(cin * k / s) ** -0.5)
+    b = _rand(cout, seed=2, scale=0.1)
+    x = _rand(B, cin, T, seed=3)
+    pad = (k - s) // 2 if tr else (k * d - d) // 2
+    kw = dict(transposed=tr, stride=s, dilation=d, padding=pad)
+    res = None if tr else _rand(B, cout, T, seed=4)
+    L = _lib.lib()
+    outs = {}
+    try:
+        for mode in (0, 1, 2):
+            _lib.check(L.amp_set_conv_blk(mode))
+            outs[mode] = [conv_forward(w, b, x, **kw), conv_forward(w, None, x, slope_in=0.1, slope_out=0.2, **kw)]
+            if res is not None:
+                outs[mode].append(conv_forward(w, b, x, slope_in=0.1, res=res, **kw))
+    finally:
+        _lib.check(L.amp_set_conv_blk(2))
+    for mode in (1, 2):
+        for a, c in zip(outs[mode], outs[0]):
+            assert torch.isfinite(a).all()
+            assert torch.equal(a, c), f"mode {mode} differs from the pipelined kernel"
+    ref = F.conv_transpose1d(x, w, b, stride=s, padding=pad) if tr else F.conv1d(x, w, b, dilation=d, padding=pad)
+    err = (outs[2][0] - ref).abs().max().item()
+    assert err <= 2e-5, err
+
+
+def test_blocked_conv_switch_rejects_bad_mode():
+    from amphion_amd import _lib
+
+    assert _lib.lib().amp_set_conv_blk(7) != 0
+    assert _lib.lib().amp_set_conv_blk(2) == 0
 
 
 # ---- a2(c1(.)) of an AMPBlock in one launch (csrc/conv_f16x3.hip, ACT variant) ----------------------------------

@@ -13,7 +13,7 @@ import torch
 from amphion_amd import _lib
 
 
-def run(prec, reps, B, Tmel):
+def run(prec, reps, B, Tmel, only=""):
     _lib.set_precision(prec)
     L = _lib.lib()
     st = _lib.current_stream_ptr(torch.device("cuda", 0))
@@ -26,6 +26,8 @@ def run(prec, reps, B, Tmel):
                 cases.append(("conv", C, C, k, d, 1, Tmel * tm, d == 1))
     for cin, cout, k, u, tm in ((512, 256, 16, 8, 1), (256, 128, 16, 8, 8), (128, 64, 4, 2, 64), (64, 32, 4, 2, 128)):
         cases.append(("convT", cin, cout, k, 1, u, Tmel * tm, False))
+    if only == "blk":   # the launches conv_blk_f16x3.hip covers: transposed convs, k = 3 at C = 256
+        cases = [c for c in cases if c[0] == "convT" or (c[1] == 256 and c[3] == 3)]
     for kind, cin, cout, k, d, u, T, with_res in cases:
         g = torch.Generator().manual_seed(1)
         tr = kind == "convT"
@@ -64,10 +66,11 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--frames", type=int, default=256)
+    ap.add_argument("--only", default="", choices=["", "blk"])
     a = ap.parse_args()
     print("prec,kind,cin,cout,k,dil,stride,T_in,res,ms,TFLOP/s,GB/s(min-traffic)")
     for p in a.precision:
-        for r in run(p, a.reps, a.batch, a.frames):
+        for r in run(p, a.reps, a.batch, a.frames, a.only):
             print(",".join(str(v) if not isinstance(v, float) else f"{v:.3f}" for v in r))
 
 
