@@ -1449,7 +1449,7 @@ int amp_set_small_conv(int on) {
 }
 
 int amp_set_conv_blk(int mode) {
-    if (mode < 0 || mode > 2) { set_error("amp_set_conv_blk: mode %d (0 off, 1 | 2 chunks per staging round)", mode); return AMP_ERR_INVALID; }
+    if (mode < -1 || mode > 2) { set_error("amp_set_conv_blk: mode %d (0 off, 1 | 2 chunks per staging round, -1 default)", mode); return AMP_ERR_INVALID; }
     g_conv_blk = mode;
     return AMP_OK;
 }

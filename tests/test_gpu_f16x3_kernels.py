@@ -110,7 +110,7 @@ def test_blocked_conv_bitwise(tr, cin, cout, k, s, d, B, T):
             if res is not None:
                 outs[mode].append(conv_forward(w, b, x, slope_in=0.1, res=res, **kw))
     finally:
-        _lib.check(L.amp_set_conv_blk(2))
+        _lib.check(L.amp_set_conv_blk(-1))
     for mode in (1, 2):
         for a, c in zip(outs[mode], outs[0]):
             assert torch.isfinite(a).all()
@@ -124,7 +124,7 @@ def test_blocked_conv_switch_rejects_bad_mode():
     from amphion_amd import _lib
 
     assert _lib.lib().amp_set_conv_blk(7) != 0
-    assert _lib.lib().amp_set_conv_blk(2) == 0
+    assert _lib.lib().amp_set_conv_blk(-1) == 0
 
 
 # ---- a2(c1(.)) of an AMPBlock in one launch (csrc/conv_f16x3.hip, ACT variant) ----------------------------------
