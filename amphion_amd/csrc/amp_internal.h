@@ -33,6 +33,9 @@ struct ConvArgs {
     int M;               // GEMM rows = Cout * up
     int Tq;              // GEMM columns per batch item
     int tiles_per_item;  // ceil(Tq / NT)
+    int row_groups;      // > 0: 1-D grid of B * tiles_per_item * row_groups workgroups with the row group as the FASTEST index
+                         //      (the row groups of one x tile run back to back on one XCD: x is fetched into ONE L2 once
+                         //      instead of once per row group from HBM); 0: 2-D grid, row group = blockIdx.y
     int off0, dstep;     // tap offsets
     int halo_left;       // max(0, -min_j off_j)
     int wd;              // staged columns actually needed: NT + halo_left + halo_right

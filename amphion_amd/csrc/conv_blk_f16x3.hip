@@ -48,7 +48,9 @@ __global__ __launch_bounds__(256, 2) void conv_blk_kernel(const ConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, l31 = lane & 31;
     const int nbx = gridDim.x;   // XCD-contiguous tile runs, see conv_f16x3.hip
-    const int bx = ((nbx & 7) == 0 && !a.lens) ? (int)(blockIdx.x & 7) * (nbx >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    int bx = ((nbx & 7) == 0 && !a.lens) ? (int)(blockIdx.x & 7) * (nbx >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    int rg = blockIdx.y;         // 256-row group
+    if (a.row_groups > 0) { rg = bx % a.row_groups; bx /= a.row_groups; }   // row group fastest, see ConvArgs
     const int item = bx / a.tiles_per_item;
     const int tile = bx - item * a.tiles_per_item;
     const int q0 = tile * NT;
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256, 2) void conv_blk_kernel(const ConvArgs a) {
         const long long first_out = (long long)q0 * a.up - a.up_pad;
         if ((a.up > 1 || a.Tout == a.Tin) && first_out >= lv * a.up) return;
     }
-    const int mb0 = (blockIdx.y * 4 + wave) * MI;   // first 32-row block of this wave (host: M % 256 == 0)
+    const int mb0 = (rg * 4 + wave) * MI;   // first 32-row block of this wave (host: M % 256 == 0)
 
     const int up = a.up;
     const int qw = q0 + l31;
@@ -358,6 +360,7 @@ static hipError_t launch_blk_one(const ConvArgs& a, hipStream_t stream) {
         attr_set |= 1ull << dev;
     }
     dim3 grid((unsigned)(a.B * a.tiles_per_item), (unsigned)(a.M / 256));
+    if (a.row_groups > 0) grid = dim3((unsigned)(a.B * a.tiles_per_item * a.row_groups), 1u);
     hipLaunchKernelGGL((conv_blk_kernel<KT, NI, HALO, CM>), grid, dim3(256), lds, stream, a);
     return hipGetLastError();
 }

@@ -73,7 +73,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
     const int nbx = gridDim.x;
     // (ragged batches keep the dispatch order: with utterances of different lengths a contiguous run per XCD would hand
     // one XCD the long utterances and another only tiles that exit at once -- measured 43.8 vs 48.7 ms padded, visit AD)
-    const int bx = ((nbx & 7) == 0 && !a.lens) ? (int)(blockIdx.x & 7) * (nbx >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    int bx = ((nbx & 7) == 0 && !a.lens) ? (int)(blockIdx.x & 7) * (nbx >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    int rg = blockIdx.y;         // group of 32 * WM rows
+    if (!ACT && a.row_groups > 0) { rg = bx % a.row_groups; bx /= a.row_groups; }   // row group fastest, see ConvArgs
     const int item = bx / a.tiles_per_item;
     const int tile = bx - item * a.tiles_per_item;
     const int q0 = ACT ? tile * AT - 8 : tile * NT;
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
         const long long first_out = (long long)q0 * a.up - a.up_pad;                    // first output sample of the tile
         if ((a.up > 1 || a.Tout == a.Tin) && first_out >= lv * a.up) return;            // block-uniform, before any barrier
     }
-    const int mb = blockIdx.y * WM + wm;       // 32-row block of W'
+    const int mb = rg * WM + wm;               // 32-row block of W'
 
     // accumulators start from (bias + residual + running MRF sum) * acc_scale, see conv_mfma.hip
     const int up = a.up;
@@ -526,6 +528,7 @@ static hipError_t launch_one_h(const ConvArgs& a, hipStream_t stream) {
         attr_set |= 1ull << dev;
     }
     dim3 grid((unsigned)(a.B * a.tiles_per_item), (unsigned)((a.M + 32 * WM - 1) / (32 * WM)));
+    if (a.row_groups > 0) grid = dim3((unsigned)(a.B * a.tiles_per_item * a.row_groups), 1u);   // conv_run: row_groups == grid.y
     hipLaunchKernelGGL((conv_f16x3_kernel<KT, WM, WN, NI, HALO>), grid, dim3(256), lds, stream, a);
     return hipGetLastError();
 }

@@ -390,6 +390,19 @@ static int conv_blk_mode() {
     }
     return g_conv_blk;
 }
+// Convs with more than one row group (M > 32 * WM rows: the C = 256 stage, the transposed convs' polyphase rows) launch a
+// 1-D grid with the row group as the fastest index, so that the row groups of one x tile run back to back on one XCD and x
+// comes from HBM once (ConvArgs::row_groups).  AMP_CONV_RG_FAST=0 / amp_set_conv_rg_fast(0): the 2-D grid (row group =
+// blockIdx.y, dispatched a whole grid.x apart).
+constexpr int kConvRgFastDefault = 1;
+static int g_conv_rg_fast = -1;
+static bool conv_rg_fast() {
+    if (g_conv_rg_fast < 0) {
+        const char* e = getenv("AMP_CONV_RG_FAST");
+        g_conv_rg_fast = e ? (atoi(e) != 0) : kConvRgFastDefault;
+    }
+    return g_conv_rg_fast != 0;
+}
 // the blocked launch fills the chip only when its (half as many) workgroups still give every CU its two
 constexpr long long kConvBlkMinWorkgroups = 512;
 
@@ -605,6 +618,7 @@ static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope
         if (blk_cm > 0) {
             a.tiles_per_item = (a.Tq + blk_nt - 1) / blk_nt;
             a.wd = blk_nt + c->halo_left + c->halo_right;
+            a.row_groups = (conv_rg_fast() && c->M / 256 > 1) ? c->M / 256 : 0;
             AMP_HIP(c->KT == 2 ? launch_conv_blk_kt2(blk_cm, a, stream) : launch_conv_blk_kt3(blk_cm, a, stream));
         } else if (plan.NI == 2 && small_conv_covers(c) && (c->KT <= 5 || wgs_half <= 128)) {
             // a small grid of a short contraction: the whole-K kernel (128 x 32 or 128 x 64 tiles, same bits)
@@ -614,6 +628,8 @@ static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope
             a.wd = 32 * ni + c->halo_left + c->halo_right;
             AMP_HIP(launch_conv_small(c->KT, ni, 0, a, stream));
         } else {
+            const int nrg = (c->M + plan.Mgroup() - 1) / plan.Mgroup();
+            a.row_groups = (conv_rg_fast() && nrg > 1) ? nrg : 0;
             AMP_HIP(launch_conv_f16x3(plan, a, stream));
         }
     }
@@ -1445,6 +1461,11 @@ int amp_conv_create(int transposed, int cin, int cout, int k, int stride, int di
 
 int amp_set_small_conv(int on) {
     g_small_conv = on ? 1 : 0;
+    return AMP_OK;
+}
+
+int amp_set_conv_rg_fast(int on) {
+    g_conv_rg_fast = on < 0 ? -1 : (on ? 1 : 0);   // -1: back to AMP_CONV_RG_FAST / the default
     return AMP_OK;
 }
 

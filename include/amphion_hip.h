@@ -297,6 +297,11 @@ int amp_set_small_conv(int on);
  * round, 2 = two where available (default), -1 = back to AMP_CONV_BLK / the default -- an A/B and cross-check switch. */
 int amp_set_conv_blk(int mode);
 
+/* Convs with several row groups (more GEMM rows than one workgroup holds) launch with the row group as the fastest grid
+ * index: the row groups of one x tile run back to back on one XCD and share its L2 copy of x (same bits; 1 = default).
+ * 0 = the 2-D grid with the row group in blockIdx.y, -1 = back to AMP_CONV_RG_FAST / the default -- an A/B switch. */
+int amp_set_conv_rg_fast(int on);
+
 /* ---- WN (modules/flow/modules.py:74-151), fused: two launches per layer ---- */
 
 /* WN.in_layers[i] = Conv1d(H, 2H, k, dilation, padding) (modules.py:106-114) built for the gate epilogue: the kernel

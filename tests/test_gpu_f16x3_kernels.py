@@ -120,6 +120,42 @@ def test_blocked_conv_bitwise(tr, cin, cout, k, s, d, B, T):
     assert err <= 2e-5, err
 
 
+RG_CASES = [
+    # transposed, cin, cout, k, stride, dilation, B, T   (several row groups per x tile)
+    (True, 64, 64, 16, 8, 1, 24, 1000),     # blocked kernel, 2 row groups of 256
+    (True, 32, 48, 16, 8, 1, 3, 700),       # pipelined kernel, M = 384: 3 row groups of 128
+    (False, 256, 256, 7, 1, 3, 8, 4100),    # the C = 256 stage (hifigan.py:93-100): 2 row groups of 128, ragged last tile
+    (False, 64, 200, 11, 1, 1, 2, 777),     # M = 200: the last row group is partial
+    (False, 192, 384, 5, 1, 1, 2, 64),      # small grid: half-width tiles / whole-K kernel
+]
+
+
+@pytest.mark.parametrize("tr,cin,cout,k,s,d,B,T", RG_CASES)
+def test_row_group_order_is_bitwise_neutral(tr, cin, cout, k, s, d, B, T):
+    """Row group as the fastest grid index (one XCD's L2 serves x to all row groups of a tile) vs the 2-D grid."""
+    from amphion_amd import _lib
+    from hip_helpers import conv_forward
+
+    w = _rand(*((cin, cout, k) if tr else (cout, cin, k)), seed=1, scale=(cin * k / s) ** -0.5)
+    b = _rand(cout, seed=2, scale=0.1)
+    x = _rand(B, cin, T, seed=3)
+    pad = (k - s) // 2 if tr else (k * d - d) // 2
+    kw = dict(transposed=tr, stride=s, dilation=d, padding=pad)
+    L = _lib.lib()
+    outs = {}
+    try:
+        for on in (0, 1):
+            _lib.check(L.amp_set_conv_rg_fast(on))
+            outs[on] = conv_forward(w, b, x, slope_in=0.1, **kw)
+    finally:
+        _lib.check(L.amp_set_conv_rg_fast(-1))
+    assert torch.isfinite(outs[1]).all()
+    assert torch.equal(outs[0], outs[1])
+    ref = (F.conv_transpose1d(F.leaky_relu(x, 0.1), w, b, stride=s, padding=pad) if tr
+           else F.conv1d(F.leaky_relu(x, 0.1), w, b, dilation=d, padding=pad))
+    assert (outs[1] - ref).abs().max().item() <= 2e-5
+
+
 def test_blocked_conv_switch_rejects_bad_mode():
     from amphion_amd import _lib
 

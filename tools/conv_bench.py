@@ -28,6 +28,8 @@ def run(prec, reps, B, Tmel, only=""):
         cases.append(("convT", cin, cout, k, 1, u, Tmel * tm, False))
     if only == "blk":   # the launches conv_blk_f16x3.hip covers: transposed convs, k = 3 at C = 256
         cases = [c for c in cases if c[0] == "convT" or (c[1] == 256 and c[3] == 3)]
+    if only == "rg":    # launches with several row groups per x tile: the C = 256 stage, the stride-8 transposed convs
+        cases = [c for c in cases if (c[0] == "convT" and c[6] == 8) or (c[0] == "conv" and c[1] == 256)]
     for kind, cin, cout, k, d, u, T, with_res in cases:
         g = torch.Generator().manual_seed(1)
         tr = kind == "convT"
@@ -66,7 +68,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--frames", type=int, default=256)
-    ap.add_argument("--only", default="", choices=["", "blk"])
+    ap.add_argument("--only", default="", choices=["", "blk", "rg"])
     a = ap.parse_args()
     print("prec,kind,cin,cout,k,dil,stride,T_in,res,ms,TFLOP/s,GB/s(min-traffic)")
     for p in a.precision:

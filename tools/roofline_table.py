@@ -34,6 +34,17 @@ def shape(name):
             C = 256                                                  # the unfused C = 256 stage (+ conv_pre in the k = 7 line)
             note = " (+ conv_pre's launches in the average)" if k == 7 else ""
             return f"conv C={C} k={k} (stage 0){note}", 2.0 * C * C * k * STAGE[C] * B / 1e9, 3 * TENSOR_MB(C)
+    m = re.search(r"conv_blk_kernel<(\d+), ", name)
+    if m:   # row-blocked kernel (conv_blk_f16x3.hip)
+        k = int(m.group(1))
+        if k == 3:
+            C = 256
+            return "conv C=256 k=3 (stage 0, row-blocked)", 2.0 * C * C * k * STAGE[C] * B / 1e9, 3 * TENSOR_MB(C)
+        # the two stride-8 transposed convs share the template: 512 -> 256 (T 256 -> 2048) and 256 -> 128 (2048 -> 16384);
+        # FLOPs and bytes of the average launch
+        gf = (2.0 * 512 * 256 * 16 * 256 * B + 2.0 * 256 * 128 * 16 * 2048 * B) / 2 / 1e9
+        mb = (B * 512 * 256 * 4 / 1e6 + TENSOR_MB(256) + TENSOR_MB(256) + TENSOR_MB(128)) / 2
+        return "ConvT k=16 s=8, 512->256 / 256->128 (avg launch, row-blocked)", gf, mb
     if "conv_post_stream" in name:
         return "conv_post C=32 -> 1, k=7 + tanh", 2.0 * 32 * 7 * 65536 * B / 1e9, TENSOR_MB(32) + B * 65536 * 4 / 1e6
     return None
@@ -47,7 +58,7 @@ def main():
         traffic[r["kernel"]] = float(r["total_MB_corrected"])
     print(f"# per-kernel roofline, config 2 (HiFi-GAN V1, B = 64 x 80 x 256), from {base}_kernel_stats.csv / _hbm_traffic.csv")
     print("# peak: f16x3 MFMA %.1f TFLOP/s (2516.6 / 3), HBM %.0f GB/s; 'alg MB' = read x + write y (+ residual for unfused convs)" % (PEAK_TF, PEAK_GBS))
-    print("%-52s %6s %9s %9s %8s %6s %9s %9s %8s %6s" % ("kernel", "calls", "avg us", "GFLOP", "TFLOP/s", "frac", "alg MB", "PMC MB", "GB/s", "frac"))
+    print("%-64s %6s %9s %9s %8s %6s %9s %9s %8s %6s" % ("kernel", "calls", "avg us", "GFLOP", "TFLOP/s", "frac", "alg MB", "PMC MB", "GB/s", "frac"))
     tot_us = 0.0
     for name, r in stats.items():
         sh = shape(name)
@@ -58,7 +69,7 @@ def main():
         pmc = traffic.get(name)
         tf = gflop / (us * 1e-6) / 1e3
         gbs = (pmc if pmc else mb) / 1e3 / (us * 1e-6)
-        print("%-52s %6s %9.1f %9.1f %8.1f %6.3f %9.0f %9s %8.0f %6.3f" % (label, r["Calls"], us, gflop, tf, tf / PEAK_TF, mb,
+        print("%-64s %6s %9.1f %9.1f %8.1f %6.3f %9.0f %9s %8.0f %6.3f" % (label, r["Calls"], us, gflop, tf, tf / PEAK_TF, mb,
                                                                            ("%.0f" % pmc) if pmc else "-", gbs, gbs / PEAK_GBS))
         tot_us += us * int(r["Calls"])
     print("# the launches listed cover %.1f ms of kernel time in the profiled run" % (tot_us / 1e3))
