@@ -394,6 +394,12 @@ static int conv_blk_mode() {
 // 1-D grid with the row group as the fastest index, so that the row groups of one x tile run back to back on one XCD and x
 // comes from HBM once (ConvArgs::row_groups).  AMP_CONV_RG_FAST=0 / amp_set_conv_rg_fast(0): the 2-D grid (row group =
 // blockIdx.y, dispatched a whole grid.x apart).
+// Only while the packed weights of ALL row groups fit one XCD's 4-MB L2 beside the activations (<= 3 MB): the workgroups
+// resident on an XCD then stream every row group's A fragments at once.  Measured (profiles/r2_ak_row_group_order.txt,
+// FETCH_SIZE per launch): ConvT 256 -> 128 (2.1 MB of weights) 627 -> 459 MB, C = 256 k = 11 / 7 (2.9 / 1.8 MB) 422 -> 369 /
+// 386 -> 293 MB, but ConvT 512 -> 256 (8.4 MB) 269 -> 417 MB; launch times unchanged either way (these kernels are not
+// HBM-bound: the bytes are energy, not time).
+constexpr size_t kConvRgFastMaxWeightBytes = 3u << 20;
 constexpr int kConvRgFastDefault = 1;
 static int g_conv_rg_fast = -1;
 static bool conv_rg_fast() {
@@ -541,6 +547,9 @@ static int conv_build(amp_conv* c, const float* w, const float* bias) {
     return AMP_OK;
 }
 
+// bytes of the packed f16x3 A fragments of all row blocks (hi + lo planes)
+static size_t conv_weight_bytes(const amp_conv* c) { return (size_t)c->Mpad * c->nchunks * KC16 * c->KT * 4; }
+
 static int conv_out_len(const amp_conv* c, int T) {
     if (!c->transposed) return T + 2 * c->padding - c->dilation * (c->k - 1);
     return (T - 1) * c->stride - 2 * c->padding + c->k;
@@ -618,7 +627,7 @@ static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope
         if (blk_cm > 0) {
             a.tiles_per_item = (a.Tq + blk_nt - 1) / blk_nt;
             a.wd = blk_nt + c->halo_left + c->halo_right;
-            a.row_groups = (conv_rg_fast() && c->M / 256 > 1) ? c->M / 256 : 0;
+            a.row_groups = (conv_rg_fast() && c->M / 256 > 1 && conv_weight_bytes(c) <= kConvRgFastMaxWeightBytes) ? c->M / 256 : 0;
             AMP_HIP(c->KT == 2 ? launch_conv_blk_kt2(blk_cm, a, stream) : launch_conv_blk_kt3(blk_cm, a, stream));
         } else if (plan.NI == 2 && small_conv_covers(c) && (c->KT <= 5 || wgs_half <= 128)) {
             // a small grid of a short contraction: the whole-K kernel (128 x 32 or 128 x 64 tiles, same bits)
@@ -629,7 +638,7 @@ static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope
             AMP_HIP(launch_conv_small(c->KT, ni, 0, a, stream));
         } else {
             const int nrg = (c->M + plan.Mgroup() - 1) / plan.Mgroup();
-            a.row_groups = (conv_rg_fast() && nrg > 1) ? nrg : 0;
+            a.row_groups = (conv_rg_fast() && nrg > 1 && conv_weight_bytes(c) <= kConvRgFastMaxWeightBytes) ? nrg : 0;
             AMP_HIP(launch_conv_f16x3(plan, a, stream));
         }
     }

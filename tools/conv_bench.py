@@ -29,7 +29,7 @@ def run(prec, reps, B, Tmel, only=""):
     if only == "blk":   # the launches conv_blk_f16x3.hip covers: transposed convs, k = 3 at C = 256
         cases = [c for c in cases if c[0] == "convT" or (c[1] == 256 and c[3] == 3)]
     if only == "rg":    # launches with several row groups per x tile: the C = 256 stage, the stride-8 transposed convs
-        cases = [c for c in cases if (c[0] == "convT" and c[6] == 8) or (c[0] == "conv" and c[1] == 256)]
+        cases = [c for c in cases if (c[0] == "convT" and c[5] == 8) or (c[0] == "conv" and c[1] == 256)]
     for kind, cin, cout, k, d, u, T, with_res in cases:
         g = torch.Generator().manual_seed(1)
         tr = kind == "convT"
