@@ -18,6 +18,12 @@ OBJ = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "lib", "libamphion_hip.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# experiment builds (same-box A/B through AMP_LIB_PATH, see _lib.py): AMP_BUILD_TAG=<tag> AMP_BUILD_FLAGS="-DX ..." write
+# lib/libamphion_hip_<tag>.so from objects under csrc/_build_<tag>/
+TAG = os.environ.get("AMP_BUILD_TAG", "")
+if TAG:
+    OBJ = os.path.join(CSRC, "_build_" + TAG)
+    LIB = os.path.join(HERE, "lib", "libamphion_hip_" + TAG + ".so")
 ARCH = "gfx950"
 CONV_TAPS = (1, 2, 3, 5, 7, 11)
 PAIR_TAPS = (3, 5, 7, 11)
@@ -25,7 +31,7 @@ SMALL_TAPS = (1, 3, 5, 7, 11)
 BLK_TAPS = (2, 3)
 
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC, "-Wall",
-         "-Wno-unused-function"]
+         "-Wno-unused-function"] + os.environ.get("AMP_BUILD_FLAGS", "").split()
 
 
 def _units():

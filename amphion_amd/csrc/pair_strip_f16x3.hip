@@ -98,9 +98,16 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
     // Step-local, opaque copies of T and the row bases (set at the top of every step): with the plain values hipcc
     // hoists every row offset r * T and the 48 residual / output addresses out of the step loop and holds them
     // across both convs (all 106 SGPRs + 256 VGPRs + spills); re-deriving them per step costs a few SALU ops.
+    // The laundered pointers are cast back to the GLOBAL address space: through a generic pointer of unknown origin hipcc
+    // emits flat_load / flat_store (1 056 + 480 in this file), which also count in lgkmcnt and return out of order with
+    // LDS -- the next step's first ds_read then waits for every epilogue store of this one.
+    typedef const float __attribute__((address_space(1)))* gcf_ptr;
+    typedef float __attribute__((address_space(1)))* gf_ptr;
     int Ts = T;
-    const float* xres_s = xres;
-    float* yr_s = yr;
+    const float* xres_l = xres;
+    float* yr_l = yr;
+    gcf_ptr xres_s = (gcf_ptr)xres;
+    gf_ptr yr_s = (gf_ptr)yr;
     float range_max = 0.f;       // largest |staged operand| (x16 applied): beyond 65504 it left the f16 range (a.range_flag)
     float xs[NST][4];
     auto stage_load = [&](int chunk, int tbase) {
@@ -166,8 +173,9 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
         const float* bias1 = a.bias1;
         const float* bias2 = a.bias2;
         asm volatile("" : "+s"(bias1), "+s"(bias2));
-        Ts = T; xres_s = xres; yr_s = yr;
-        asm volatile("" : "+s"(Ts), "+v"(xres_s), "+v"(yr_s));
+        Ts = T; xres_l = xres; yr_l = yr;
+        asm volatile("" : "+s"(Ts), "+v"(xres_l), "+v"(yr_l));
+        xres_s = (gcf_ptr)xres_l; yr_s = (gf_ptr)yr_l;
         const int tbase = X - h1;             // global column of staged column 0
         // output columns of this step: q = X - H2 + col
         int qc[NI];
