@@ -113,6 +113,7 @@ _SIGNATURES = {
     "amp_set_small_conv": (c_int, [c_int]),
     "amp_set_conv_blk": (c_int, [c_int]),
     "amp_set_conv_rg_fast": (c_int, [c_int]),
+    "amp_set_pingpong": (c_int, [c_int]),
     "amp_set_fuse_act": (c_int, [c_int]),
     "amp_conv_act_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "amp_conv_create_gated": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, POINTER(c_void_p)]),

@@ -33,6 +33,9 @@ struct ConvArgs {
     int M;               // GEMM rows = Cout * up
     int Tq;              // GEMM columns per batch item
     int tiles_per_item;  // ceil(Tq / NT)
+    int rev;             // 1: walk the tiles in descending order.  Successive launches alternate (conv_run / pair_run): a launch's
+                         //    input is mostly the previous launch's output, whose LAST-written part is what the 256-MB Infinity
+                         //    Cache still holds when the next launch starts
     int row_groups;      // > 0: 1-D grid of B * tiles_per_item * row_groups workgroups with the row group as the FASTEST index
                          //      (the row groups of one x tile run back to back on one XCD: x is fetched into ONE L2 once
                          //      instead of once per row group from HBM); 0: 2-D grid, row group = blockIdx.y
@@ -81,6 +84,7 @@ struct PairArgs {
     int strip_len;             // strip kernel (pair_strip_f16x3.hip): output columns per workgroup ...
     int strips_per_item;       // ... and workgroups per batch item, ceil(T / strip_len)
     int wide;                  // strip kernel: 1 = the 8-wave, double-width variant (one workgroup per CU)
+    int rev;                   // 1: descending tile / strip order, see ConvArgs::rev
     int stagger;               // experiment: start delay of de-phased workgroups, in s_sleep(127) units (0 = none)
     int stagger_mode;          // 1: second-slot workgroups (blockIdx >> 8 odd) wait `stagger`; 2: (blockIdx >> 3) & 7 eighths of it
     int dil;

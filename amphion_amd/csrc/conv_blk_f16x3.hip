@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256, 2) void conv_blk_kernel(const ConvArgs a) {
     const int hi = lane >> 5, l31 = lane & 31;
     const int nbx = gridDim.x;   // XCD-contiguous tile runs, see conv_f16x3.hip
     int bx = ((nbx & 7) == 0 && !a.lens) ? (int)(blockIdx.x & 7) * (nbx >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (a.rev) bx = nbx - 1 - bx;   // descending tile order: start where the previous launch stopped writing (ConvArgs::rev)
     int rg = blockIdx.y;         // 256-row group
     if (a.row_groups > 0) { rg = bx % a.row_groups; bx /= a.row_groups; }   // row group fastest, see ConvArgs
     const int item = bx / a.tiles_per_item;

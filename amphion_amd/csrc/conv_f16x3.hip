@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
     // (ragged batches keep the dispatch order: with utterances of different lengths a contiguous run per XCD would hand
     // one XCD the long utterances and another only tiles that exit at once -- measured 43.8 vs 48.7 ms padded, visit AD)
     int bx = ((nbx & 7) == 0 && !a.lens) ? (int)(blockIdx.x & 7) * (nbx >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (a.rev) bx = nbx - 1 - bx;   // descending tile order: start where the previous launch stopped writing (ConvArgs::rev)
     int rg = blockIdx.y;         // group of 32 * WM rows
     if (!ACT && a.row_groups > 0) { rg = bx % a.row_groups; bx /= a.row_groups; }   // row group fastest, see ConvArgs
     const int item = bx / a.tiles_per_item;

@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairArgs a) {
     const int nbx = gridDim.x;  // XCD-contiguous tile runs, see conv_f16x3.hip
     // (ragged batches keep the dispatch order: with utterances of different lengths a contiguous run per XCD would hand
     // one XCD the long utterances and another only tiles that exit at once -- measured 43.8 vs 48.7 ms padded, visit AD)
-    const int bx = ((nbx & 7) == 0 && !a.lens) ? (int)(blockIdx.x & 7) * (nbx >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    int bx = ((nbx & 7) == 0 && !a.lens) ? (int)(blockIdx.x & 7) * (nbx >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (a.rev) bx = nbx - 1 - bx;   // descending tile order: start where the previous launch stopped writing (PairArgs::rev)
     const int item = bx / a.tiles_per_item;
     const int tile = bx - item * a.tiles_per_item;
     const int q0 = tile * NT;                 // first output column

@@ -69,7 +69,8 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
     const int nbx = gridDim.x;  // XCD-contiguous runs of strips, see conv_f16x3.hip
     // (ragged batches keep the dispatch order: with utterances of different lengths a contiguous run per XCD would hand
     // one XCD the long utterances and another only tiles that exit at once -- measured 43.8 vs 48.7 ms padded, visit AD)
-    const int bx = ((nbx & 7) == 0 && !a.lens) ? (int)(blockIdx.x & 7) * (nbx >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    int bx = ((nbx & 7) == 0 && !a.lens) ? (int)(blockIdx.x & 7) * (nbx >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (a.rev) bx = nbx - 1 - bx;   // descending tile order: start where the previous launch stopped writing (PairArgs::rev)
     const int item = bx / a.strips_per_item;
     const int strip = bx - item * a.strips_per_item;
     constexpr int C = 32 * WM * MI;

@@ -302,6 +302,10 @@ int amp_set_conv_blk(int mode);
  * 0 = the 2-D grid with the row group in blockIdx.y, -1 = back to AMP_CONV_RG_FAST / the default -- an A/B switch. */
 int amp_set_conv_rg_fast(int on);
 
+/* Ping-pong tile order: every other conv / fused-pair launch walks its tiles in descending order, starting on the part of its
+ * input that the previous launch wrote last (same bits).  -1 = back to AMP_PINGPONG / the default -- an A/B switch. */
+int amp_set_pingpong(int on);
+
 /* ---- WN (modules/flow/modules.py:74-151), fused: two launches per layer ---- */
 
 /* WN.in_layers[i] = Conv1d(H, 2H, k, dilation, padding) (modules.py:106-114) built for the gate epilogue: the kernel

@@ -41,6 +41,31 @@ def test_config2_hifigan_v1_full_size():
     assert err <= TOL
 
 
+def test_config2_tile_order_is_bitwise_neutral():
+    """Ping-pong tile order (every other conv / pair launch walks its tiles backwards, amp_set_pingpong) changes no bit of the
+    waveform: tiles are independent (no atomics, x and y never alias across tiles)."""
+    from amphion_amd import _lib
+    from amphion_amd.models.vocoders.gan.generator.hifigan import HiFiGAN
+
+    hp = vo.hifigan_v1_hp()
+    m = HiFiGAN(NS(preprocess=NS(n_mel=80, hop_size=256), model=NS(hifigan=NS(**hp))))
+    m.load_state_dict(synth.synth_state_dict(synth.hifigan_param_shapes(80, hp), 1234))
+    m = m.cuda().eval()
+    mel = synth.synth_mel(24, 80, 256, seed=5).cuda()
+    L = _lib.lib()
+    outs = {}
+    try:
+        with torch.no_grad():
+            for on in (0, 1):
+                _lib.check(L.amp_set_pingpong(on))
+                outs[on] = m(mel).clone()
+                outs[(on, "again")] = m(mel).clone()      # the launch parity differs between successive forwards
+    finally:
+        _lib.check(L.amp_set_pingpong(-1))
+    assert torch.isfinite(outs[1]).all()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[(1, "again")]) and torch.equal(outs[0], outs[(0, "again")])
+
+
 def test_config3_bigvgan_base_full_size():
     from amphion_amd.models.vocoders.gan.generator.bigvgan import BigVGAN
 
