@@ -131,7 +131,7 @@ hipError_t launch_conv_post(const float* x, const float* w_dev /*[Cin*K]*/, cons
 // Activation1d (anti-aliased Snake); a_dev = alpha (already exp'ed if logscale), invb_dev = 1/(beta+1e-9)
 hipError_t launch_act1d(const float* x, float* y, int B, int C, int T, const float* a_dev, const float* invb_dev,
                         const float* filt_up12, const float* filt_dn12, const int* lens, int len_mul,
-                        hipStream_t stream);
+                        hipStream_t stream, int rev = 0 /* 1: descending workgroup order, ConvArgs::rev */);
 
 // y[b,c,t] += cond[b,c]   (HiFiGAN_vits `x + self.cond(g)` with g of length 1)
 hipError_t launch_add_channel_bias(float* y, const float* cb, int B, int C, int T, hipStream_t stream);

@@ -1355,7 +1355,7 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
                         // xt = c2(a2(c1(a1(x)))) ; x = xt + x              bigvgan.py:137-146
                         const ActParams& a1 = rb.acts[2 * p];
                         const ActParams& a2 = rb.acts[2 * p + 1];
-                        AMP_HIP(launch_act1d(cur, ACT_, B, C, t, a1.a_dev, a1.invb_dev, a1.fu_dev, a1.fd_dev, lens, lm, sj));
+                        AMP_HIP(launch_act1d(cur, ACT_, B, C, t, a1.a_dev, a1.invb_dev, a1.fu_dev, a1.fd_dev, lens, lm, sj, next_rev(lens)));
                         if (cur == TMP_) {  // a previous pair was fused into TMP_: keep the unfused ping-pong legal
                             AMP_HIP(hipMemcpyAsync(R_, TMP_, (size_t)B * C * t * sizeof(float), hipMemcpyDeviceToDevice, sj));
                             cur = R_;
@@ -1367,7 +1367,7 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
                             c2_in = TMP_;
                         } else {
                             AMP_RC(conv_run(rb.c1[p].get(), ACT_, B, t, 1.f, nullptr, 1.f, TMP_, 0, 1.f, sj, 0, lens, lm));
-                            AMP_HIP(launch_act1d(TMP_, ACT_, B, C, t, a2.a_dev, a2.invb_dev, a2.fu_dev, a2.fd_dev, lens, lm, sj));
+                            AMP_HIP(launch_act1d(TMP_, ACT_, B, C, t, a2.a_dev, a2.invb_dev, a2.fu_dev, a2.fd_dev, lens, lm, sj, next_rev(lens)));
                         }
                         if (!last) { AMP_RC(conv_run(rb.c2[p].get(), c2_in, B, t, 1.f, cur, 1.f, R_, 0, 1.f, sj, 0, lens, lm)); cur = R_; }
                         else AMP_RC(conv_run(rb.c2[p].get(), c2_in, B, t, 1.f, cur, 1.f, XS, mode_last, (float)nk, sj, 0, lens, lm));
@@ -1378,7 +1378,7 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
                     float sl = slope;
                     if (big) {
                         const ActParams& a1 = rb.acts[p];
-                        AMP_HIP(launch_act1d(cur, ACT_, B, C, t, a1.a_dev, a1.invb_dev, a1.fu_dev, a1.fd_dev, lens, lm, sj));
+                        AMP_HIP(launch_act1d(cur, ACT_, B, C, t, a1.a_dev, a1.invb_dev, a1.fu_dev, a1.fd_dev, lens, lm, sj, next_rev(lens)));
                         in = ACT_;
                         sl = 1.f;
                     }
@@ -1400,7 +1400,7 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
         float* tmp = X; X = XS; XS = tmp;  // x = xs / num_kernels
     }
     if (big) {
-        AMP_HIP(launch_act1d(X, ACT, B, g->post_cin, t, g->act_post.a_dev, g->act_post.invb_dev, g->act_post.fu_dev, g->act_post.fd_dev, lens, lm, st));
+        AMP_HIP(launch_act1d(X, ACT, B, g->post_cin, t, g->act_post.a_dev, g->act_post.invb_dev, g->act_post.fu_dev, g->act_post.fd_dev, lens, lm, st, next_rev(lens)));
         AMP_HIP(launch_conv_post(ACT, g->post_w_dev, g->post_b_dev, wav_dev, B, g->post_cin, t, 7, 1.f, 1, lens, lm, st));
     } else {
         // F.leaky_relu(x) with the DEFAULT slope 0.01 (hifigan.py:215,439), conv_post, tanh

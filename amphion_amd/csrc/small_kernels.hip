@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void act1d_kernel(const float* __restrict__ x,
                                                     const float* __restrict__ a_dev,
                                                     const float* __restrict__ invb_dev, const float* __restrict__ fu,
                                                     const float* __restrict__ fd, const int* __restrict__ lens,
-                                                    int len_mul) {
+                                                    int len_mul, int rev) {
     // staged window xl[i] = x[clamp(t0 - 8 + i)], i < A1_TT + 16 (starts 8 before the tile: 16-B aligned rows)
     __shared__ __attribute__((aligned(16))) float xl[A1_TT + 16];
     __shared__ __attribute__((aligned(16))) float sl[2 * A1_TT + 16];   // swizzled (sl_pos): whole float4 pairs
@@ -187,9 +187,11 @@ __global__ __launch_bounds__(256) void act1d_kernel(const float* __restrict__ x,
     const int tid = threadIdx.x;
     const int ntiles = (T + A1_TT - 1) / A1_TT;   // T = row stride (padded length)
     const int ngroups = (ntiles + NTILE - 1) / NTILE;
-    const int bc = blockIdx.x / ngroups;
+    // rev: descending workgroup order (this launch starts on what the previous one wrote last, ConvArgs::rev)
+    const int blk = rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const int bc = blk / ngroups;
     const int c = bc % C;
-    const int tile_first = (blockIdx.x - bc * ngroups) * NTILE;
+    const int tile_first = (blk - bc * ngroups) * NTILE;
     // Tv = the utterance's own length: the replicate padding (resample.py:36-45, filter.py:92-99) clamps to
     // ITS last sample, so a padded batch equals the per-utterance results
     int Tv = T;
@@ -364,18 +366,18 @@ __global__ __launch_bounds__(256) void act1d_kernel(const float* __restrict__ x,
 
 template <int NTILE>
 static hipError_t launch_act1d_n(const float* x, float* y, int B, int C, int T, const float* a_dev, const float* invb_dev,
-                                 const float* fu, const float* fd, const int* lens, int len_mul, hipStream_t stream) {
+                                 const float* fu, const float* fd, const int* lens, int len_mul, hipStream_t stream, int rev) {
     const int ntiles = (T + A1_TT - 1) / A1_TT;
     const int ngroups = (ntiles + NTILE - 1) / NTILE;
     dim3 grid((unsigned)((size_t)ngroups * (size_t)(B * C)));
     hipLaunchKernelGGL(act1d_kernel<NTILE>, grid, dim3(256), 0, stream, x, y, C, T, a_dev, invb_dev, fu, fd, lens,
-                       len_mul);
+                       len_mul, rev);
     return hipGetLastError();
 }
 
 hipError_t launch_act1d(const float* x, float* y, int B, int C, int T, const float* a_dev, const float* invb_dev,
                         const float* filt_up12, const float* filt_dn12, const int* lens, int len_mul,
-                        hipStream_t stream) {
+                        hipStream_t stream, int rev) {
     // tiles per workgroup.  Measured on C3 (profiles/r2_uv_act1d.txt): 2 tiles (straight-line, both windows requested at
     // entry) 141 us per launch on average, rolled strips of 8 / 16 / 32 tiles 125.5 / 122.6 / 125.8 us: long-lived
     // workgroups stop paying their start-up 32 768 times per launch.  Strips need a grid that still fills the chip
@@ -386,12 +388,12 @@ hipError_t launch_act1d(const float* x, float* y, int B, int C, int T, const flo
         const long long total = (long long)B * C * ((T + A1_TT - 1) / A1_TT);
         ntile = total >= 16 * 4096 ? 16 : (total >= 8 * 4096 ? 8 : 2);
     }
-    if (ntile == 1) return launch_act1d_n<1>(x, y, B, C, T, a_dev, invb_dev, filt_up12, filt_dn12, lens, len_mul, stream);
-    if (ntile == 4) return launch_act1d_n<4>(x, y, B, C, T, a_dev, invb_dev, filt_up12, filt_dn12, lens, len_mul, stream);
-    if (ntile == 8) return launch_act1d_n<8>(x, y, B, C, T, a_dev, invb_dev, filt_up12, filt_dn12, lens, len_mul, stream);
-    if (ntile == 16) return launch_act1d_n<16>(x, y, B, C, T, a_dev, invb_dev, filt_up12, filt_dn12, lens, len_mul, stream);
-    if (ntile == 32) return launch_act1d_n<32>(x, y, B, C, T, a_dev, invb_dev, filt_up12, filt_dn12, lens, len_mul, stream);
-    return launch_act1d_n<2>(x, y, B, C, T, a_dev, invb_dev, filt_up12, filt_dn12, lens, len_mul, stream);
+    if (ntile == 1) return launch_act1d_n<1>(x, y, B, C, T, a_dev, invb_dev, filt_up12, filt_dn12, lens, len_mul, stream, rev);
+    if (ntile == 4) return launch_act1d_n<4>(x, y, B, C, T, a_dev, invb_dev, filt_up12, filt_dn12, lens, len_mul, stream, rev);
+    if (ntile == 8) return launch_act1d_n<8>(x, y, B, C, T, a_dev, invb_dev, filt_up12, filt_dn12, lens, len_mul, stream, rev);
+    if (ntile == 16) return launch_act1d_n<16>(x, y, B, C, T, a_dev, invb_dev, filt_up12, filt_dn12, lens, len_mul, stream, rev);
+    if (ntile == 32) return launch_act1d_n<32>(x, y, B, C, T, a_dev, invb_dev, filt_up12, filt_dn12, lens, len_mul, stream, rev);
+    return launch_act1d_n<2>(x, y, B, C, T, a_dev, invb_dev, filt_up12, filt_dn12, lens, len_mul, stream, rev);
 }
 
 // ---------------------------------------------------------------------------------------------

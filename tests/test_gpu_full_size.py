@@ -41,17 +41,27 @@ def test_config2_hifigan_v1_full_size():
     assert err <= TOL
 
 
-def test_config2_tile_order_is_bitwise_neutral():
-    """Ping-pong tile order (every other conv / pair launch walks its tiles backwards, amp_set_pingpong) changes no bit of the
-    waveform: tiles are independent (no atomics, x and y never alias across tiles)."""
+@pytest.mark.parametrize("arch", ["hifigan", "bigvgan"])
+def test_tile_order_is_bitwise_neutral(arch):
+    """Ping-pong tile order (every other conv / pair / activation launch walks its tiles backwards, amp_set_pingpong) changes
+    no bit of the waveform: tiles are independent (no atomics, x and y never alias across tiles)."""
     from amphion_amd import _lib
-    from amphion_amd.models.vocoders.gan.generator.hifigan import HiFiGAN
 
-    hp = vo.hifigan_v1_hp()
-    m = HiFiGAN(NS(preprocess=NS(n_mel=80, hop_size=256), model=NS(hifigan=NS(**hp))))
-    m.load_state_dict(synth.synth_state_dict(synth.hifigan_param_shapes(80, hp), 1234))
+    if arch == "hifigan":
+        from amphion_amd.models.vocoders.gan.generator.hifigan import HiFiGAN
+
+        hp = vo.hifigan_v1_hp()
+        m = HiFiGAN(NS(preprocess=NS(n_mel=80, hop_size=256), model=NS(hifigan=NS(**hp))))
+        m.load_state_dict(synth.synth_state_dict(synth.hifigan_param_shapes(80, hp), 1234))
+        mel = synth.synth_mel(24, 80, 256, seed=5).cuda()
+    else:
+        from amphion_amd.models.vocoders.gan.generator.bigvgan import BigVGAN
+
+        hp = vo.bigvgan_base_hp()
+        m = BigVGAN(NS(preprocess=NS(n_mel=100, hop_size=256), model=NS(bigvgan=NS(**hp))))
+        m.load_state_dict(synth.synth_state_dict(synth.bigvgan_param_shapes(100, hp), 1234, g_gain=0.75))
+        mel = synth.synth_mel(12, 100, 200, seed=6).cuda()
     m = m.cuda().eval()
-    mel = synth.synth_mel(24, 80, 256, seed=5).cuda()
     L = _lib.lib()
     outs = {}
     try:
