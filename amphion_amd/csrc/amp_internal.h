@@ -192,14 +192,26 @@ __device__ __forceinline__ void split_f16(float v, _Float16& h, _Float16& l) {
 typedef float amp_f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 amp_f16x2 __attribute__((ext_vector_type(2)));
 
+// lo = f16(v - hi) is ONE v_fma_mixlo_f16 / v_fma_mixhi_f16 per element (fp32 v, constant 1.0, the f16 half of hi negated: the
+// difference is exact in fp32, so the single rounding of the mix form is the rounding of the conversion): 3 VALU instructions
+// per operand pair instead of 5 (v_cvt_pk_f16_f32, 2 x v_cvt_f32_f16, v_pk_add_f32, v_cvt_pk_f16_f32).  hipcc does not select
+// the mix form for a subtraction (it vectorises it); tests/experiments/split_mix.hip compares both forms on the hardware over
+// 2^25 operand pairs covering every sign / exponent / upper-mantissa pattern.
 __device__ __forceinline__ void split4_f16(amp_f32x2 v01, amp_f32x2 v23, uint2& h, uint2& l) {
     asm("" : "+v"(v01));      // opaque, as in split_f16: no folding of the producing multiply into ONE of the conversions
     asm("" : "+v"(v23));
     const amp_f16x2 h01 = __builtin_convertvector(v01, amp_f16x2), h23 = __builtin_convertvector(v23, amp_f16x2);
+    h.x = __builtin_bit_cast(unsigned, h01); h.y = __builtin_bit_cast(unsigned, h23);
+#ifndef AMP_SPLIT_PACKED
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(l.x) : "v"(v01.x), "v"(h.x));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l.x) : "v"(v01.y), "v"(h.x));
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(l.y) : "v"(v23.x), "v"(h.y));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l.y) : "v"(v23.y), "v"(h.y));
+#else
     const amp_f32x2 d01 = v01 - __builtin_convertvector(h01, amp_f32x2), d23 = v23 - __builtin_convertvector(h23, amp_f32x2);
     const amp_f16x2 l01 = __builtin_convertvector(d01, amp_f16x2), l23 = __builtin_convertvector(d23, amp_f16x2);
-    h.x = __builtin_bit_cast(unsigned, h01); h.y = __builtin_bit_cast(unsigned, h23);
     l.x = __builtin_bit_cast(unsigned, l01); l.y = __builtin_bit_cast(unsigned, l23);
+#endif
 }
 
 // leaky-ReLU-on-load + x16 of four staged values (x already zeroed where the conv pads) -> hi / lo planes; keeps the
