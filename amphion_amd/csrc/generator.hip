@@ -888,7 +888,7 @@ static int act_params_upload(const float* alpha_dev, const float* beta_dev, int 
 
 extern "C" {
 
-int amp_version(void) { return 121; }   // 100: round 1; 120: + amp_conv_create_gated / amp_wn_forward / amp_conv_act_forward, switches; 121: + amp_set_conv_blk
+int amp_version(void) { return 122; }   // 100: round 1; 120: + amp_conv_create_gated / amp_wn_forward / amp_conv_act_forward, switches; 122: + amp_set_conv_blk / _conv_rg_fast / _pingpong
 const char* amp_last_error(void) { return g_err; }
 
 int amp_set_precision(int precision) {

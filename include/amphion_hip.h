@@ -83,7 +83,7 @@ typedef struct amp_gen_desc {
 
 typedef struct amp_gen amp_gen;
 
-/* Library / device probes.  amp_version: 100 = round 1's surface; 120 adds the fused-WN and conv + activation entry points, 121 amp_set_conv_blk. */
+/* Library / device probes.  amp_version: 100 = round 1's surface; 120 adds the fused-WN and conv + activation entry points, 122 amp_set_conv_blk / amp_set_conv_rg_fast / amp_set_pingpong. */
 int amp_version(void);
 const char* amp_last_error(void);
 /* Number of HIP devices visible (0 when there is no GPU); never fails. */

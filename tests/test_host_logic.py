@@ -100,6 +100,21 @@ def test_fused_wn_entry_points_validate_without_device():
     assert L.amp_set_small_conv(1) == 0
 
 
+def test_kernel_policy_switches_validate_without_device():
+    """The A/B switches of round 2's third session are plain host state: callable without a GPU, -1 restores the default,
+    out-of-range modes are refused with a message."""
+    L = _lib.lib()
+    assert L.amp_version() >= 122
+    for mode in (0, 1, 2, -1):
+        assert L.amp_set_conv_blk(mode) == 0
+    with pytest.raises(_lib.AmpError) as ei:
+        _lib.check(L.amp_set_conv_blk(3))
+    assert "amp_set_conv_blk" in str(ei.value)
+    for on in (0, 1, -1):
+        assert L.amp_set_conv_rg_fast(on) == 0
+        assert L.amp_set_pingpong(on) == 0
+
+
 def test_c_abi_from_plain_c(tmp_path):
     """include/amphion_hip.h compiles as C99 and a plain-C program links against the library and exercises the
     no-GPU paths (tests/c/abi_smoke.c) -- the boundary is a C ABI, not a Python extension."""
