@@ -28,7 +28,7 @@ ARCH = "gfx950"
 CONV_TAPS = (1, 2, 3, 5, 7, 11)
 PAIR_TAPS = (3, 5, 7, 11)
 SMALL_TAPS = (1, 3, 5, 7, 11)
-BLK_TAPS = (2, 3)
+BLK_TAPS = (2, 3, 7, 11)
 
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC, "-Wall",
          "-Wno-unused-function"] + os.environ.get("AMP_BUILD_FLAGS", "").split()

@@ -12,7 +12,7 @@
 // Per output element the order of operations (accumulator start, chunks, taps, the three MFMAs of a term, epilogue) is
 // that of conv_f16x3.hip: the results are bit-identical (tests/test_gpu_f16x3_kernels.py).
 //
-// Compiled once per tap count:  -DAMP_KT=<2|3>.
+// Compiled once per tap count:  -DAMP_KT=<2|3|7|11>.
 #include "amp_internal.h"
 
 #ifndef AMP_KT
@@ -32,9 +32,15 @@ union FragB {
 #define AMP_PIN_VMEM() __builtin_amdgcn_sched_barrier(0x386)
 
 // 4 waves along M (WN = 1), MI = 2 row blocks per wave: 256 rows x NT = 32 * NI columns per workgroup.
-template <int KT, int NI, int HALO, int CM>
+// RING = 0: one A-fragment register set per staging round (CM * KT taps), every entry re-loaded for the next round right after
+// its use.  RING = D > 0 (long tap loops, CM = 1): a ring of D taps -- two row blocks' whole-chunk sets (16 * KT registers)
+// plus 128 accumulators do not fit two waves per SIMD at KT = 7 / 11.  Tap g lives in slot g % D and the slot is re-loaded right
+// after tap g with the next tap that will use it: g + D of this chunk, or -- from the last D taps -- tap (g % D) of the NEXT
+// chunk, whose first D taps restart at slot 0.  Loads run 2-4 taps (3 000-6 000 matrix-pipe cycles) ahead of their use.
+template <int KT, int NI, int HALO, int CM, int RING = 0>
 __global__ __launch_bounds__(256, 2) void conv_blk_kernel(const ConvArgs a) {
     constexpr int MI = 2;
+    static_assert(RING == 0 || (CM == 1 && RING <= KT), "the A ring serves one chunk per round");
     constexpr int NT = 32 * NI;                // output columns per workgroup
     constexpr int S = NT + HALO;               // staged columns
     constexpr int NST = (4 * S) / 256;         // staging items (column x channel quad) per thread and chunk
@@ -192,7 +198,8 @@ __global__ __launch_bounds__(256, 2) void conv_blk_kernel(const ConvArgs a) {
     constexpr size_t kRound = (size_t)VT * 128;
     const size_t mbs = (size_t)a.nchunks * (KT * 128);   // uint4 per row block
     const uint4* wa = static_cast<const uint4*>(a.wp) + (size_t)mb0 * mbs + lane;
-    FragB a_h[MI][VT], a_l[MI][VT];
+    constexpr int NA = RING > 0 ? RING : VT;             // A-fragment register sets held per row block
+    FragB a_h[MI][NA], a_l[MI][NA];
 
     const int rd0 = hi * S + l31 + a.halo_left + a.off0;
     const int dstep = a.dstep;
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void conv_blk_kernel(const ConvArgs a) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int v = 0; v < VT; ++v) {
+        for (int v = 0; v < NA; ++v) {
             a_h[mi][v].u = wa[mi * mbs + v * 128];
             a_l[mi][v].u = wa[mi * mbs + v * 128 + 64];
         }
@@ -214,36 +221,48 @@ __global__ __launch_bounds__(256, 2) void conv_blk_kernel(const ConvArgs a) {
         const bool more = (c + 1) < nrounds;
         stage_load(more ? c + 1 : c);
         AMP_PIN_VMEM();
-        wa += kRound;
+        if constexpr (RING == 0) wa += kRound;
         const uint4* base = smem4 + (c & 1) * (CM * BUF) + rd0;
 #pragma unroll
         for (int cc = 0; cc < CM; ++cc)
 #pragma unroll
             for (int g = 0; g < KT; ++g) {
-                const int v = cc * KT + g;
+                const int v = RING > 0 ? g % NA : cc * KT + g;          // register set of this tap
+                // RING: the tap the slot serves next -- g + RING of this chunk, or tap g % RING of the next chunk
+                const int vn = RING > 0 ? (g + RING < KT ? g + RING : KT + g % NA) : v;
                 const uint4* bg = base + cc * BUF + g * dstep;
-                FragB bh[NI], bl[NI];
+                // BH = 2 (ring form): the tap's B fragments in two halves of NI / 2 column tiles -- 16 registers instead of 32
+                // (what lets a ring of 4 taps fit); every accumulator still sees hh, hl, lh of this tap in that order
+                constexpr int BH = (RING > 3 && NI % 2 == 0) ? 2 : 1;
+                constexpr int NB = NI / BH;
 #pragma unroll
-                for (int t = 0; t < NI; ++t) {
-                    bh[t].u = bg[32 * t];
-                    bl[t].u = bg[2 * S + 32 * t];
-                }
+                for (int th = 0; th < BH; ++th) {
+                    FragB bh[NB], bl[NB];
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
+                    for (int t = 0; t < NB; ++t) {
+                        bh[t].u = bg[32 * (th * NB + t)];
+                        bl[t].u = bg[2 * S + 32 * (th * NB + t)];
+                    }
 #pragma unroll
-                    for (int t = 0; t < NI; ++t)
-                        acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[mi][v].h, bh[t].h, acc[mi][t], 0, 0, 0);
+                    for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-                    for (int t = 0; t < NI; ++t)
-                        acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[mi][v].h, bl[t].h, acc[mi][t], 0, 0, 0);
+                        for (int t = 0; t < NB; ++t)
+                            acc[mi][th * NB + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[mi][v].h, bh[t].h, acc[mi][th * NB + t], 0, 0, 0);
 #pragma unroll
-                    for (int t = 0; t < NI; ++t)
-                        acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l[mi][v].h, bh[t].h, acc[mi][t], 0, 0, 0);
-                    a_h[mi][v].u = wa[mi * mbs + v * 128];
-                    a_l[mi][v].u = wa[mi * mbs + v * 128 + 64];
+                        for (int t = 0; t < NB; ++t)
+                            acc[mi][th * NB + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[mi][v].h, bl[t].h, acc[mi][th * NB + t], 0, 0, 0);
+#pragma unroll
+                        for (int t = 0; t < NB; ++t)
+                            acc[mi][th * NB + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l[mi][v].h, bh[t].h, acc[mi][th * NB + t], 0, 0, 0);
+                        if (th == BH - 1) {
+                            a_h[mi][v].u = wa[mi * mbs + vn * 128];
+                            a_l[mi][v].u = wa[mi * mbs + vn * 128 + 64];
+                        }
+                    }
                 }
                 AMP_PIN_VMEM();
             }
+        if constexpr (RING > 0) wa += kRound;   // the ring's offsets are relative to the chunk being computed
         if (more) stage_store(c + 1, (c + 1) & 1);
         __syncthreads();
     }
@@ -347,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void conv_blk_kernel(const ConvArgs a) {
     }
 }
 
-template <int KT, int NI, int HALO, int CM>
+template <int KT, int NI, int HALO, int CM, int RING = 0>
 static hipError_t launch_blk_one(const ConvArgs& a, hipStream_t stream) {
     constexpr int S = 32 * NI + HALO;
     const size_t lds = (size_t)2 * CM * 4 * S * sizeof(uint4);
@@ -355,14 +374,14 @@ static hipError_t launch_blk_one(const ConvArgs& a, hipStream_t stream) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!((attr_set >> dev) & 1ull) && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_blk_kernel<KT, NI, HALO, CM>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_blk_kernel<KT, NI, HALO, CM, RING>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set |= 1ull << dev;
     }
     dim3 grid((unsigned)(a.B * a.tiles_per_item), (unsigned)(a.M / 256));
     if (a.row_groups > 0) grid = dim3((unsigned)(a.B * a.tiles_per_item * a.row_groups), 1u);
-    hipLaunchKernelGGL((conv_blk_kernel<KT, NI, HALO, CM>), grid, dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((conv_blk_kernel<KT, NI, HALO, CM, RING>), grid, dim3(256), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -374,6 +393,11 @@ static hipError_t launch_blk_one(const ConvArgs& a, hipStream_t stream) {
 //   up-sampling layer (T = 256) a third tile with ONE column; one or two chunks per round (180 / 227 VGPRs);
 //   KT = 3: 128-column tiles, one chunk per round (244 VGPRs; two chunks' A fragments for two row blocks are 96
 //   registers more than the 256 of two waves per SIMD hold: 96-column tiles still spill 17).
+//   KT = 7 / 11: 128-column tiles, one chunk per round, A-fragment ring of AMP_BLK_RING taps (4, with the B fragments of a tap
+//   in two halves: 253 VGPRs; 3 with whole-tap B fragments 252 and 3 % slower, 4 with whole-tap B fragments spills 23).
+#ifndef AMP_BLK_RING
+#define AMP_BLK_RING 4
+#endif
 int AMP_CAT(conv_blk_nt_kt, AMP_KT)(int cm, int halo_total) {
     constexpr int KT = AMP_KT;
     if (KT == 2) return ((cm == 1 || cm == 2) && halo_total <= 32) ? 96 : 0;
@@ -387,9 +411,12 @@ hipError_t AMP_CAT(launch_conv_blk_kt, AMP_KT)(int cm, const ConvArgs& a, hipStr
     if constexpr (KT == 2) {
         if (cm == 2) return launch_blk_one<KT, 3, 32, 2>(a, stream);
         return launch_blk_one<KT, 3, 32, 1>(a, stream);
-    } else {
+    } else if constexpr (KT == 3) {
         if (cm != 1) return hipErrorInvalidValue;
         return launch_blk_one<KT, 4, 64, 1>(a, stream);
+    } else {
+        if (cm != 1) return hipErrorInvalidValue;
+        return launch_blk_one<KT, 4, 64, 1, AMP_BLK_RING>(a, stream);
     }
 }
 

@@ -375,18 +375,22 @@ static bool small_conv_enabled() {
 // Row-blocked conv kernel (conv_blk_f16x3.hip: 64 rows per wave, 256 per workgroup) for the short tap loops -- the
 // transposed convs (2 taps per chunk) and k = 3 convs -- whose GEMM rows are a multiple of 256; same bits as
 // conv_f16x3.hip.  AMP_CONV_BLK / amp_set_conv_blk: 0 off, 1 one 16-channel chunk per staging round, 2 two chunks per
-// round where the kernel has that variant (transposed convs).
+// round where the kernel has that variant (transposed convs), 3 (default) = 2 + the A-fragment-ring form for k = 7 / 11.
 int conv_blk_nt_kt2(int, int);
 int conv_blk_nt_kt3(int, int);
+int conv_blk_nt_kt7(int, int);
+int conv_blk_nt_kt11(int, int);
 hipError_t launch_conv_blk_kt2(int, const ConvArgs&, hipStream_t);
 hipError_t launch_conv_blk_kt3(int, const ConvArgs&, hipStream_t);
-constexpr int kConvBlkDefault = 2;
+hipError_t launch_conv_blk_kt7(int, const ConvArgs&, hipStream_t);
+hipError_t launch_conv_blk_kt11(int, const ConvArgs&, hipStream_t);
+constexpr int kConvBlkDefault = 3;
 static int g_conv_blk = -1;
 static int conv_blk_mode() {
     if (g_conv_blk < 0) {
         const char* e = getenv("AMP_CONV_BLK");
         g_conv_blk = e ? atoi(e) : kConvBlkDefault;
-        if (g_conv_blk < 0 || g_conv_blk > 2) g_conv_blk = kConvBlkDefault;
+        if (g_conv_blk < 0 || g_conv_blk > 3) g_conv_blk = kConvBlkDefault;
     }
     return g_conv_blk;
 }
@@ -634,17 +638,19 @@ static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope
         // narrower tiles while the chip is badly under-filled: one 3-s utterance 1.16 -> 1.06 ms, a 10-s one 2.28 -> 2.30
         const long long wgs_half = (long long)B * ((a.Tq + 63) / 64) * ((c->M + plan.Mgroup() - 1) / plan.Mgroup());
         int blk_cm = 0, blk_nt = 0;
-        if (conv_blk_mode() > 0 && plan.NI == 4 && plan.WM == 4 && (c->KT == 2 || c->KT == 3) && c->M % 256 == 0 && !c->tanh_out) {
-            int cm = (conv_blk_mode() == 2 && c->KT == 2 && c->nchunks % 2 == 0) ? 2 : 1;
+        const bool blk_kt = c->KT == 2 || c->KT == 3 || (conv_blk_mode() == 3 && (c->KT == 7 || c->KT == 11));   // mode 3: + the A-ring form for k = 7 / 11
+        if (conv_blk_mode() > 0 && plan.NI == 4 && plan.WM == 4 && blk_kt && c->M % 256 == 0 && !c->tanh_out) {
+            int cm = (conv_blk_mode() >= 2 && c->KT == 2 && c->nchunks % 2 == 0) ? 2 : 1;
             const int halo = c->halo_left + c->halo_right;
-            const int nt = c->KT == 2 ? conv_blk_nt_kt2(cm, halo) : conv_blk_nt_kt3(cm, halo);
+            const int nt = c->KT == 2 ? conv_blk_nt_kt2(cm, halo) : c->KT == 3 ? conv_blk_nt_kt3(cm, halo) : c->KT == 7 ? conv_blk_nt_kt7(cm, halo) : conv_blk_nt_kt11(cm, halo);
             if (nt > 0 && (long long)B * ((a.Tq + nt - 1) / nt) * (c->M / 256) >= kConvBlkMinWorkgroups) { blk_cm = cm; blk_nt = nt; }
         }
         if (blk_cm > 0) {
             a.tiles_per_item = (a.Tq + blk_nt - 1) / blk_nt;
             a.wd = blk_nt + c->halo_left + c->halo_right;
             a.row_groups = (conv_rg_fast() && c->M / 256 > 1 && conv_weight_bytes(c) <= kConvRgFastMaxWeightBytes) ? c->M / 256 : 0;
-            AMP_HIP(c->KT == 2 ? launch_conv_blk_kt2(blk_cm, a, stream) : launch_conv_blk_kt3(blk_cm, a, stream));
+            AMP_HIP(c->KT == 2 ? launch_conv_blk_kt2(blk_cm, a, stream) : c->KT == 3 ? launch_conv_blk_kt3(blk_cm, a, stream) :
+                    c->KT == 7 ? launch_conv_blk_kt7(blk_cm, a, stream) : launch_conv_blk_kt11(blk_cm, a, stream));
         } else if (plan.NI == 2 && small_conv_covers(c) && (c->KT <= 5 || wgs_half <= 128)) {
             // a small grid of a short contraction: the whole-K kernel (128 x 32 or 128 x 64 tiles, same bits)
             const int ni = small_conv_ni(c);
@@ -1501,7 +1507,7 @@ int amp_set_conv_rg_fast(int on) {
 }
 
 int amp_set_conv_blk(int mode) {
-    if (mode < -1 || mode > 2) { set_error("amp_set_conv_blk: mode %d (0 off, 1 | 2 chunks per staging round, -1 default)", mode); return AMP_ERR_INVALID; }
+    if (mode < -1 || mode > 3) { set_error("amp_set_conv_blk: mode %d (0 off, 1 | 2 chunks per staging round, 3 = 2 + k = 7 / 11, -1 default)", mode); return AMP_ERR_INVALID; }
     g_conv_blk = mode;
     return AMP_OK;
 }

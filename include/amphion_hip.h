@@ -291,10 +291,11 @@ void amp_conv_destroy(amp_conv* c);
  * them on the pipelined kernel -- an A/B and cross-check switch, also AMP_SMALL_CONV=0 in the environment. */
 int amp_set_small_conv(int on);
 
-/* Transposed convs and k = 3 convs whose GEMM rows are a multiple of 256 (ConvTranspose1d: Cout * stride) run, on grids
+/* Transposed convs and k = 3 / 7 / 11 convs whose GEMM rows are a multiple of 256 (ConvTranspose1d: Cout * stride) run, on grids
  * of 512+ workgroups, on the row-blocked kernel (csrc/conv_blk_f16x3.hip: 64 rows per wave, x staged once per 256 rows;
  * same bits as the pipelined kernel).  mode 0 keeps them on the pipelined kernel, 1 = one 16-channel chunk per staging
- * round, 2 = two where available (default), -1 = back to AMP_CONV_BLK / the default -- an A/B and cross-check switch. */
+ * round, 2 = two where available, 3 = 2 + k = 7 / 11 on the A-fragment-ring form (default), -1 = back to AMP_CONV_BLK /
+ * the default -- an A/B and cross-check switch. */
 int amp_set_conv_blk(int mode);
 
 /* Convs with several row groups (more GEMM rows than one workgroup holds) launch with the row group as the fastest grid

@@ -84,6 +84,10 @@ BLK_CASES = [
     (False, 256, 256, 3, 1, 5, 8, 8200),
     (False, 100, 256, 3, 1, 3, 8, 8321),   # Cin not a multiple of 16
     (False, 64, 512, 3, 1, 1, 4, 8200),    # two row groups
+    (False, 256, 256, 7, 1, 3, 8, 8200),   # mode 3: the A-fragment ring form for k = 7 / 11 (the C = 256 stage)
+    (False, 256, 256, 11, 1, 5, 8, 8200),
+    (False, 48, 256, 11, 1, 1, 8, 8300),   # three chunks
+    (False, 16, 512, 7, 1, 1, 4, 8200),    # ONE chunk: the ring's look-ahead into the "next chunk" reads the pad / next row block
 ]
 
 
@@ -104,14 +108,14 @@ def test_blocked_conv_bitwise(tr, cin, cout, k, s, d, B, T):
     L = _lib.lib()
     outs = {}
     try:
-        for mode in (0, 1, 2):
+        for mode in (0, 1, 2, 3):
             _lib.check(L.amp_set_conv_blk(mode))
             outs[mode] = [conv_forward(w, b, x, **kw), conv_forward(w, None, x, slope_in=0.1, slope_out=0.2, **kw)]
             if res is not None:
                 outs[mode].append(conv_forward(w, b, x, slope_in=0.1, res=res, **kw))
     finally:
         _lib.check(L.amp_set_conv_blk(-1))
-    for mode in (1, 2):
+    for mode in (1, 2, 3):
         for a, c in zip(outs[mode], outs[0]):
             assert torch.isfinite(a).all()
             assert torch.equal(a, c), f"mode {mode} differs from the pipelined kernel"

@@ -105,10 +105,10 @@ def test_kernel_policy_switches_validate_without_device():
     out-of-range modes are refused with a message."""
     L = _lib.lib()
     assert L.amp_version() >= 122
-    for mode in (0, 1, 2, -1):
+    for mode in (0, 1, 2, 3, -1):
         assert L.amp_set_conv_blk(mode) == 0
     with pytest.raises(_lib.AmpError) as ei:
-        _lib.check(L.amp_set_conv_blk(3))
+        _lib.check(L.amp_set_conv_blk(4))
     assert "amp_set_conv_blk" in str(ei.value)
     for on in (0, 1, -1):
         assert L.amp_set_conv_rg_fast(on) == 0
