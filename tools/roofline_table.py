@@ -37,9 +37,9 @@ def shape(name):
     m = re.search(r"conv_blk_kernel<(\d+), ", name)
     if m:   # row-blocked kernel (conv_blk_f16x3.hip)
         k = int(m.group(1))
-        if k == 3:
+        if k in (3, 7, 11):
             C = 256
-            return "conv C=256 k=3 (stage 0, row-blocked)", 2.0 * C * C * k * STAGE[C] * B / 1e9, 3 * TENSOR_MB(C)
+            return f"conv C=256 k={k} (stage 0, row-blocked)", 2.0 * C * C * k * STAGE[C] * B / 1e9, 3 * TENSOR_MB(C)
         # the two stride-8 transposed convs share the template: 512 -> 256 (T 256 -> 2048) and 256 -> 128 (2048 -> 16384);
         # FLOPs and bytes of the average launch
         gf = (2.0 * 512 * 256 * 16 * 256 * B + 2.0 * 256 * 128 * 16 * 2048 * B) / 2 / 1e9
@@ -54,14 +54,19 @@ def main():
     base = sys.argv[1] if len(sys.argv) > 1 else "profiles/r2"
     stats = {r["Name"]: r for r in csv.DictReader(open(base + "_kernel_stats.csv"))}
     traffic = {}
-    for r in csv.DictReader(l for l in open(base + "_hbm_traffic.csv") if not l.startswith("#") and l.strip()):
-        traffic[r["kernel"]] = float(r["total_MB_corrected"])
+    import os
+    if os.path.exists(base + "_hbm_traffic.csv"):      # optional: a visit without PMC passes lists the algorithmic bytes only
+        for r in csv.DictReader(l for l in open(base + "_hbm_traffic.csv") if not l.startswith("#") and l.strip()):
+            traffic[r["kernel"]] = float(r["total_MB_corrected"])
     print(f"# per-kernel roofline, config 2 (HiFi-GAN V1, B = 64 x 80 x 256), from {base}_kernel_stats.csv / _hbm_traffic.csv")
     print("# peak: f16x3 MFMA %.1f TFLOP/s (2516.6 / 3), HBM %.0f GB/s; 'alg MB' = read x + write y (+ residual for unfused convs)" % (PEAK_TF, PEAK_GBS))
     print("%-64s %6s %9s %9s %8s %6s %9s %9s %8s %6s" % ("kernel", "calls", "avg us", "GFLOP", "TFLOP/s", "frac", "alg MB", "PMC MB", "GB/s", "frac"))
     tot_us = 0.0
+    blk7 = any("conv_blk_kernel<7," in n for n in stats)     # then the pipelined k = 7 row is conv_pre alone
     for name, r in stats.items():
         sh = shape(name)
+        if blk7 and sh and sh[0].startswith("conv C=256 k=7 (stage 0) "):
+            sh = ("conv_pre 80 -> 512, k=7 (T = 256)", 2.0 * 80 * 512 * 7 * 256 * B / 1e9, B * (80 + 512) * 256 * 4 / 1e6)
         us = float(r["AverageNs"]) / 1e3
         if sh is None:
             continue
