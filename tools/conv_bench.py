@@ -30,6 +30,8 @@ def run(prec, reps, B, Tmel, only=""):
         cases = [c for c in cases if c[0] == "convT" or (c[1] == 256 and c[3] == 3)]
     if only == "rg":    # launches with several row groups per x tile: the C = 256 stage, the stride-8 transposed convs
         cases = [c for c in cases if (c[0] == "convT" and c[5] == 8) or (c[0] == "conv" and c[1] == 256)]
+    if only == "c128":  # the unfused C = 128 convs (BigVGAN's stage 1; HiFi-GAN runs these as fused pairs)
+        cases = [c for c in cases if c[0] == "conv" and c[1] == 128]
     for kind, cin, cout, k, d, u, T, with_res in cases:
         g = torch.Generator().manual_seed(1)
         tr = kind == "convT"
@@ -68,7 +70,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--frames", type=int, default=256)
-    ap.add_argument("--only", default="", choices=["", "blk", "rg"])
+    ap.add_argument("--only", default="", choices=["", "blk", "rg", "c128"])
     a = ap.parse_args()
     print("prec,kind,cin,cout,k,dil,stride,T_in,res,ms,TFLOP/s,GB/s(min-traffic)")
     for p in a.precision:
