@@ -277,7 +277,7 @@ static StripChoice strip_choice(int C, int k) {
     // experiment switches (unset = the policy below; 0 = per-tile kernel): AMP_STRIP_K11 for the k = 11, C = 128 pairs only,
     // AMP_STRIP_C128 for every C = 128 pair.  1 narrow strips, planner | 2 wide tiles | 3 wide, 2 steps | 4 wide, planner |
     // 5 / 6 / 7: the 4-wave 2 x 2-blocked variant (64 rows x 96 columns per wave, one workgroup per CU) as tiles /
-    // 2 steps / planner
+    // 2 steps / planner; 8 / 9: its A-ring form (64 rows x 128 columns per wave) with 1 / 2 steps per strip
     static const int k11 = [] { const char* e = getenv("AMP_STRIP_K11"); return e ? atoi(e) : -1; }();
     static const int c128 = [] { const char* e = getenv("AMP_STRIP_C128"); return e ? atoi(e) : -1; }();
     static const int c64 = [] { const char* e = getenv("AMP_STRIP_C64"); return e ? atoi(e) : -1; }();   // same codes, C = 64
@@ -291,12 +291,18 @@ static StripChoice strip_choice(int C, int k) {
         case 5: return {true, 2, 1};
         case 6: return {true, 2, 2};
         case 7: return {true, 2, 0};
+        case 8: return {true, 3, 1};
+        case 9: return {true, 3, 2};
         default: break;
     }
     // measured policy (profiles/r2_o_policy.txt, rocprofv3 per-kernel averages inside the forward, config 2): the
     // 2 x 2-blocked 4-wave variant in strips of two steps wins at C = 128 for k = 11 (2 122 -> 2 024 us) and k = 7
     // (1 372 -> 1 321 us) and loses for k = 3 (684 -> 748 us); every other shape stays on the per-tile kernel
-    if (C == 128 && (k == 7 || k == 11)) return {true, 2, 2};
+    // third session (profiles/r2_aw_strip_ring.txt): the same form with an A-fragment ring and 64 x 128-column wave tiles
+    // (wide = 3, pair_strip_f16x3.hip), one 256-column step per strip: k = 11 1.86 ms against 2.23 for the per-tile kernel in
+    // the same process (the whole-chunk form above: 0.957 of the per-tile kernel), k = 7 1.27 against 1.43.
+    // AMP_STRIP_C128=6 selects the whole-chunk form again (A/B switch), 8 / 9 the ring form with one / two steps per strip.
+    if (C == 128 && (k == 7 || k == 11)) return {true, 3, 1};
     return {false, 0, 0};
 }
 
@@ -760,7 +766,7 @@ static int pair_run(const amp_conv* c1, const amp_conv* c2, const float* x, int 
         if (steps > 0 && steps * n1 - (c1->k - 1) < T) { a.strip_len = steps * n1 - (c1->k - 1); a.strips_per_item = (T + a.strip_len - 1) / a.strip_len; }
         // one workgroup per CU: a grid that cannot fill the chip twice over (a single utterance) is better served by the
         // 4x as many independent tiles of the per-tile kernel (same bits)
-        if (g_pair_strips == -1 && sc.wide == 2 && (long long)B * a.strips_per_item < 512 && pair_tile(c1->k, c1->cin, c1->dilation) > 0) {
+        if (g_pair_strips == -1 && sc.wide >= 2 && (long long)B * a.strips_per_item < 512 && pair_tile(c1->k, c1->cin, c1->dilation) > 0) {
             const int NT = pair_tile(c1->k, c1->cin, c1->dilation);
             a.tiles_per_item = (T + NT - 1) / NT;
             AMP_HIP(launch_pair(c1->k, a, stream));

@@ -44,8 +44,18 @@ union FragS {
 
 #define AMP_PIN_VMEM() __builtin_amdgcn_sched_barrier(0x386)
 
-template <int KT, int WM, int WN, int NI, int SX, int MI = 1>
+// RING = D > 0 (round 2, third session; `wide` = 3): the A fragments as a ring of D taps per row block instead of a whole chunk's set
+// (conv_blk_f16x3.hip: tap g in slot g % D, re-loaded right after its use with tap g + D of this chunk or tap g % D of the next
+// one, across conv1 -> conv2 -> the next step's conv1) -- 16 * D registers instead of 16 * KT for two row blocks, which is what
+// leaves room for NI = 4 column tiles per wave (64 rows x 128 columns: A-fragment traffic per MFMA -25 %, seam waste (k - 1) / 256
+// instead of / 192); the B fragments of a tap are read in two halves.  SBUF = 1: ONE x staging buffer (the 136-KB xt tile of a
+// 256-column step leaves 20 KB of the 160: the chunk loop waits for every wave's reads before the next chunk is written -- one
+// more barrier per chunk).  Same bits as every other form; measured 1.86-1.90 ms against 2.23 for the per-tile kernel in the
+// same process at k = 11 (the whole-chunk 2 x 2-blocked strips: 0.957 of the per-tile kernel), 1.27 against 1.43 at k = 7.
+template <int KT, int WM, int WN, int NI, int SX, int MI = 1, int RING = 0, int SBUF = 2>
 __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_kernel(const PairArgs a) {
+    static_assert(RING == 0 || RING <= KT, "ring of at most one chunk");
+    static_assert(SBUF == 1 || SBUF == 2, "staging buffers");
     constexpr int NTHR = 64 * WM * WN;
     constexpr int N1 = 32 * NI * WN;          // xt columns per step = output columns per step
     constexpr int H2 = (KT - 1) / 2;
@@ -58,8 +68,8 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
     static_assert(SX % 64 == 0, "staging items must have a wave-uniform channel quad");
     static_assert((4 * SX) % NTHR == 0, "staging items must divide over the threads");
     static_assert(HB <= 32, "the carried columns must belong to the last n-tile");
-    extern __shared__ __attribute__((aligned(16))) uint4 smem4[];  // [2][XBUF] + [NCH][XTCH]
-    uint4* const xt4 = smem4 + 2 * XBUF;
+    extern __shared__ __attribute__((aligned(16))) uint4 smem4[];  // [SBUF][XBUF] + [NCH][XTCH]
+    uint4* const xt4 = smem4 + SBUF * XBUF;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -148,7 +158,17 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
     constexpr size_t MBS = (size_t)NCH * (KT * 128);   // uint4 per 32-row block of packed A fragments
     const uint4* wa1 = static_cast<const uint4*>(a.wp1) + (size_t)(MI * wm) * MBS + lane;
     const uint4* wa2 = static_cast<const uint4*>(a.wp2) + (size_t)(MI * wm) * MBS + lane;
-    FragS a_h[MI][KT], a_l[MI][KT];
+    constexpr int NA = RING > 0 ? RING : KT;          // A-fragment register sets per row block
+    FragS a_h[MI][NA], a_l[MI][NA];
+    // after tap g of the chunk at `wcur`: the register set of tap g is re-loaded with the tap it serves next -- the same tap of the
+    // next chunk (`wnext`) without a ring; with a ring tap g + RING of this chunk, or tap g % RING of the next chunk
+    auto reload = [&](int mi, int g, const uint4* wcur, const uint4* wnext) __attribute__((always_inline)) {
+        const int v = RING > 0 ? g % NA : g;
+        const bool same = RING > 0 && g + RING < KT;
+        const uint4* src = same ? wcur + (size_t)(g + RING) * 128 : wnext + (size_t)(RING > 0 ? g % NA : g) * 128;
+        a_h[mi][v].u = src[mi * MBS];
+        a_l[mi][v].u = src[mi * MBS + 64];
+    };
     const int rd1 = hi * SX + colw;
     const int rd2 = hi * XT + colw;
 
@@ -161,7 +181,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int g = 0; g < KT; ++g) {
+        for (int g = 0; g < NA; ++g) {
             a_h[mi][g].u = wa1[mi * MBS + g * 128];
             a_l[mi][g].u = wa1[mi * MBS + g * 128 + 64];
         }
@@ -218,34 +238,43 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
             const bool more = (c + 1) < NCH;
             stage_load(more ? c + 1 : c, tbase);
             AMP_PIN_VMEM();
+            const uint4* wcur = wa1 + (size_t)c * (KT * 128);
             const uint4* wan = more ? wa1 + (size_t)(c + 1) * (KT * 128) : wa2;
-            const uint4* base = smem4 + (c & 1) * XBUF + rd1;
+            const uint4* base = smem4 + (SBUF == 2 ? (c & 1) : 0) * XBUF + rd1;
 #pragma unroll
             for (int g = 0; g < KT; ++g) {
+                const int v = RING > 0 ? g % NA : g;
                 const uint4* bg = base + g * dil;
-                FragS bh[NI], bl[NI];
+                // the tap's B fragments in BH halves (ring form with an even NI: 16 registers instead of 32); every accumulator still
+                // sees hh, hl, lh of the tap in this order
+                constexpr int BH = (RING > 0 && NI % 2 == 0) ? 2 : 1;
+                constexpr int NB = NI / BH;
 #pragma unroll
-                for (int t = 0; t < NI; ++t) {
-                    bh[t].u = bg[32 * t];
-                    bl[t].u = bg[2 * SX + 32 * t];
-                }
+                for (int th = 0; th < BH; ++th) {
+                    FragS bh[NB], bl[NB];
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
+                    for (int t = 0; t < NB; ++t) {
+                        bh[t].u = bg[32 * (th * NB + t)];
+                        bl[t].u = bg[2 * SX + 32 * (th * NB + t)];
+                    }
 #pragma unroll
-                    for (int t = 0; t < NI; ++t)
-                        acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[mi][g].h, bh[t].h, acc[mi][t], 0, 0, 0);
+                    for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-                    for (int t = 0; t < NI; ++t)
-                        acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[mi][g].h, bl[t].h, acc[mi][t], 0, 0, 0);
+                        for (int t = 0; t < NB; ++t)
+                            acc[mi][th * NB + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[mi][v].h, bh[t].h, acc[mi][th * NB + t], 0, 0, 0);
 #pragma unroll
-                    for (int t = 0; t < NI; ++t)
-                        acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l[mi][g].h, bh[t].h, acc[mi][t], 0, 0, 0);
-                    a_h[mi][g].u = wan[mi * MBS + g * 128];
-                    a_l[mi][g].u = wan[mi * MBS + g * 128 + 64];
+                        for (int t = 0; t < NB; ++t)
+                            acc[mi][th * NB + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[mi][v].h, bl[t].h, acc[mi][th * NB + t], 0, 0, 0);
+#pragma unroll
+                        for (int t = 0; t < NB; ++t)
+                            acc[mi][th * NB + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l[mi][v].h, bh[t].h, acc[mi][th * NB + t], 0, 0, 0);
+                        if (th == BH - 1) reload(mi, g, wcur, wan);
+                    }
                 }
                 AMP_PIN_VMEM();
             }
-            if (more) stage_store((c + 1) & 1, tbase);
+            if (SBUF == 1) __syncthreads();   // every wave has read the one staging buffer
+            if (more) stage_store(SBUF == 2 ? (c + 1) & 1 : 0, tbase);
             __syncthreads();
         }
 
@@ -303,30 +332,36 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
         // ---------------- conv2 over the xt tile ----------------
 #pragma unroll 1
         for (int c = 0; c < NCH; ++c) {
+            const uint4* wcur = wa2 + (size_t)c * (KT * 128);
             const uint4* wan = (c + 1) < NCH ? wa2 + (size_t)(c + 1) * (KT * 128) : wa1;
             const uint4* base = xt4 + c * XTCH + rd2;
 #pragma unroll
             for (int g = 0; g < KT; ++g) {
+                const int v = RING > 0 ? g % NA : g;
                 const uint4* bg = base + g;
-                FragS bh[NI], bl[NI];
+                constexpr int BH = (RING > 0 && NI % 2 == 0) ? 2 : 1;
+                constexpr int NB = NI / BH;
 #pragma unroll
-                for (int t = 0; t < NI; ++t) {
-                    bh[t].u = bg[32 * t];
-                    bl[t].u = bg[2 * XT + 32 * t];
-                }
+                for (int th = 0; th < BH; ++th) {
+                    FragS bh[NB], bl[NB];
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
+                    for (int t = 0; t < NB; ++t) {
+                        bh[t].u = bg[32 * (th * NB + t)];
+                        bl[t].u = bg[2 * XT + 32 * (th * NB + t)];
+                    }
 #pragma unroll
-                    for (int t = 0; t < NI; ++t)
-                        acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[mi][g].h, bh[t].h, acc[mi][t], 0, 0, 0);
+                    for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-                    for (int t = 0; t < NI; ++t)
-                        acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[mi][g].h, bl[t].h, acc[mi][t], 0, 0, 0);
+                        for (int t = 0; t < NB; ++t)
+                            acc[mi][th * NB + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[mi][v].h, bh[t].h, acc[mi][th * NB + t], 0, 0, 0);
 #pragma unroll
-                    for (int t = 0; t < NI; ++t)
-                        acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l[mi][g].h, bh[t].h, acc[mi][t], 0, 0, 0);
-                    a_h[mi][g].u = wan[mi * MBS + g * 128];
-                    a_l[mi][g].u = wan[mi * MBS + g * 128 + 64];
+                        for (int t = 0; t < NB; ++t)
+                            acc[mi][th * NB + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[mi][v].h, bl[t].h, acc[mi][th * NB + t], 0, 0, 0);
+#pragma unroll
+                        for (int t = 0; t < NB; ++t)
+                            acc[mi][th * NB + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l[mi][v].h, bh[t].h, acc[mi][th * NB + t], 0, 0, 0);
+                        if (th == BH - 1) reload(mi, g, wcur, wan);
+                    }
                 }
                 AMP_PIN_VMEM();
             }
@@ -376,22 +411,22 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
     if (a.range_flag && __any(range_max > 65504.f) && lane == 0) atomicOr(a.range_flag, 1u);
 }
 
-template <int KT, int WM, int WN, int NI, int SX, int MI = 1>
+template <int KT, int WM, int WN, int NI, int SX, int MI = 1, int RING = 0, int SBUF = 2>
 static hipError_t launch_strip_one(const PairArgs& a, hipStream_t stream) {
     constexpr int N1 = 32 * NI * WN;
     constexpr int XT = N1 + (KT - 1);
-    const size_t lds = ((size_t)2 * 4 * SX + (size_t)2 * WM * MI * 4 * XT) * sizeof(uint4);
+    const size_t lds = ((size_t)SBUF * 4 * SX + (size_t)2 * WM * MI * 4 * XT) * sizeof(uint4);
     static unsigned long long attr_set = 0;   // per device: the attribute belongs to the device's copy of the function
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!((attr_set >> dev) & 1ull) && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_strip_kernel<KT, WM, WN, NI, SX, MI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_strip_kernel<KT, WM, WN, NI, SX, MI, RING, SBUF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set |= 1ull << dev;
     }
     dim3 grid((unsigned)(a.B * a.strips_per_item));
-    hipLaunchKernelGGL((pair_strip_kernel<KT, WM, WN, NI, SX, MI>), grid, dim3(64 * WM * WN), lds, stream, a);
+    hipLaunchKernelGGL((pair_strip_kernel<KT, WM, WN, NI, SX, MI, RING, SBUF>), grid, dim3(64 * WM * WN), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -400,6 +435,7 @@ static hipError_t launch_strip_one(const PairArgs& a, hipStream_t stream) {
 
 // Step width (xt columns = output columns per step) for C channels, or 0 when (C, KT, dilation) is not covered;
 // *wg_per_cu = resident workgroups per CU (LDS / register bound), used by the host to size the strips.
+// wide = 3: the 2 x 2-blocked form with an A-fragment ring and 256-column steps (C = 128, k >= 7).
 // wide = 1: 8-wave workgroups with twice the step width, one per CU -- waves (wm, 0) and (wm, 1) fetch the same A
 // fragments (the second hits L1), and the k - 1 seam columns / the dilated halo are paid once per 2 x the columns.
 int AMP_CAT(strip_step_kt, AMP_KT)(int C, int dil, int wide, int* wg_per_cu) {
@@ -407,6 +443,7 @@ int AMP_CAT(strip_step_kt, AMP_KT)(int C, int dil, int wide, int* wg_per_cu) {
     const int span = (KT - 1) * dil;   // staged halo = 2 * h1
     int n1 = 0, wg = 2;
     if (C == 256) { n1 = (96 + span <= 256) ? 96 : 0; wg = 1; }
+    else if (wide == 3) { n1 = (C == 128 && KT >= 7 && 256 + span <= 320) ? 256 : 0; wg = 1; }    // 4 waves x (64 rows x 128 columns), A ring
     else if (wide == 2 && C == 128) { n1 = (192 + span <= 256) ? 192 : 0; wg = 1; }   // 4 waves x (64 rows x 96 columns)
     else if (wide == 2 && C == 64) { n1 = (256 + span <= 320) ? 256 : 0; wg = 1; }    // 4 waves x (64 rows x 64 columns)
     else if (wide && C == 128) { n1 = (192 + span <= 256) ? 192 : 0; wg = 1; }
@@ -423,6 +460,12 @@ hipError_t AMP_CAT(launch_strip_kt, AMP_KT)(const PairArgs& a, hipStream_t strea
     constexpr int KT = AMP_KT;
     const int span = (KT - 1) * a.dil;
     if (a.C == 256) return launch_strip_one<KT, 8, 1, 3, 256>(a, stream);
+    if (a.wide == 3) {
+        if constexpr (KT >= 7) {
+            if (a.C == 128) return launch_strip_one<KT, 2, 2, 4, 320, 2, 4, 1>(a, stream);
+        }
+        return hipErrorInvalidValue;
+    }
     if (a.wide == 2 && a.C == 128) return launch_strip_one<KT, 2, 2, 3, 256, 2>(a, stream);
     if (a.wide == 2 && a.C == 64) return launch_strip_one<KT, 1, 4, 2, 320, 2>(a, stream);
     if (a.wide) {

@@ -322,7 +322,10 @@ def main():
         # which fused-pair kernel the k = 11, C = 128 pairs run (generator.hip: strip_choice): the measured default is the
         # 2 x 2-blocked strip kernel; AMP_PAIR_STRIP=0 the per-tile kernel of round 1, =1 the 4-wave strips
         sel = os.environ.get("AMP_PAIR_STRIP")
-        pair_name = {"0": "pair_f16x3_kernel<11, 4, 1, 3, 192>", "1": "pair_strip_kernel<11, 4, 1, 3, *>"}.get(sel, "pair_strip_kernel<11, 2, 2, 3, 256, 2>")
+        # default since round 2's third session: the 2 x 2-blocked strips with an A-fragment ring (64 x 128-column wave tiles);
+        # AMP_STRIP_C128=6 selects the whole-chunk form of the second session again
+        dflt = "pair_strip_kernel<11, 2, 2, 3, 256, 2>" if os.environ.get("AMP_STRIP_C128") in ("5", "6", "7") else "pair_strip_kernel<11, 2, 2, 4, 320, 2, 4, 1>"
+        pair_name = {"0": "pair_f16x3_kernel<11, 4, 1, 3, 192>", "1": "pair_strip_kernel<11, 4, 1, 3, *>"}.get(sel, dflt)
         kname = pair_name if fused else "conv_mfma_kernel<11, 4, 1, 8, 64>"
         if fused and os.path.exists(PROFILE_TRAFFIC_CSV):              # PMC pass of an EARLIER run of this command (static)
             tr = [float(line.rsplit(",", 1)[1]) * float(line.rsplit(",", 6)[1]) for line in open(PROFILE_TRAFFIC_CSV)
@@ -341,7 +344,8 @@ def main():
             "frac": dom_tflops / peak_tflops,
             "traffic": traffic,
             "traffic_source": ("static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command "
-                               "(FETCH x2 gfx950 correction), " + os.path.relpath(PROFILE_TRAFFIC_CSV, ROOT)) if traffic else None,
+                               "(FETCH x2 gfx950 correction), " + os.path.relpath(PROFILE_TRAFFIC_CSV, ROOT)) if traffic else
+                              ("no PMC pass of this kernel is on file yet (" + os.path.relpath(PROFILE_TRAFFIC_CSV, ROOT) + ")" if fused else None),
             "algorithmic_flop_per_launch": dom_flop,
             "algorithmic_bytes_per_launch": dom_bytes,
             "launch_us": dom_s * 1e6,
