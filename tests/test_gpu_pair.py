@@ -50,6 +50,17 @@ STRIP_CASES = [
 ]
 
 
+# launches of 512+ strips at C = 128, k in {7, 11}: the policy's A-ring strips (pair_strip_f16x3.hip, wide = 3: 64 x 128-column wave
+# tiles, one 256-column step per strip); smaller launches of the same shapes fall back to the per-tile kernel
+RING_CASES = [
+    # C, k, dilation, B, T
+    (128, 11, 5, 64, 2100),
+    (128, 7, 3, 64, 4100),
+    (128, 11, 1, 48, 6000),
+    (128, 7, 5, 70, 1999),
+]
+
+
 def _pair_inputs(C, k, B, T):
     w1 = _rand(C, C, k, seed=1, scale=(C * k) ** -0.5)
     b1 = _rand(C, seed=2, scale=0.1)
@@ -86,7 +97,7 @@ def test_strip_kernel_equals_tile_kernel_bitwise(C, k, d, B, T, strips):
     assert torch.equal(y_strip, y_tile)
 
 
-@pytest.mark.parametrize("C,k,d,B,T", [c for c in PAIR_CASES + STRIP_CASES if c[0] in (64, 128)])
+@pytest.mark.parametrize("C,k,d,B,T", [c for c in PAIR_CASES + STRIP_CASES if c[0] in (64, 128)] + RING_CASES)
 def test_policy_kernel_equals_tile_kernel_bitwise(C, k, d, B, T, strips):
     """Whatever kernel the per-shape policy picks (amp_set_pair_strips(-1): the default table, or an experiment variant
     selected with AMP_STRIP_C128 / AMP_STRIP_K11 -- wide 8-wave tiles, the 2 x 2-blocked 4-wave variant, ...) gives the
