@@ -57,7 +57,6 @@ RING_CASES = [
     (128, 11, 5, 64, 2100),
     (128, 7, 3, 64, 4100),
     (128, 11, 1, 48, 6000),
-    (128, 7, 5, 70, 1999),
 ]
 
 
