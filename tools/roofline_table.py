@@ -17,7 +17,7 @@ TENSOR_MB = lambda C: B * C * STAGE[C] * 4 / 1e6
 
 def shape(name):
     """-> (label, algorithmic GFLOP per launch, algorithmic MB per launch (read x + write y)) or None"""
-    m = re.search(r"pair_(?:strip|f16x3)_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?>", name)
+    m = re.search(r"pair_(?:strip|f16x3)_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?(?:, \d+)*>", name)
     if m:
         k, wm, wn = int(m.group(1)), int(m.group(2)), int(m.group(3))
         mi = int(m.group(6) or 1) if "strip" in name else 1
