@@ -443,7 +443,10 @@ int AMP_CAT(strip_step_kt, AMP_KT)(int C, int dil, int wide, int* wg_per_cu) {
     const int span = (KT - 1) * dil;   // staged halo = 2 * h1
     int n1 = 0, wg = 2;
     if (C == 256) { n1 = (96 + span <= 256) ? 96 : 0; wg = 1; }
-    else if (wide == 3) { n1 = (C == 128 && KT >= 7 && 256 + span <= 320) ? 256 : 0; wg = 1; }    // 4 waves x (64 rows x 128 columns), A ring
+    else if (wide == 3 && C == 128) { n1 = (KT >= 7 && 256 + span <= 320) ? 256 : 0; wg = 1; }    // 4 waves x (64 rows x 128 columns), A ring
+    // C = 64 in the same form (a wave owns all 64 rows x 96 columns, 384-column steps, 130 KB of LDS): built as an experiment
+    // (AMP_STRIP_C64=8 | 9), NOT yet run on hardware and not in the policy
+    else if (wide == 3) { n1 = (C == 64 && KT >= 7 && 384 + span <= 448) ? 384 : 0; wg = 1; }
     else if (wide == 2 && C == 128) { n1 = (192 + span <= 256) ? 192 : 0; wg = 1; }   // 4 waves x (64 rows x 96 columns)
     else if (wide == 2 && C == 64) { n1 = (256 + span <= 320) ? 256 : 0; wg = 1; }    // 4 waves x (64 rows x 64 columns)
     else if (wide && C == 128) { n1 = (192 + span <= 256) ? 192 : 0; wg = 1; }
@@ -463,6 +466,7 @@ hipError_t AMP_CAT(launch_strip_kt, AMP_KT)(const PairArgs& a, hipStream_t strea
     if (a.wide == 3) {
         if constexpr (KT >= 7) {
             if (a.C == 128) return launch_strip_one<KT, 2, 2, 4, 320, 2, 4, 1>(a, stream);
+            if (a.C == 64) return launch_strip_one<KT, 1, 4, 3, 448, 2, 4, 1>(a, stream);
         }
         return hipErrorInvalidValue;
     }
