@@ -1,5 +1,6 @@
-// Row-blocked variant of the f16x3 implicit-GEMM conv (conv_f16x3.hip) for SHORT tap loops: the transposed convs
-// (hifigan.py:204-207: polyphase rows, 2 taps per 16-channel chunk) and the k = 3 convs of the C = 256 stage.
+// Row-blocked variant of the f16x3 implicit-GEMM conv (conv_f16x3.hip) for convs with 256+ GEMM rows: the transposed convs
+// (hifigan.py:204-207: polyphase rows, 2 taps per 16-channel chunk) and the convs of the C = 256 stage (hifigan.py:93-100 unfused;
+// k = 3 with a whole-chunk A-fragment set, k = 7 / 11 with a ring of four taps, see RING below).
 //
 // In conv_f16x3.hip a wave owns 32 GEMM rows x 128 columns: per tap it fetches 2 A fragments (hi, lo) from L2 and 8 B
 // fragments from LDS for 12 MFMAs, and a 16-channel chunk of x is staged (global -> split -> LDS) once per 128-row
