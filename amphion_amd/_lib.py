@@ -85,6 +85,7 @@ _SIGNATURES = {
     "amp_gen_set_profiling": (c_int, [c_void_p, c_int]),
     "amp_gen_last_timing_ms": (c_int, [c_void_p, c_int, POINTER(c_float)]),
     "amp_gen_timing_ms": (c_int, [c_void_p, c_int, c_int, POINTER(c_float)]),
+    "amp_gen_kernel_name": (c_int, [c_void_p, c_int, c_int, c_char_p, c_size_t]),
     "amp_gen_destroy": (None, [c_void_p]),
     "amp_conv_create": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, POINTER(c_void_p)]),
     "amp_conv_out_len": (c_int, [c_void_p, c_int]),

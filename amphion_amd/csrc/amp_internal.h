@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include <string>
 #include <vector>
@@ -164,6 +165,24 @@ hipError_t launch_mel(const amp_mel_desc& d, const float* wav, const int* lens, 
                       const float* melbasis, float* mel, float* mag, float* re, float* im, hipStream_t stream);
 
 void set_error(const char* fmt, ...);
+
+// Which kernels a stretch of launch_* calls issued, as rocprofv3 prints them ("pair_strip_kernel<11, 2, 2, 4, 320, 2, 4, 1>"):
+// while the calling thread points tl_kernel_log at a string (a profiled amp_gen_forward does, per resblock), every launch
+// appends its kernel's name once (" | "-joined) -- bench.py reports the variant the policy actually picked, not a literal.
+extern thread_local std::string* tl_kernel_log;
+template <typename... A>
+inline void note_kernel(const char* base, A... args) {
+    if (!tl_kernel_log) return;
+    char buf[128];
+    const int v[] = {static_cast<int>(args)...};
+    int n = snprintf(buf, sizeof(buf), "%s<", base);
+    for (size_t i = 0; i < sizeof...(args) && n < (int)sizeof(buf) - 16; ++i)
+        n += snprintf(buf + n, sizeof(buf) - n, i ? ", %d" : "%d", v[i]);
+    snprintf(buf + n, sizeof(buf) - n, ">");
+    if (tl_kernel_log->find(buf) != std::string::npos) return;
+    if (!tl_kernel_log->empty()) *tl_kernel_log += " | ";
+    *tl_kernel_log += buf;
+}
 
 // The f16x3 kernels stage fp32 activations as hi + lo f16 pairs after an exact x16: anything beyond |x| = 4094 (or
 // non-finite) cannot be represented.  They OR 1 into this per-device word when that happens (range_guard.hip).

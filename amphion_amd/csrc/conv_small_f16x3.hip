@@ -431,6 +431,7 @@ static hipError_t launch_small_one(const ConvArgs& a, hipStream_t stream) {
         attr_set |= 1ull << dev;
     }
     dim3 grid((unsigned)(a.B * a.tiles_per_item), (unsigned)((a.M + 127) / 128));
+    note_kernel("conv_small_kernel", KT, NI, HALO, EPI);
     hipLaunchKernelGGL((conv_small_kernel<KT, NI, HALO, EPI>), grid, dim3(256), lds, stream, a);
     return hipGetLastError();
 }

@@ -69,6 +69,7 @@ struct RangeGuard {
     bool pending = false;          // an async copy of `dev` is in flight / unread
 };
 static RangeGuard g_guard[64];                    // op-level launches (amp_conv_forward, amp_pair_forward, ...): one word per device
+thread_local std::string* tl_kernel_log = nullptr;    // amp_internal.h: note_kernel()
 static thread_local unsigned* tl_range_flag = nullptr;   // set while an amp_gen forward is launching: that handle's own word
 
 static bool guard_init(RangeGuard& g) {
@@ -826,6 +827,7 @@ struct amp_gen {
         hipEvent_t ev_begin = nullptr, ev_end = nullptr;
         std::vector<hipEvent_t> ev_mrf;  // begin/end per (batch group, stage)
         std::vector<hipEvent_t> ev_rb;   // per (batch group, stage): n_kernels + 1 marks around the resblocks
+        std::vector<std::string> rb_kernels;   // per (stage, resblock): the distinct kernels its launches ran, " | "-joined (first batch group)
         int ev_groups = 0;
         bool valid = false;
     };
@@ -1288,12 +1290,29 @@ int amp_gen_timing_ms(amp_gen* g, int back, int which, float* ms_out) {
 
 int amp_gen_last_timing_ms(amp_gen* g, int which, float* ms_out) { return amp_gen_timing_ms(g, 0, which, ms_out); }
 
+int amp_gen_kernel_name(amp_gen* g, int back, int which, char* buf, size_t n) {
+    if (!g || !buf || n == 0) { set_error("amp_gen_kernel_name: null argument"); return AMP_ERR_INVALID; }
+    if (g->prof.empty() || back < 0 || (size_t)back >= g->prof.size() || (size_t)back >= g->prof_count) {
+        set_error("amp_gen_kernel_name: no profiled forward %d back (slots=%zu, recorded=%zu)", back, g->prof.size(), g->prof_count);
+        return AMP_ERR_STATE;
+    }
+    const amp_gen::ProfSlot& p = g->prof[(g->prof_count - 1 - (size_t)back) % g->prof.size()];
+    const int i = (which - 100) / 16, j = (which - 100) % 16;
+    if (which < 100 || i >= g->d.n_stages || j >= g->d.n_kernels || (size_t)(i * g->d.n_kernels + j) >= p.rb_kernels.size()) {
+        set_error("amp_gen_kernel_name: which=%d", which);
+        return AMP_ERR_INVALID;
+    }
+    snprintf(buf, n, "%s", p.rb_kernels[(size_t)i * g->d.n_kernels + j].c_str());
+    return AMP_OK;
+}
+
 #define AMP_RC(expr) do { int rc__ = (expr); if (rc__ != AMP_OK) return rc__; } while (0)
 
 // One group of `B` items through the whole generator (buffers sized for `be` elements each).
 static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond_dev, const int* lens, int B, int T,
                              float* wav_dev, float* base, size_t be, hipStream_t st,
-                             hipEvent_t* ev_mrf /* 2 per stage, or null */, hipEvent_t* ev_rb /* (n_kernels+1) per stage */) {
+                             hipEvent_t* ev_mrf /* 2 per stage, or null */, hipEvent_t* ev_rb /* (n_kernels+1) per stage */,
+                             std::vector<std::string>* rb_names = nullptr /* per (stage, resblock), or null */) {
     const amp_gen_desc& d = g->d;
     const bool big = d.arch == AMP_ARCH_BIGVGAN;
     float* X = base;            // stage input / MRF accumulator (ping-pong with XS)
@@ -1339,6 +1358,9 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
                 }
             }
             if (ev_rb && !conc) AMP_HIP(hipEventRecord(ev_rb[(size_t)i * (nk + 1) + j], sj));
+            // profiled forward: every launch of this resblock logs its kernel's name (note_kernel, amp_internal.h)
+            struct LogScope { LogScope(std::string* p) { tl_kernel_log = p; if (p) p->clear(); } ~LogScope() { tl_kernel_log = nullptr; } }
+                log_scope(rb_names ? &(*rb_names)[(size_t)i * nk + j] : nullptr);
             const ResBlock& rb = g->rbs[(size_t)i * nk + j];
             const int nd = (int)rb.dil.size();
             const int mode_last = (nk == 1) ? 0 : (j == 0 ? 0 : (j == nk - 1 ? 2 : 1));
@@ -1456,6 +1478,7 @@ int amp_gen_forward_ragged(amp_gen* g, const float* mel_dev, const float* cond_d
             ps->ev_rb.push_back(e);
         }
         ps->ev_groups = ngroups;
+        ps->rb_kernels.assign((size_t)d.n_stages * d.n_kernels, std::string());
         AMP_HIP(hipEventRecord(ps->ev_begin, st));
     }
     for (int gi = 0; gi < ngroups; ++gi) {
@@ -1466,7 +1489,8 @@ int amp_gen_forward_ragged(amp_gen* g, const float* mel_dev, const float* cond_d
                                  lens_dev ? lens_dev + b0 : nullptr, Bg, T,
                                  wav_dev + (size_t)b0 * L, (float*)workspace_dev, be, st,
                                  ps ? ps->ev_mrf.data() + 2 * (size_t)d.n_stages * gi : nullptr,
-                                 ps ? ps->ev_rb.data() + (size_t)d.n_stages * (d.n_kernels + 1) * gi : nullptr));
+                                 ps ? ps->ev_rb.data() + (size_t)d.n_stages * (d.n_kernels + 1) * gi : nullptr,
+                                 (ps && gi == 0) ? &ps->rb_kernels : nullptr));
     }
     if (ps) { AMP_HIP(hipEventRecord(ps->ev_end, st)); ps->valid = true; ++g->prof_count; }
     AMP_RC(range_publish(&g->guard, st));

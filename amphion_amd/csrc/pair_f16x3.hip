@@ -317,6 +317,7 @@ static hipError_t launch_pair_one(const PairArgs& a, hipStream_t stream) {
         attr_set |= 1ull << dev;
     }
     dim3 grid((unsigned)(a.B * a.tiles_per_item));
+    note_kernel("pair_f16x3_kernel", KT, WM, WN, NI, SX);
     hipLaunchKernelGGL((pair_f16x3_kernel<KT, WM, WN, NI, SX>), grid, dim3(256), lds, stream, a);
     return hipGetLastError();
 }

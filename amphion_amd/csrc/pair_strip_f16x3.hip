@@ -426,6 +426,7 @@ static hipError_t launch_strip_one(const PairArgs& a, hipStream_t stream) {
         attr_set |= 1ull << dev;
     }
     dim3 grid((unsigned)(a.B * a.strips_per_item));
+    note_kernel("pair_strip_kernel", KT, WM, WN, NI, SX, MI, RING, SBUF);
     hipLaunchKernelGGL((pair_strip_kernel<KT, WM, WN, NI, SX, MI, RING, SBUF>), grid, dim3(64 * WM * WN), lds, stream, a);
     return hipGetLastError();
 }

@@ -370,6 +370,7 @@ static hipError_t launch_act1d_n(const float* x, float* y, int B, int C, int T, 
     const int ntiles = (T + A1_TT - 1) / A1_TT;
     const int ngroups = (ntiles + NTILE - 1) / NTILE;
     dim3 grid((unsigned)((size_t)ngroups * (size_t)(B * C)));
+    note_kernel("act1d_kernel", NTILE);
     hipLaunchKernelGGL(act1d_kernel<NTILE>, grid, dim3(256), 0, stream, x, y, C, T, a_dev, invb_dev, fu, fd, lens,
                        len_mul, rev);
     return hipGetLastError();

@@ -77,6 +77,16 @@ class PosteriorEncoder(nn.Module):
         return z, m, logs, x_mask
 
 
+def _dec_exact(self, z, g):
+    """``self.dec(z, g=g)`` with the fp32 reference's operand range: the decoder's own range flag is checked for THIS call and
+    the exact-fp32 kernels take over if an activation did not fit (``HipGenerator.forward_exact_range``) -- the waveform
+    that leaves ``infer`` / ``reconstruct`` is never silently inf / NaN.  The check synchronises once, after the last
+    launch of the call; the op-level check that follows it finds the stream already drained."""
+    if g is not None and not hasattr(self.dec, "cond"):
+        raise AttributeError("'HiFiGAN_vits' object has no attribute 'cond'")
+    return self.dec.forward_exact_range(z, g)
+
+
 class SynthesizerTrnDecodePath(nn.Module):
     """The sub-modules of ``SynthesizerTrn`` (vits.py:155-379) that config 5 exercises -- ``enc_q``,
     ``flow``, ``dec`` -- under the reference's attribute names, so a full VITS checkpoint loads with
@@ -91,13 +101,16 @@ class SynthesizerTrnDecodePath(nn.Module):
         self.enc_q = PosteriorEncoder(spec_channels, inter_channels, hidden_channels, 5, 1, 16, gin_channels=gin_channels)
         self.flow = ResidualCouplingBlock(inter_channels, hidden_channels, 5, 1, 4, gin_channels=gin_channels)
 
+    _dec_exact = _dec_exact
+
     def reconstruct(self, y, y_lengths, g_src=None, g_tgt=None, noise=None):
         """voice_conversion topology (vits.py:371-379): enc_q -> flow -> flow(reverse) -> dec."""
         lens = hip_ops.lens_tensor(y_lengths, _lib.require_device_tensor(y, "y").device)
         z, m_q, logs_q, y_mask = self.enc_q(y, lens, g=g_src, noise=noise)
         z_p = self.flow(z, lens, g=g_src)
         z_hat = self.flow(z_p, lens, g=g_tgt, reverse=True)
-        o_hat = self.dec(hip_ops.sequence_mask_(z_hat.clone(), lens), g=g_tgt)
+        o_hat = self._dec_exact(hip_ops.sequence_mask_(z_hat.clone(), lens), g_tgt)
+        _lib.range_check(z_hat.device)       # enc_q / flow are op-level f16x3 launches: an operand beyond |x| = 4094 raises HERE
         return o_hat, y_mask, (z, z_p, z_hat)
 
 
@@ -156,6 +169,8 @@ class SynthesizerTrn(nn.Module):
         if n_speakers >= 1:
             self.emb_g = nn.Embedding(n_speakers, gin_channels)
 
+    _dec_exact = _dec_exact
+
     def forward(self, data):
         raise NotImplementedError("SynthesizerTrn.forward is the training step; this package is inference-only")
 
@@ -181,7 +196,8 @@ class SynthesizerTrn(nn.Module):
         z_p = hip_ops.gauss_sample(m_e, logs_e, _lib.require_device_tensor(noise_z, "noise_z"), noise_scale)
         z = self.flow(z_p, y_lengths, g=g, reverse=True)
         zm = hip_ops.sequence_mask_(z.clone(), y_lengths)
-        o = self.dec(zm[:, :, :max_len].contiguous() if max_len is not None else zm, g=g)
+        o = self._dec_exact(zm[:, :, :max_len].contiguous() if max_len is not None else zm, g)
+        _lib.range_check(dev)                # text encoder / duration predictor / flow: op-level f16x3 launches (as in reconstruct)
         y_mask = (torch.arange(t_y, device=dev).unsqueeze(0) < y_lengths.unsqueeze(1)).unsqueeze(1).to(z.dtype)
         return {"y_hat": o, "attn": attn, "mask": y_mask, "z": z, "z_p": z_p, "m_p": m_e, "logs_p": logs_e}
 
@@ -194,5 +210,6 @@ class SynthesizerTrn(nn.Module):
         z, m_q, logs_q, y_mask = self.enc_q(y, lens, g=g_src)
         z_p = self.flow(z, lens, g=g_src)
         z_hat = self.flow(z_p, lens, g=g_tgt, reverse=True)
-        o_hat = self.dec(hip_ops.sequence_mask_(z_hat.clone(), lens), g=g_tgt)
+        o_hat = self._dec_exact(hip_ops.sequence_mask_(z_hat.clone(), lens), g_tgt)
+        _lib.range_check(z_hat.device)       # enc_q / flow are op-level f16x3 launches: an operand beyond |x| = 4094 raises HERE
         return o_hat, y_mask, (z, z_p, z_hat)

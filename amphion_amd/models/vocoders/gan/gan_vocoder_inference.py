@@ -8,7 +8,21 @@ arithmetic, but runs each padded batch through the generator ONCE instead of one
 """
 import torch
 
+from amphion_amd import _lib
 from amphion_amd.utils.util import pad_mels_to_tensors
+
+
+def _reference_range(model, run, device):
+    """``run()`` with the fp32 reference's operand range.  The f16x3 kernels flag an activation beyond |x| = 4094 instead
+    of producing the reference's value; the audio is about to be copied to the host anyway, so the flag is checked HERE,
+    for this very batch: generators on the handle path fall back to their exact-fp32 kernels and repeat
+    (``HipGenerator._amp_exact_range``); op-level models (MelGAN, APNet) raise ``AmpError`` -- never inf / NaN audio
+    returned silently, never an error surfacing one batch late."""
+    if hasattr(model, "_amp_exact_range"):
+        return model._amp_exact_range(run)
+    out = run()
+    _lib.range_check(device)
+    return out
 
 
 def vocoder_inference(cfg, model, mels, f0s=None, device=None, fast_inference=False):
@@ -18,12 +32,15 @@ def vocoder_inference(cfg, model, mels, f0s=None, device=None, fast_inference=Fa
         mels = mels.to(device)
         if f0s is not None:
             f0s = f0s.to(device)
-        if f0s is None and not cfg.preprocess.extract_amplitude_phase:
-            output = model.forward(mels)
-        elif cfg.preprocess.extract_amplitude_phase:
-            (_, _, _, _, output) = model.forward(mels)
-        else:
-            output = model.forward(mels, f0s)
+
+        def run():
+            if f0s is None and not cfg.preprocess.extract_amplitude_phase:
+                return model.forward(mels)
+            if cfg.preprocess.extract_amplitude_phase:
+                return model.forward(mels)[4]
+            return model.forward(mels, f0s)
+
+        output = _reference_range(model, run, mels.device)
         return output.squeeze(1).detach().cpu()
 
 
@@ -58,7 +75,8 @@ def synthesis_audios(cfg, model, mels, f0s=None, batch_size=None, fast_inference
                 batch = torch.zeros((len(grp), n_mel, lens[0]), dtype=torch.float32)
                 for r, i in enumerate(grp):
                     batch[r, :, : lens[r]] = torch.as_tensor(mels[i], dtype=torch.float32)
-                out = model.forward_ragged(batch.to(device), lens).squeeze(1).cpu()
+                batch = batch.to(device)
+                out = _reference_range(model, lambda: model.forward_ragged(batch, lens), device).squeeze(1).cpu()
                 for r, i in enumerate(grp):
                     audios[i] = out[r, : lens[r] * hop].clone()
         return audios
@@ -84,7 +102,8 @@ def synthesis_audios(cfg, model, mels, f0s=None, batch_size=None, fast_inference
             ext = [min(T, int(f) + rf) for f in mel_frame]
             model.eval()
             with torch.no_grad():
-                out = model.forward_ragged(mel_batch.to(device), ext).squeeze(1).cpu()
+                mel_dev = mel_batch.to(device)
+                out = _reference_range(model, lambda: model.forward_ragged(mel_dev, ext), device).squeeze(1).cpu()
         else:
             out = vocoder_inference(cfg, model, mel_batch, f0s=f0_batch, device=device, fast_inference=fast_inference)
         for i in range(mel_batch.shape[0]):

@@ -213,10 +213,19 @@ class HipGenerator(nn.Module):
         fin = weakref.finalize(self, _destroy_handle, h.value)
         prev_prec = L.amp_get_precision()
         try:
+            staged = []
             for key, t in self._amp_weights():
                 c = t.detach().to(torch.float32).contiguous()      # host or device: amp_gen_set_weight takes either
+                staged.append((key, c, c.is_cuda and c.data_ptr() != t.data_ptr()))
+            # amp_gen_set_weight copies with a blocking hipMemcpy on the NULL stream; torch's side streams do not order with
+            # it, so a temporary made by a conversion kernel (fp16 / bf16 or non-contiguous parameters) on a non-default
+            # current stream -- capture()'s warm-up always runs on one -- must be complete before it is read
+            for dev in {c.device for _, c, converted in staged if converted}:
+                torch.cuda.current_stream(dev).synchronize()
+            for key, c, _ in staged:
                 shape = (ctypes.c_int64 * c.dim())(*c.shape)
                 _lib.check(L.amp_gen_set_weight(h, key.encode(), ctypes.c_void_p(c.data_ptr()), shape, c.dim()))
+            del staged
             with torch.cuda.device(device):
                 if getattr(self, "_amp_force_f32", False):      # forward_exact_range fell back: pack for the fp32 kernels
                     _lib.check(L.amp_set_precision(_lib.AMP_PRECISION_F32))
@@ -233,16 +242,20 @@ class HipGenerator(nn.Module):
         return h
 
     def _amp_forward(self, x, g=None, lengths=None, workspace=None):
-        # Inference only: the HIP kernels have no backward.  A gradient asked for THROUGH the generator cannot be
-        # honoured -> fail; a module left in training mode merely gets told once.
+        # Inference only: the HIP kernels have no backward.  A gradient asked for THROUGH the generator cannot be honoured,
+        # and neither can a training step: a module in training mode, with autograd on and trainable parameters, is what a
+        # GAN trainer calls (the registry / class patch of amphion_amd.integration reaches gan_vocoder_trainer.py and the
+        # VITS trainers too) -- an output without grad_fn would let loss_g.backward() succeed through the discriminator
+        # only and the generator would silently never train.  Fail instead.
         if torch.is_grad_enabled() and isinstance(x, torch.Tensor):
             if x.requires_grad:
                 raise RuntimeError("amphion_amd generators are inference-only (no backward through the HIP kernels): "
                                    "detach the input or call under torch.no_grad()")
-            if self.training and not getattr(self, "_amp_warned_training", False):
-                self._amp_warned_training = True
-                warnings.warn("amphion_amd generator called in training mode with autograd on: the output carries no "
-                              "gradient (inference-only kernels); call .eval() / torch.no_grad()", RuntimeWarning, stacklevel=3)
+            if self.training and any(p.requires_grad for p in self.parameters()):
+                raise RuntimeError("amphion_amd generators are inference-only: called in training mode with autograd on and "
+                                   "trainable parameters, the output would carry no gradient and the generator would never "
+                                   "train; call .eval() / torch.no_grad() for inference, or build the reference class "
+                                   "(module._reference_<Name>, kept by amphion_amd.integration) for training")
         x = _lib.require_device_tensor(x, "generator input")
         if x.dim() != 3:
             raise ValueError(f"expected [B, C, T] input, got {tuple(x.shape)}")
@@ -299,19 +312,28 @@ class HipGenerator(nn.Module):
     def forward_exact_range(self, x, g=None, lengths=None):
         """Forward with the fp32 reference's operand range: runs the f16x3 kernels, checks the range flag (one
         synchronisation) and, if an activation did not fit, repeats the call on the exact-fp32 MFMA kernels (handle
-        rebuilt once; it stays in fp32 from then on)."""
-        out = self._amp_forward(x, g, lengths=lengths)
+        rebuilt once; it stays in fp32 from then on).  This is what the drop-in entry points (``vocoder_inference``,
+        ``synthesis_audios``, ``inference_batches``) call: they copy the audio to the host anyway, so the check's
+        synchronisation is free and no batch -- the last or only one included -- returns inf / NaN audio silently."""
+        return self._amp_exact_range(lambda: self._amp_forward(x, g, lengths=lengths))
+
+    def _amp_exact_range(self, run):
+        """``run()`` (one or more forwards of this generator), then the range check; on ``AMP_ERR_RANGE`` -- from the check
+        or from ``run`` itself, which reports a flag an EARLIER unchecked forward left behind -- switch this generator to
+        the exact-fp32 kernels and run again."""
         try:
+            out = run()
             self.check_range()
+            return out
         except _lib.AmpError as e:
             if e.status != _lib.AMP_ERR_RANGE or getattr(self, "_amp_force_f32", False):
                 raise
-            warnings.warn("amphion_amd: an activation left the split-f16 operand range; this generator now runs the "
-                          "exact-fp32 kernels", RuntimeWarning, stacklevel=2)
-            self._amp_force_f32 = True
-            self._amp_release()
-            out = self._amp_forward(x, g, lengths=lengths)
-            self.check_range()
+        warnings.warn("amphion_amd: an activation left the split-f16 operand range; this generator now runs the "
+                      "exact-fp32 kernels", RuntimeWarning, stacklevel=3)
+        self._amp_force_f32 = True
+        self._amp_release()
+        out = run()
+        self.check_range()
         return out
 
     def receptive_frames(self):
@@ -365,7 +387,7 @@ class HipGenerator(nn.Module):
 
         The graph records raw device pointers: it owns its OWN workspace (kept alive by ``replay``; eager forwards of
         other shapes may re-allocate the module's), and it is tied to the packed weights of the current handle --
-        ``replay()`` raises once the parameters changed (``load_state_dict``, ``.to()``, ``set_precision`` ...) instead
+        ``replay()`` raises once the parameters changed (``load_state_dict``, ``.to()``, an in-place update ...) instead
         of reading freed memory; capture again after such a change.
         """
         dev = next(self.parameters()).device
@@ -415,3 +437,10 @@ class HipGenerator(nn.Module):
         ms = ctypes.c_float()
         _lib.check(_lib.lib().amp_gen_timing_ms(self._amp_handle, back, which, ctypes.byref(ms)))
         return ms.value
+
+    def kernel_names(self, which, back=0):
+        """The kernels resblock j of stage i (``which`` = 100 + 16*i + j) launched in a recorded forward, as the library
+        reports them (``amp_gen_kernel_name``: rocprofv3 spelling incl. template arguments), a list of names."""
+        buf = ctypes.create_string_buffer(1024)
+        _lib.check(_lib.lib().amp_gen_kernel_name(self._amp_handle, back, which, buf, len(buf)))
+        return [n for n in buf.value.decode().split(" | ") if n]

@@ -42,7 +42,8 @@ PEAK_HBM_GBS = 8000.0
 # on MI355X (profiles/r1_mfma_peak_microbench.txt): the chip clocks down to ~1.6 GHz under MFMA load
 # (2192 TF on zeros, 1580-1630 TF on random data), so this -- not 2516.6 -- is what a perfect kernel gets.
 SUSTAINED_F16_TFLOPS = 1600.0
-PROFILE_TRAFFIC_CSV = os.path.join(ROOT, "profiles", "r2_hbm_traffic.csv")   # written by tools/summarize_prof.py from a PMC pass
+# written by tools/summarize_prof.py from the FETCH_SIZE / WRITE_SIZE passes of tools/gpu_round.sh (newest round first)
+PROFILE_TRAFFIC_CSVS = [os.path.join(ROOT, "profiles", n) for n in ("r3_hbm_traffic.csv", "r2_hbm_traffic.csv")]
 # arithmetic of the conv contractions -> (dtype string, peak for ALGORITHMIC flops, note)
 PRECISIONS = {
     "f16x3": ("f32 (split-f16 MFMA: 3 x v_mfma_f32_32x32x16_f16 per term, f32 accumulate)", PEAK_F16_TFLOPS / 3.0,
@@ -319,20 +320,23 @@ def main():
         dom_s = (sum(dom_ms) / len(dom_ms)) * 1e-3 / dom_launches
         dom_tflops = dom_flop / dom_s / 1e12
         traffic = None
-        # which fused-pair kernel the k = 11, C = 128 pairs run (generator.hip: strip_choice): the measured default is the
-        # 2 x 2-blocked strip kernel; AMP_PAIR_STRIP=0 the per-tile kernel of round 1, =1 the 4-wave strips
-        sel = os.environ.get("AMP_PAIR_STRIP")
-        # default since round 2's third session: the 2 x 2-blocked strips with an A-fragment ring (64 x 128-column wave tiles);
-        # AMP_STRIP_C128=6 selects the whole-chunk form of the second session again
-        dflt = "pair_strip_kernel<11, 2, 2, 3, 256, 2>" if os.environ.get("AMP_STRIP_C128") in ("5", "6", "7") else "pair_strip_kernel<11, 2, 2, 4, 320, 2, 4, 1>"
-        pair_name = {"0": "pair_f16x3_kernel<11, 4, 1, 3, 192>", "1": "pair_strip_kernel<11, 4, 1, 3, *>"}.get(sel, dflt)
-        kname = pair_name if fused else "conv_mfma_kernel<11, 4, 1, 8, 64>"
-        if fused and os.path.exists(PROFILE_TRAFFIC_CSV):              # PMC pass of an EARLIER run of this command (static)
-            tr = [float(line.rsplit(",", 1)[1]) * float(line.rsplit(",", 6)[1]) for line in open(PROFILE_TRAFFIC_CSV)
-                  if kname.split("*")[0] in line]
-            nl = [float(line.rsplit(",", 6)[1]) for line in open(PROFILE_TRAFFIC_CSV) if kname.split("*")[0] in line]
-            if tr:
-                traffic = sum(tr) / sum(nl) * 1e6                      # FETCH_SIZE x2 (gfx950) + WRITE_SIZE, bytes/launch
+        # which kernel the three launches of that resblock ran: reported by the library for the profiled forwards themselves
+        # (amp_gen_kernel_name: the launch policy's actual pick for this shape, rocprofv3 spelling), not assumed here
+        knames = sorted({n for back in range(args.steps) for n in model.kernel_names(100 + 16 * DOM_STAGE + DOM_RB, back)})
+        kname = " | ".join(knames)
+        traffic_csv = None
+        if len(knames) == 1:
+            # PMC bytes of exactly this instantiation from the newest profile set that has it (a PMC pass cannot run inside
+            # the timed process: "static").  FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, bytes per launch.
+            for path in PROFILE_TRAFFIC_CSVS:
+                if not os.path.exists(path):
+                    continue
+                rows = [line for line in open(path) if ("amp::" + knames[0] + "(") in line]
+                if rows:
+                    n = sum(float(r.rsplit(",", 6)[1]) for r in rows)
+                    traffic = sum(float(r.rsplit(",", 1)[1]) * float(r.rsplit(",", 6)[1]) for r in rows) / n * 1e6
+                    traffic_csv = os.path.relpath(path, ROOT)
+                    break
         roofline = {
             "kernel": kname + (" (fused ResBlock pair, C=128, k=11: conv1 -> LDS -> conv2 + residual; the three launches of "
                                "resblock j=2 of stage 1, dilations 1 / 3 / 5)" if fused else ""),
@@ -342,10 +346,12 @@ def main():
             "peak_note": peak_note,
             "unit": "TFLOP/s",
             "frac": dom_tflops / peak_tflops,
+            "kernel_source": "amp_gen_kernel_name (library-reported for the timed forwards)",
             "traffic": traffic,
+            "traffic_over_algorithmic": (traffic / dom_bytes) if traffic else None,
             "traffic_source": ("static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command "
-                               "(FETCH x2 gfx950 correction), " + os.path.relpath(PROFILE_TRAFFIC_CSV, ROOT)) if traffic else
-                              ("no PMC pass of this kernel is on file yet (" + os.path.relpath(PROFILE_TRAFFIC_CSV, ROOT) + ")" if fused else None),
+                               "(FETCH x2 gfx950 correction), " + traffic_csv) if traffic else
+                              "no PMC pass of this kernel instantiation is on file under profiles/",
             "algorithmic_flop_per_launch": dom_flop,
             "algorithmic_bytes_per_launch": dom_bytes,
             "launch_us": dom_s * 1e6,

@@ -165,6 +165,10 @@ int amp_gen_forward_ragged(amp_gen* g, const float* mel_dev, const float* cond_d
 int amp_gen_set_profiling(amp_gen* g, int slots);
 int amp_gen_timing_ms(amp_gen* g, int back, int which, float* ms_out);
 int amp_gen_last_timing_ms(amp_gen* g, int which, float* ms_out);
+/* Which kernels the launches of resblock j of stage i (which = 100 + 16*i + j, as above) were in that profiled forward:
+ * the distinct kernel names as rocprofv3 prints them (template arguments included), " | "-joined, written to buf[n].
+ * This is what the launch policy actually picked for the shape -- bench.py reports it instead of assuming. */
+int amp_gen_kernel_name(amp_gen* g, int back, int which, char* buf, size_t n);
 
 void amp_gen_destroy(amp_gen* g);
 
@@ -323,7 +327,9 @@ int amp_conv_create_gated(int hidden, int k, int dilation, int padding, const fl
  * in_layers[i]: amp_conv_create_gated handles; res_skip_layers[i]: amp_conv_create 1x1 convs (H -> 2H, last H -> H).
  * x_dev [B, H, T] is the caller's working copy and is MODIFIED; cond_dev = cond_layer(g) [B, 2H*n_layers] (element
  * (b, r) at cond_dev[b*cond_batch_stride + r]) or NULL; lens_dev int32 [B] or NULL; acts_ws_dev scratch [B, H, T];
- * out_dev [B, H, T] (written, not read). */
+ * out_dev [B, H, T] (written, not read).  With lens_dev, columns t >= lens[b] of out_dev (and of x_dev) are UNSPECIFIED --
+ * whole tiles beyond an utterance's end are skipped and never stored: ASSIGN zero there (amp_sequence_mask does, as
+ * WN.forward's final `* x_mask` would), do not multiply what is left in them by a mask (0 * NaN). */
 int amp_wn_forward(const amp_conv* const* in_layers, const amp_conv* const* res_skip_layers, int n_layers, float* x_dev,
                    const float* cond_dev, long long cond_batch_stride, const int32_t* lens_dev, int B, int T,
                    float* acts_ws_dev, float* out_dev, void* stream);

@@ -272,8 +272,9 @@ def test_load_audio_torch_and_save_feature(tmp_path):
 
 
 def test_generator_is_inference_only():
-    # no backward through the HIP kernels: an input that asks for a gradient is refused, a module left in
-    # training mode is warned once; a CPU tensor is refused either way (no fallback)
+    # no backward through the HIP kernels: an input that asks for a gradient is refused, and so is a training step (training
+    # mode + autograd + trainable parameters: what a GAN trainer does through the integration patch -- the generator would
+    # silently never train); a CPU tensor is refused either way (no fallback)
     import warnings
     from types import SimpleNamespace as NS
 
@@ -287,10 +288,13 @@ def test_generator_is_inference_only():
     m = HiFiGAN(NS(preprocess=NS(n_mel=8), model=NS(hifigan=NS(**hp))))
     with pytest.raises(RuntimeError, match="inference-only"):
         m(torch.zeros(1, 8, 4, requires_grad=True))
-    with pytest.warns(RuntimeWarning, match="training mode"), pytest.raises(RuntimeError, match="no CPU fallback"):
+    with pytest.raises(RuntimeError, match="training mode"):
         m(torch.zeros(1, 8, 4))
     with warnings.catch_warnings():
-        warnings.simplefilter("error")                      # told once only; and never in eval / no_grad
+        warnings.simplefilter("error")                      # under no_grad, frozen, or in eval: nothing to say
+        with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU fallback"):
+            m(torch.zeros(1, 8, 4))
+        m.requires_grad_(False)
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             m(torch.zeros(1, 8, 4))
         m2 = HiFiGAN(NS(preprocess=NS(n_mel=8), model=NS(hifigan=NS(**hp)))).eval()
