@@ -299,6 +299,9 @@ def main():
         mrf_ms.append(model.last_timing_ms(1, back))
         stage_ms.append([model.last_timing_ms(2 + i, back) for i in range(len(hp["upsample_rates"]))])
         dom_ms.append(model.last_timing_ms(100 + 16 * DOM_STAGE + DOM_RB, back))
+    # which kernel the launches of that resblock ran: reported by the library for the profiled forwards themselves
+    # (amp_gen_kernel_name: the launch policy's actual pick for this shape, rocprofv3 spelling), not assumed here
+    knames = sorted({n for back in range(args.steps) for n in model.kernel_names(100 + 16 * DOM_STAGE + DOM_RB, back)})
     model.set_profiling(0)
 
     if rank == 0:
@@ -320,9 +323,6 @@ def main():
         dom_s = (sum(dom_ms) / len(dom_ms)) * 1e-3 / dom_launches
         dom_tflops = dom_flop / dom_s / 1e12
         traffic = None
-        # which kernel the three launches of that resblock ran: reported by the library for the profiled forwards themselves
-        # (amp_gen_kernel_name: the launch policy's actual pick for this shape, rocprofv3 spelling), not assumed here
-        knames = sorted({n for back in range(args.steps) for n in model.kernel_names(100 + 16 * DOM_STAGE + DOM_RB, back)})
         kname = " | ".join(knames)
         traffic_csv = None
         if len(knames) == 1:

@@ -47,6 +47,31 @@ def test_infer_matches_reference(tag):
         assert (o[k] - _t(tag, k)).abs().max().item() <= tol, k
 
 
+def test_infer_full_size_matches_reference():
+    """The oracle pinned at config/vits.json:28-75 dimensions too (hidden 192, 6 layers, filter 768, full decoder; B = 4,
+    T_text up to 100): golden_vits_infer_full.npz = the REAL reference's infer (make_golden_vits_infer.py --full)."""
+    F = np.load(os.path.join(HERE, "golden", "golden_vits_infer_full.npz"))
+    with open(os.path.join(HERE, "golden", "keys_vits_synthesizer.json")) as f:
+        shapes = {k: tuple(s) for k, s in json.load(f)}
+    sd = {k: synth.synth_tensor(k, v, int(F["weight_seed"]), 1.0 if k.startswith("dec.") else 0.5) for k, v in shapes.items()}
+    hp = dict(inter_channels=192, hidden_channels=192, filter_channels=768, n_heads=2, n_layers=6, kernel_size=3, resblock="1",
+              resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5]] * 3, upsample_rates=[8, 8, 2, 2],
+              upsample_initial_channel=512, upsample_kernel_sizes=[16, 16, 4, 4], n_speakers=0, use_sdp=True)
+    x, xl = torch.from_numpy(F["x"]), torch.from_numpy(F["x_lengths"])
+    torch.manual_seed(int(F["noise_seed"]))
+    n_dp = torch.randn(x.shape[0], 2, x.shape[1])
+    n_z = torch.randn(x.shape[0], 192, int(F["y_frames"].max()), generator=torch.Generator().manual_seed(int(F["noise_seed"]) + 1))
+    assert abs(float(n_z.double().sum()) - F["noise_z_check"][0]) < 1e-6 and float(n_dp[1, 1, 17]) == F["noise_dp_check"][1]
+    with torch.no_grad():
+        o = vio.vits_infer(sd, hp, x, xl, n_z, noise_dp=n_dp, noise_scale=0.667, length_scale=1.0, noise_scale_w=0.8)
+    D = int(F["decim"])
+    assert torch.equal(o["attn"].sum(2)[:, 0].to(torch.int32), torch.from_numpy(F["durations"]))
+    assert (o["logw"] - torch.from_numpy(F["logw"])).abs().max().item() <= 2e-4
+    for k, tol in (("m_p", 2e-5), ("logs_p", 2e-5), ("z_p", 1e-4), ("z", 1e-4)):
+        assert (o[k][:, :, ::D] - torch.from_numpy(F[k])).abs().max().item() <= tol, k
+    assert (o["y_hat"] - torch.from_numpy(F["y_hat"])).abs().max().item() <= 1e-4
+
+
 def test_text_encoder_pieces():
     sd = _weights("sdp")
     with torch.no_grad():
