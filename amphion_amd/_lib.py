@@ -110,6 +110,8 @@ _SIGNATURES = {
     "amp_wav_to_pcm16": (c_int, [c_void_p, c_int, c_int, ctypes.c_longlong, c_void_p, c_void_p, ctypes.c_longlong, c_void_p]),
     "amp_conv_set_option": (c_int, [c_void_p, c_int, c_int]),
     "amp_pair_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "amp_resblock_forward": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_int, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "amp_set_resblock_fusion": (c_int, [c_int]),
     "amp_conv_destroy": (None, [c_void_p]),
     "amp_set_small_conv": (c_int, [c_int]),
     "amp_set_conv_blk": (c_int, [c_int]),
@@ -180,6 +182,7 @@ def check(status):
     return status
 
 
+AMP_ERR_UNSUPPORTED = -4
 AMP_ERR_RANGE = -6
 
 

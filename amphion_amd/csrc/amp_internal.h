@@ -84,14 +84,36 @@ struct PairArgs {
     int tiles_per_item;        // per-tile kernel (pair_f16x3.hip): ceil(T / NT)
     int strip_len;             // strip kernel (pair_strip_f16x3.hip): output columns per workgroup ...
     int strips_per_item;       // ... and workgroups per batch item, ceil(T / strip_len)
-    int wide;                  // strip kernel: 1 = the 8-wave, double-width variant (one workgroup per CU)
+    int wide;                  // strip kernel: 0 = four-wave strips, 3 = the 2 x 2-blocked A-ring form (one workgroup per CU)
     int rev;                   // 1: descending tile / strip order, see ConvArgs::rev
-    int stagger;               // experiment: start delay of de-phased workgroups, in s_sleep(127) units (0 = none)
-    int stagger_mode;          // 1: second-slot workgroups (blockIdx >> 8 odd) wait `stagger`; 2: (blockIdx >> 3) & 7 eighths of it
     int dil;
     float slope;               // leaky_relu slope (on x while staging, on conv1's output at the seam)
     float sc1, isc1, sc2, isc2;  // 16 * 2^s operand scaling of each conv and its reciprocal
     int mode;
+    float div;
+    const int* lens;           // ragged batches, see ConvArgs
+    int len_mul;
+    unsigned* range_flag;      // see ConvArgs
+};
+
+// Arguments of the whole-ResBlock kernel (rb_f16x3.hip): for p < np:  x = x + c2_p(lrelu(c1_p(lrelu(x))))   [then the MRF modes]
+constexpr int AMP_RB_MAX_PAIRS = 3;
+struct RbArgs {
+    const float* x;            // [B, C, T] input of the block
+    float* y;                  // [B, C, T] output; must NOT alias x (other tiles read x's halo)
+    const void* wp1[AMP_RB_MAX_PAIRS];     // c1_p (kernel k, dilation dil[p]): packed f16x3 A fragments
+    const float* bias1[AMP_RB_MAX_PAIRS];
+    const void* wp2[AMP_RB_MAX_PAIRS];     // c2_p (kernel k, dilation 1)
+    const float* bias2[AMP_RB_MAX_PAIRS];
+    float sc1[AMP_RB_MAX_PAIRS], isc1[AMP_RB_MAX_PAIRS], sc2[AMP_RB_MAX_PAIRS], isc2[AMP_RB_MAX_PAIRS];   // 16 * 2^s and reciprocal
+    int dil[AMP_RB_MAX_PAIRS];
+    int np;                    // pairs in the block (1 .. AMP_RB_MAX_PAIRS)
+    int rh;                    // one-sided receptive field of the block: sum_p (k-1)/2 * (dil[p] + 1) columns
+    int B, C, T;
+    int tiles_per_item;        // ceil(T / (W - 2 * rh))
+    int rev;                   // 1: descending tile order, see ConvArgs::rev
+    float slope;               // leaky_relu slope
+    int mode;                  // 0: y = v   1: y = y + v   2: y = (y + v) / div   (the LAST pair's MRF mode)
     float div;
     const int* lens;           // ragged batches, see ConvArgs
     int len_mul;
@@ -123,6 +145,10 @@ hipError_t launch_pair(int k, const PairArgs& a, hipStream_t stream);
 // strip-mined fused pair (pair_strip_f16x3.hip): columns per step for (C, k, dilation), 0 = not covered
 int strip_step(int k, int C, int dil, int wide, int* wg_per_cu);
 hipError_t launch_strip(int k, const PairArgs& a, hipStream_t stream);
+
+// whole ResBlock1 (rb_f16x3.hip): tile width for (C, k, max dilation) in form `wide`, 0 = not covered; launch
+int rb_tile(int k, int C, int max_dil, int wide);
+hipError_t launch_rb(int k, const RbArgs& a, int wide, hipStream_t stream);
 
 // conv_post: y[b,0,t] = tanh( bias + sum_i sum_j w[i][j] * act_in(x[b,i,t+j-pad]) )   (Cout == 1)
 hipError_t launch_conv_post(const float* x, const float* w_dev /*[Cin*K]*/, const float* bias_dev /*[1] or null*/,

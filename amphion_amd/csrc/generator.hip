@@ -9,6 +9,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "amp_internal.h"
@@ -135,14 +136,31 @@ static int range_publish(RangeGuard* g, hipStream_t st) {
     return AMP_OK;
 }
 
+// Wait for everything queued on `st` WITHOUT the runtime's blocking wait: an event record + a polling loop (hipEventQuery,
+// yielding between polls).  The blocking forms (hipStreamSynchronize, a copy into pageable memory) hand the thread to the
+// interrupt path once the wait is long, and on the MI355X boxes of round 3 that path woke up ~21 ms late on every other call
+// when it was entered behind a whole generator forward: the list API's calls alternated 37 / 62 ms with the GPU idle in between
+// (profiles/r3_e_*: rocprofv3 timeline, the gap sits after the forward's last kernel) -- which is what the driver's single
+// round-2 sample of 66.5 ms against the README's 38 ms was.
+static int wait_stream_polling(RangeGuard* g, hipStream_t st) {
+    AMP_HIP(hipEventRecord(g->ev, st));
+    for (;;) {
+        const hipError_t q = hipEventQuery(g->ev);
+        if (q == hipSuccess) return AMP_OK;
+        if (q != hipErrorNotReady) { (void)hipGetLastError(); set_error("hipEventQuery: %s", hipGetErrorString(q)); return AMP_ERR_HIP; }
+        std::this_thread::yield();
+    }
+}
+
 // synchronising check of one guard
 static int range_check_sync(RangeGuard* g, hipStream_t st, const char* who) {
     if (!g || !g->dev) return AMP_OK;
     if (stream_is_capturing(st)) { set_error("%s: the stream is capturing", who); return AMP_ERR_STATE; }
-    unsigned v = 0;
-    AMP_HIP(hipMemcpyAsync(&v, g->dev, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-    AMP_HIP(hipStreamSynchronize(st));
+    AMP_HIP(hipMemcpyAsync(g->host, g->dev, sizeof(unsigned), hipMemcpyDeviceToHost, st));   // pinned mirror: truly asynchronous
+    const int rc = wait_stream_polling(g, st);
+    if (rc != AMP_OK) return rc;
     g->pending = false;
+    const unsigned v = *g->host;
     *g->host = 0;
     if (v == 0) return AMP_OK;
     AMP_HIP(hipMemsetAsync(g->dev, 0, sizeof(unsigned), st));
@@ -248,15 +266,72 @@ hipError_t launch_strip(int k, const PairArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
-// AMP_FUSE_PAIRS=0 runs every ResBlock pair as two conv launches (A/B switch for the fused kernel).
-static int g_fuse_pairs = -1;
-static bool fuse_pairs_enabled() {
-    if (g_fuse_pairs < 0) {
-        const char* e = getenv("AMP_FUSE_PAIRS");
-        g_fuse_pairs = (e && !strcmp(e, "0")) ? 0 : 1;
+int rb_tile_kt3(int, int, int);
+int rb_tile_kt5(int, int, int);
+int rb_tile_kt7(int, int, int);
+int rb_tile_kt11(int, int, int);
+hipError_t launch_rb_kt3(const RbArgs&, int, hipStream_t);
+hipError_t launch_rb_kt5(const RbArgs&, int, hipStream_t);
+hipError_t launch_rb_kt7(const RbArgs&, int, hipStream_t);
+hipError_t launch_rb_kt11(const RbArgs&, int, hipStream_t);
+
+int rb_tile(int k, int C, int max_dil, int wide) {
+    switch (k) {
+        case 3: return rb_tile_kt3(C, max_dil, wide);
+        case 5: return rb_tile_kt5(C, max_dil, wide);
+        case 7: return rb_tile_kt7(C, max_dil, wide);
+        case 11: return rb_tile_kt11(C, max_dil, wide);
     }
-    return g_fuse_pairs != 0;
+    return 0;
 }
+
+hipError_t launch_rb(int k, const RbArgs& a, int wide, hipStream_t s) {
+    switch (k) {
+        case 3: return launch_rb_kt3(a, wide, s);
+        case 5: return launch_rb_kt5(a, wide, s);
+        case 7: return launch_rb_kt7(a, wide, s);
+        case 11: return launch_rb_kt11(a, wide, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---- launch-policy switches: ONE configuration, read from the environment once (first use) and changed afterwards only
+// through the amp_set_* entry points the tests use for their bitwise A/B comparisons.  Nothing on a launch path calls getenv.
+//   AMP_PRECISION     f32 | f16x3       arithmetic of the conv contractions (amp_set_precision), read in precision()
+//   AMP_FUSE_PAIRS    0                 every ResBlock pair as two conv launches
+//   AMP_PAIR_STRIP    0 | 1             per-tile pair kernel everywhere | four-wave strips wherever built (default: the policy)
+//   AMP_RB_FUSION     0 .. 3            whole-ResBlock kernel: off | policy (default) | wherever built | + four-wave tiles
+//   AMP_CONV_BLK      0 .. 3            row-blocked conv kernel forms (default 3)
+//   AMP_GROUP_MB      n                 depth-first batch groups of n MB (default 0 = off)
+constexpr int kConvBlkDefault = 3;
+struct Config {
+    int fuse_pairs = 1;
+    int pair_strips = -1;      // -1 policy, 0 per-tile kernel, 1 four-wave strips
+    int rb_fusion = 1;
+    int conv_blk = kConvBlkDefault;
+    size_t group_bytes = 0;
+    // no environment form: bit-identical A/B switches for the tests (amp_set_small_conv / _conv_rg_fast / _pingpong / _fuse_act)
+    int small_conv = 1;
+    int conv_rg_fast = 1;
+    int pingpong = 1;
+    int fuse_act = 0;
+    Config() {
+        auto num = [](const char* name, int lo, int hi, int dflt) {
+            const char* e = getenv(name);
+            if (!e || !*e) return dflt;
+            const int v = atoi(e);
+            return (v < lo || v > hi) ? dflt : v;
+        };
+        fuse_pairs = num("AMP_FUSE_PAIRS", 0, 1, 1);
+        pair_strips = num("AMP_PAIR_STRIP", 0, 1, -1);
+        rb_fusion = num("AMP_RB_FUSION", 0, 3, 1);
+        conv_blk = num("AMP_CONV_BLK", 0, 3, kConvBlkDefault);
+        const char* e = getenv("AMP_GROUP_MB");
+        group_bytes = (e && atol(e) > 0) ? (size_t)atol(e) << 20 : 0;
+    }
+};
+static Config& cfg() { static Config c; return c; }
+static bool fuse_pairs_enabled() { return cfg().fuse_pairs != 0; }
 
 // Which fused-pair kernel a (C, k) pair runs.  Results are bit-identical either way (tests/test_gpu_pair.py); the choice
 // is measured (profiles/r2_cd_strip_kernel.txt, r2_j_strip_policy.txt): the strip-mined kernel (pair_strip_f16x3.hip)
@@ -266,43 +341,17 @@ static bool fuse_pairs_enabled() {
 // MFMA) wins 2-5 % for k >= 7 at C = 128 -- the policy at the end of strip_choice().
 //   amp_set_pair_strips(-1) / AMP_PAIR_STRIP unset: the measured policy below;  0: per-tile kernel everywhere
 //   (round 1);  1: strips wherever they are built (incl. C = 256, which has no per-tile form).
-struct StripChoice { bool use; int wide; int steps; };   // steps = 0: the planner sizes the strips
-static int g_pair_strips = -2;
+struct StripChoice { bool use; int wide; int steps; };   // wide: 0 four-wave strips, 3 the A-ring form; steps = 0: the planner sizes the strips
 static StripChoice strip_choice(int C, int k) {
-    if (g_pair_strips == -2) {
-        const char* e = getenv("AMP_PAIR_STRIP");
-        g_pair_strips = !e ? -1 : (!strcmp(e, "1") ? 1 : (!strcmp(e, "0") ? 0 : -1));
-    }
-    if (g_pair_strips == 0) return {false, 0, 0};
-    if (g_pair_strips == 1) return {true, 0, 0};
-    // experiment switches (unset = the policy below; 0 = per-tile kernel): AMP_STRIP_K11 for the k = 11, C = 128 pairs only,
-    // AMP_STRIP_C128 for every C = 128 pair.  1 narrow strips, planner | 2 wide tiles | 3 wide, 2 steps | 4 wide, planner |
-    // 5 / 6 / 7: the 4-wave 2 x 2-blocked variant (64 rows x 96 columns per wave, one workgroup per CU) as tiles /
-    // 2 steps / planner; 8 / 9: its A-ring form (64 rows x 128 columns per wave) with 1 / 2 steps per strip
-    static const int k11 = [] { const char* e = getenv("AMP_STRIP_K11"); return e ? atoi(e) : -1; }();
-    static const int c128 = [] { const char* e = getenv("AMP_STRIP_C128"); return e ? atoi(e) : -1; }();
-    static const int c64 = [] { const char* e = getenv("AMP_STRIP_C64"); return e ? atoi(e) : -1; }();   // same codes, C = 64
-    const int v = (C == 128 && c128 >= 0) ? c128 : ((C == 64 && c64 >= 0) ? c64 : ((C == 128 && k == 11 && k11 >= 0) ? k11 : -1));
-    switch (v) {
-        case 0: return {false, 0, 0};
-        case 1: return {true, 0, 0};
-        case 2: return {true, 1, 1};
-        case 3: return {true, 1, 2};
-        case 4: return {true, 1, 0};
-        case 5: return {true, 2, 1};
-        case 6: return {true, 2, 2};
-        case 7: return {true, 2, 0};
-        case 8: return {true, 3, 1};
-        case 9: return {true, 3, 2};
-        default: break;
-    }
-    // measured policy (profiles/r2_o_policy.txt, rocprofv3 per-kernel averages inside the forward, config 2): the
-    // 2 x 2-blocked 4-wave variant in strips of two steps wins at C = 128 for k = 11 (2 122 -> 2 024 us) and k = 7
-    // (1 372 -> 1 321 us) and loses for k = 3 (684 -> 748 us); every other shape stays on the per-tile kernel
-    // third session (profiles/r2_aw_strip_ring.txt): the same form with an A-fragment ring and 64 x 128-column wave tiles
-    // (wide = 3, pair_strip_f16x3.hip), one 256-column step per strip: k = 11 1.86 ms against 2.23 for the per-tile kernel in
-    // the same process (the whole-chunk form above: 0.957 of the per-tile kernel), k = 7 1.27 against 1.43.
-    // AMP_STRIP_C128=6 selects the whole-chunk form again (A/B switch), 8 / 9 the ring form with one / two steps per strip.
+    const int mode = cfg().pair_strips;
+    if (mode == 0) return {false, 0, 0};
+    if (mode == 1) return {true, 0, 0};
+    // measured policy.  C = 128, k in {7, 11}: the 2 x 2-blocked strips with an A-fragment ring, 64 x 128-column wave tiles, one
+    // 256-column step per strip (pair_strip_f16x3.hip; profiles/r2_aw_strip_ring.txt: k = 11 1.86 ms against 2.23 for the per-tile
+    // kernel, k = 7 1.27 against 1.43; inside the forward 1.88 / 1.31 ms, profiles/r3_a_kernel_stats.csv).  Everything else: per-tile
+    // kernel (the four-wave strips win 1.5 % at C = 128, k = 11 only; wide 8-wave tiles, de-phased workgroups and the whole-chunk
+    // 2 x 2 form were measured neutral or slower in round 2 and are gone; the C = 64 ring strips won 5 % at k = 11 in round 3's
+    // first visit and were then overtaken by the whole-resblock kernel, rb_form() below -- removed as unreachable).
     if (C == 128 && (k == 7 || k == 11)) return {true, 3, 1};
     return {false, 0, 0};
 }
@@ -330,12 +379,8 @@ static void strip_plan(int B, int T, int n1, int hb, int wg_per_cu, int* strip_l
 // Half-width conv tiles (NI = 2) for launches that would leave most CUs idle (a single utterance): conv_run()
 // picks them when the full-width grid has fewer workgroups than kSmallGridWorkgroups (the chip holds 2 per CU).
 // One 3-s utterance 1.56 -> 1.24 ms, one 10-s utterance 2.80 -> 2.38 ms; the frame-rate convs of VITS (short
-// contractions) neither gain nor lose (profiles/r1_exp_small_tiles.txt).  AMP_SMALL_TILES=0 switches them off.
+// contractions) neither gain nor lose (profiles/r1_exp_small_tiles.txt).
 constexpr long long kSmallGridWorkgroups = 384;
-static bool small_tiles_enabled() {
-    static const bool on = [] { const char* e = getenv("AMP_SMALL_TILES"); return !(e && !strcmp(e, "0")); }();
-    return on;
-}
 
 hipError_t launch_conv_h_act_kt3(const ConvPlan&, const ConvArgs&, hipStream_t);
 hipError_t launch_conv_h_act_kt5(const ConvPlan&, const ConvArgs&, hipStream_t);
@@ -368,16 +413,9 @@ hipError_t launch_conv_small(int KT, int ni, int epi, const ConvArgs& a, hipStre
 }
 
 // Frame-rate convs (K = Cin * k short, grids of a few hundred workgroups) run on conv_small_f16x3.hip: whole-K
-// staging, one memory latency instead of one per chunk (same bits as conv_f16x3.hip).  AMP_SMALL_CONV=0 /
+// staging, one memory latency instead of one per chunk (same bits as conv_f16x3.hip).
 // amp_set_small_conv(0) keeps them on the pipelined kernel (A/B switch, tests/test_gpu_conv.py).
-static int g_small_conv = -1;
-static bool small_conv_enabled() {
-    if (g_small_conv < 0) {
-        const char* e = getenv("AMP_SMALL_CONV");
-        g_small_conv = (e && !strcmp(e, "0")) ? 0 : 1;
-    }
-    return g_small_conv != 0;
-}
+static bool small_conv_enabled() { return cfg().small_conv != 0; }
 
 // Row-blocked conv kernel (conv_blk_f16x3.hip: 64 rows per wave, 256 per workgroup) for the short tap loops -- the
 // transposed convs (2 taps per chunk) and k = 3 convs -- whose GEMM rows are a multiple of 256; same bits as
@@ -391,19 +429,10 @@ hipError_t launch_conv_blk_kt2(int, const ConvArgs&, hipStream_t);
 hipError_t launch_conv_blk_kt3(int, const ConvArgs&, hipStream_t);
 hipError_t launch_conv_blk_kt7(int, const ConvArgs&, hipStream_t);
 hipError_t launch_conv_blk_kt11(int, const ConvArgs&, hipStream_t);
-constexpr int kConvBlkDefault = 3;
-static int g_conv_blk = -1;
-static int conv_blk_mode() {
-    if (g_conv_blk < 0) {
-        const char* e = getenv("AMP_CONV_BLK");
-        g_conv_blk = e ? atoi(e) : kConvBlkDefault;
-        if (g_conv_blk < 0 || g_conv_blk > 3) g_conv_blk = kConvBlkDefault;
-    }
-    return g_conv_blk;
-}
+static int conv_blk_mode() { return cfg().conv_blk; }
 // Convs with more than one row group (M > 32 * WM rows: the C = 256 stage, the transposed convs' polyphase rows) launch a
 // 1-D grid with the row group as the fastest index, so that the row groups of one x tile run back to back on one XCD and x
-// comes from HBM once (ConvArgs::row_groups).  AMP_CONV_RG_FAST=0 / amp_set_conv_rg_fast(0): the 2-D grid (row group =
+// comes from HBM once (ConvArgs::row_groups).  amp_set_conv_rg_fast(0): the 2-D grid (row group =
 // blockIdx.y, dispatched a whole grid.x apart).
 // Only while the packed weights of ALL row groups fit one XCD's 4-MB L2 beside the activations (<= 3 MB): the workgroups
 // resident on an XCD then stream every row group's A fragments at once.  Measured (profiles/r2_ak_row_group_order.txt,
@@ -412,27 +441,15 @@ static int conv_blk_mode() {
 // HBM-bound: the bytes are energy, not time).
 constexpr size_t kConvRgFastMaxWeightBytes = 3u << 20;
 constexpr int kConvRgFastDefault = 1;
-static int g_conv_rg_fast = -1;
-static bool conv_rg_fast() {
-    if (g_conv_rg_fast < 0) {
-        const char* e = getenv("AMP_CONV_RG_FAST");
-        g_conv_rg_fast = e ? (atoi(e) != 0) : kConvRgFastDefault;
-    }
-    return g_conv_rg_fast != 0;
-}
+static bool conv_rg_fast() { return cfg().conv_rg_fast != 0; }
 // Ping-pong tile order: every other conv / pair launch walks its tiles from the last item's end backwards, so that it starts
-// on the part of its input the previous launch wrote last (still in the Infinity Cache).  AMP_PINGPONG / amp_set_pingpong.
+// on the part of its input the previous launch wrote last (still in the Infinity Cache).  amp_set_pingpong.
 // Measured (profiles/r2_am_pingpong.txt, one box, alternating runs): config 2 30.99 -> 30.87 ms, the gain in the HBM-leaning
 // stages (C = 64: 7.20 -> 7.15 ms, C = 32: 4.40 -> 4.32 ms); C3 / C5 unchanged.
 constexpr int kPingPongDefault = 1;
-static int g_pingpong = -1;
 static thread_local unsigned g_launch_parity = 0;
 static int next_rev(const int* lens) {
-    if (g_pingpong < 0) {
-        const char* e = getenv("AMP_PINGPONG");
-        g_pingpong = e ? (atoi(e) != 0) : kPingPongDefault;
-    }
-    if (!g_pingpong || lens) return 0;   // ragged batches keep the dispatch order
+    if (!cfg().pingpong || lens) return 0;   // ragged batches keep the dispatch order
     return (int)(g_launch_parity++ & 1u);
 }
 // the blocked launch fills the chip only when its (half as many) workgroups still give every CU its two
@@ -590,13 +607,8 @@ static bool small_conv_static_ok(const amp_conv* c) {
 }
 static bool small_conv_covers(const amp_conv* c) { return small_conv_enabled() && small_conv_static_ok(c); }
 // tile width of the whole-K kernel in 32-column units: 128 x 32 tiles (two workgroups per CU) when the receptive field
-// fits their 32-column halo, else 128 x 64.  AMP_SMALL_NI=1|2 forces one (A/B switch; 1 only where it fits).
-static int small_conv_ni(const amp_conv* c) {
-    static const int forced = [] { const char* e = getenv("AMP_SMALL_NI"); return e ? atoi(e) : 0; }();
-    const bool fits1 = c->halo_left + c->halo_right <= 32;
-    if (forced == 2 || !fits1) return 2;
-    return 1;
-}
+// fits their 32-column halo, else 128 x 64.
+static int small_conv_ni(const amp_conv* c) { return (c->halo_left + c->halo_right <= 32) ? 1 : 2; }
 
 // mode 0: y = v, 1: y += v, 2: y = (y + v) / div
 static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope_in, const float* res, float slope_out,
@@ -610,7 +622,7 @@ static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope
     a.B = B; a.Cin = c->cin; a.Tin = T; a.xbs = xbs > 0 ? xbs : (long long)c->cin * T; a.nchunks = c->nchunks; a.M = c->M;
     a.Tq = c->transposed ? T + c->ntaps - 1 : Tout;
     ConvPlan plan = c->plan;
-    if (c->precision == PREC_F16X3 && small_tiles_enabled()) {
+    if (c->precision == PREC_F16X3) {
         // a grid that leaves most CUs idle (a single utterance): half-width tiles, twice the workgroups
         const long long wgs = (long long)B * ((a.Tq + plan.NT() - 1) / plan.NT()) * ((c->M + plan.Mgroup() - 1) / plan.Mgroup());
         if (wgs < kSmallGridWorkgroups) plan.NI = 2;
@@ -679,15 +691,8 @@ static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope
 // profiles/r2_y_conv_act_fused.txt: the conv launches grow by 110-145 us each, as much as the act1d launch they
 // replace, plus 14 % recomputed margin: C3 27.6 vs 26.8 ms).  The activation is VALU + LDS work that the stand-alone
 // kernel runs at 8 waves per SIMD under its own HBM stream; behind a conv it runs at 2 waves per SIMD and overlaps
-// nothing.  Off unless AMP_FUSE_ACT=1 / amp_set_fuse_act(1).
-static int g_fuse_act = -1;
-static bool fuse_act_enabled() {
-    if (g_fuse_act < 0) {
-        const char* e = getenv("AMP_FUSE_ACT");
-        g_fuse_act = (e && !strcmp(e, "1")) ? 1 : 0;
-    }
-    return g_fuse_act != 0;
-}
+// nothing.  Off unless amp_set_fuse_act(1).
+static bool fuse_act_enabled() { return cfg().fuse_act != 0; }
 
 // conv + Activation1d in one launch is built for: f16x3, Conv1d with 'same' zero padding, k in {3, 5, 7, 11}, a bias,
 // rows a multiple of the kernel's row group; the launch must be large enough for full-width tiles
@@ -762,24 +767,102 @@ static int pair_run(const amp_conv* c1, const amp_conv* c2, const float* x, int 
     if (n1 > 0) {
         a.wide = sc.wide;
         strip_plan(B, T, n1, c1->k - 1, wg, &a.strip_len, &a.strips_per_item);
-        int steps = sc.steps;
-        { const char* e = getenv("AMP_STRIP_STEPS"); if (e && atoi(e) > 0) steps = atoi(e); }
+        const int steps = sc.steps;
         if (steps > 0 && steps * n1 - (c1->k - 1) < T) { a.strip_len = steps * n1 - (c1->k - 1); a.strips_per_item = (T + a.strip_len - 1) / a.strip_len; }
         // one workgroup per CU: a grid that cannot fill the chip twice over (a single utterance) is better served by the
         // 4x as many independent tiles of the per-tile kernel (same bits)
-        if (g_pair_strips == -1 && sc.wide >= 2 && (long long)B * a.strips_per_item < 512 && pair_tile(c1->k, c1->cin, c1->dilation) > 0) {
+        if (cfg().pair_strips == -1 && sc.wide >= 2 && (long long)B * a.strips_per_item < 512 && pair_tile(c1->k, c1->cin, c1->dilation) > 0) {
             const int NT = pair_tile(c1->k, c1->cin, c1->dilation);
             a.tiles_per_item = (T + NT - 1) / NT;
             AMP_HIP(launch_pair(c1->k, a, stream));
             return AMP_OK;
         }
-        { const char* e = getenv("AMP_STRIP_STAGGER"); a.stagger = e ? atoi(e) : 0; e = getenv("AMP_STRIP_STAGGER_MODE"); a.stagger_mode = e ? atoi(e) : 1; }
         AMP_HIP(launch_strip(c1->k, a, stream));
         return AMP_OK;
     }
     const int NT = pair_tile(c1->k, c1->cin, c1->dilation);
     a.tiles_per_item = (T + NT - 1) / NT;
     AMP_HIP(launch_pair(c1->k, a, stream));
+    return AMP_OK;
+}
+
+// Whole ResBlock1 in one launch (rb_f16x3.hip): x read once, y written once per resblock, the residual carried in
+// registers; bit-identical to the chain of fused pairs.  amp_set_resblock_fusion / AMP_RB_FUSION: 0 off (three pair
+// launches), 1 (default) the measured policy below, 2 every shape the kernel is built for, 3 = 2 with the four-wave
+// 512-column tiles at C = 32 (two workgroups per CU) instead of the eight-wave 1024-column ones.
+static int rb_fusion_mode() { return cfg().rb_fusion; }
+// form of the kernel for (C, k): -1 = run the pairs
+static int rb_form(int C, int k) {
+    const int m = rb_fusion_mode();
+    if (m == 0) return -1;
+    if (m == 3) return C == 32 ? 0 : 1;
+    if (m == 2) return 1;
+    // policy: measured INSIDE the config-2 forward at thermal steady state, one box, modes alternating
+    // (profiles/r3_e_inforward_resblock_modes_and_list_api_probe.txt; ms per resblock, fused pairs -> this kernel):
+    //   C = 32  k = 3 0.99 -> 0.56, k = 7 1.38 -> 1.12 with the four-wave 512-column tiles (two workgroups per CU: one's seams run
+    //           under the other's MFMAs; the eight-wave 1024-column tiles: 0.66 / 1.15); k = 11 1.77 -> 1.70 with the EIGHT-wave
+    //           tiles (13 % recomputed halo instead of 31 %; four-wave: 1.79)
+    //   C = 64  (eight waves, 512 columns) k = 3 1.27 -> 0.98, k = 7 2.22 -> 2.05, k = 11 3.42 (ring strips) -> 3.40: a draw in time
+    //           at a third of the HBM traffic -- op-level, at boost clocks, the same launch is 2.5 ms (r3_c_resblock_k11.txt): under
+    //           the package power limit what counts is energy per output, and 31 % recomputed MFMAs cancel the saved HBM round trips
+    //   C = 128 k = 3 (eight waves, 256 columns, 16 guard columns: 147 KB) 1.91 -> 1.70; k = 5 2.70 -> 2.53 op-level
+    // forward 29.15 -> 27.5 ms on that box.
+    if (C == 32) return k >= 11 ? 1 : 0;
+    if (C == 64 || C == 128) return 1;           // C = 128: k <= 5 only (rb_tile)
+    return -1;
+}
+// the workgroups of a launch must fill the chip (256 CUs) at least twice over; a single utterance keeps the pairs' 4x more
+// numerous tiles (same bits)
+constexpr long long kRbMinWorkgroups = 512;
+
+static bool rb_supported(const std::vector<std::unique_ptr<amp_conv>>& c1, const std::vector<std::unique_ptr<amp_conv>>& c2, int B, int T) {
+    const int np = (int)c1.size();
+    if (np < 1 || np > AMP_RB_MAX_PAIRS || (int)c2.size() != np) return false;
+    int max_dil = 1, rh = 0;
+    for (int p = 0; p < np; ++p) {
+        if (!pair_supported(c1[p].get(), c2[p].get())) return false;
+        if (c1[p]->cin != c1[0]->cin || c1[p]->k != c1[0]->k) return false;
+        max_dil = c1[p]->dilation > max_dil ? c1[p]->dilation : max_dil;
+        rh += (c1[p]->k - 1) / 2 * (c1[p]->dilation + 1);
+    }
+    const int form = rb_form(c1[0]->cin, c1[0]->k);
+    if (form < 0) return false;
+    const int W = rb_tile(c1[0]->k, c1[0]->cin, max_dil, form);
+    if (W <= 0 || W - 2 * rh < W / 2) return false;          // at least half of every tile must be output
+    const int NT = W - 2 * rh;
+    if (rb_fusion_mode() == 1 && (long long)B * ((T + NT - 1) / NT) < kRbMinWorkgroups) return false;
+    return true;
+}
+
+static int rb_run(const std::vector<std::unique_ptr<amp_conv>>& c1, const std::vector<std::unique_ptr<amp_conv>>& c2, const float* x,
+                  int B, int T, float slope, float* y, int mode, float div, hipStream_t stream, const int* lens = nullptr, int len_mul = 1) {
+    if (x == y) { set_error("rb_run: x and y must not alias"); return AMP_ERR_INVALID; }
+    if (slope > 1.f) { set_error("rb_run: leaky_relu slope %g > 1 is outside the fused kernels", (double)slope); return AMP_ERR_UNSUPPORTED; }
+    RbArgs a{};
+    a.x = x; a.y = y;
+    a.np = (int)c1.size();
+    int max_dil = 1;
+    for (int p = 0; p < a.np; ++p) {
+        a.wp1[p] = c1[p]->wp_dev; a.bias1[p] = c1[p]->bias_dev; a.wp2[p] = c2[p]->wp_dev; a.bias2[p] = c2[p]->bias_dev;
+        a.sc1[p] = 16.f * c1[p]->wscale; a.isc1[p] = 1.f / a.sc1[p];
+        a.sc2[p] = 16.f * c2[p]->wscale; a.isc2[p] = 1.f / a.sc2[p];
+        a.dil[p] = c1[p]->dilation;
+        a.rh += (c1[p]->k - 1) / 2 * (c1[p]->dilation + 1);
+        max_dil = c1[p]->dilation > max_dil ? c1[p]->dilation : max_dil;
+    }
+    for (int p = a.np; p < AMP_RB_MAX_PAIRS; ++p) {   // never dereferenced; keep the pointers valid all the same
+        a.wp1[p] = a.wp1[0]; a.bias1[p] = a.bias1[0]; a.wp2[p] = a.wp2[0]; a.bias2[p] = a.bias2[0]; a.dil[p] = 1;
+    }
+    a.B = B; a.C = c1[0]->cin; a.T = T;
+    const int form = rb_form(a.C, c1[0]->k);
+    const int W = rb_tile(c1[0]->k, a.C, max_dil, form);
+    const int NT = W - 2 * a.rh;
+    a.tiles_per_item = (T + NT - 1) / NT;
+    a.slope = slope; a.mode = mode; a.div = div;
+    a.lens = lens; a.len_mul = len_mul;
+    a.range_flag = range_flag_for_current_device();
+    a.rev = next_rev(lens);
+    AMP_HIP(launch_rb(c1[0]->k, a, form, stream));
     return AMP_OK;
 }
 
@@ -834,16 +917,8 @@ struct amp_gen {
     std::vector<ProfSlot> prof;          // empty = profiling off
     size_t prof_count = 0;               // forwards recorded so far
     RangeGuard guard;                    // this handle's f16 operand-range word (allocated by finalize on its device)
-    // concurrent resblocks (BigVGAN): side streams for resblocks 1 .. n_kernels-1, fork / accumulate-order events
-    int n_side = 0;
-    hipStream_t side[AMP_MAX_KERNELS] = {};
-    hipEvent_t ev_fork = nullptr;
-    hipEvent_t ev_last[AMP_MAX_KERNELS] = {};
     ~amp_gen() {
         guard_free(guard);
-        for (int i = 0; i < n_side; ++i) if (side[i]) (void)hipStreamDestroy(side[i]);
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
-        for (auto e : ev_last) if (e) (void)hipEventDestroy(e);
         for (float* p : dev_allocs) (void)hipFree(p);
         for (auto& p : prof) {
             if (p.ev_begin) (void)hipEventDestroy(p.ev_begin);
@@ -1146,15 +1221,6 @@ int amp_gen_finalize(amp_gen* g) {
         if ((rc = upload(g, w.data(), w.size(), &g->post_w_dev)) != AMP_OK) return rc;
         if (bias) if ((rc = upload(g, bias, 1, &g->post_b_dev)) != AMP_OK) return rc;
     }
-    {
-        const char* e = getenv("AMP_BIGVGAN_STREAMS");
-        const bool want = g->d.arch == AMP_ARCH_BIGVGAN && g->d.n_kernels > 1 && e && !strcmp(e, "1");
-        if (want) {
-            AMP_HIP(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
-            for (int j = 0; j < g->d.n_kernels; ++j) AMP_HIP(hipEventCreateWithFlags(&g->ev_last[j], hipEventDisableTiming));
-            for (int j = 0; j + 1 < g->d.n_kernels; ++j) { AMP_HIP(hipStreamCreateWithFlags(&g->side[j], hipStreamNonBlocking)); g->n_side = j + 1; }
-        }
-    }
     if (!guard_init(g->guard)) { set_error("amp_gen_finalize: cannot allocate the range-guard word"); return AMP_ERR_HIP; }
     g->w.clear();  // host copies no longer needed
     g->finalized = true;
@@ -1174,17 +1240,9 @@ static size_t gen_buf_elems(const amp_gen* g, int B, int T) {
     return (mx + 63) & ~(size_t)63;
 }
 
-// BigVGAN's forward alternates MFMA-bound convs with VALU-bound anti-aliased activations (a third of its time):
-// the n_kernels resblocks of a stage are independent until they accumulate into the MRF sum, so each runs on its
-// own stream (own R / TMP / ACT scratch) and the activation waves of one can fill the VALU slots under the conv waves
-// of another (they fit beside them: 64 VGPRs next to 2 x 223).  Opt-in with AMP_BIGVGAN_STREAMS=1: on MI355X the
-// kernels do overlap (rocprofv3: act1d launches 132 -> 250 us, convs 380 -> 820 us while co-resident) but the forward
-// takes the same 28.1 ms (profiles/r2_i_bigvgan_streams.txt) -- the package power limit, not issue slots, is the bound.
-static bool gen_concurrent(const amp_gen* g) { return g->n_side > 0; }
-static int gen_num_bufs(const amp_gen* g) {
-    if (gen_concurrent(g)) return 3 + 3 * g->d.n_kernels;
-    return g->d.arch == AMP_ARCH_BIGVGAN ? 6 : 5;
-}
+// scratch tensors of a forward: X, XS, U, R, TMP (+ ACT for BigVGAN).  (Round 2 also ran BigVGAN's resblocks of a stage on concurrent
+// streams: the kernels overlapped and the forward took the same 28.1 ms, profiles/r2_i_bigvgan_streams.txt -- removed.)
+static int gen_num_bufs(const amp_gen* g) { return g->d.arch == AMP_ARCH_BIGVGAN ? 6 : 5; }
 
 // Optional depth-first batch grouping: a group of items runs through the WHOLE generator before the
 // next one starts, with a working set (the scratch tensors of its largest stage) bounded by
@@ -1192,14 +1250,7 @@ static int gen_num_bufs(const amp_gen* g) {
 // is OFF by default (0 = whole batch per layer): sized to the 256 MiB Infinity Cache it was measured
 // SLOWER on MI355X (36.2 ms ungrouped vs 45.6 / 49.9 / 62.4 ms at 200 / 144 / 104 MB groups,
 // profiles/r1_exp_group.txt) -- the small grids under-fill 256 CUs and the cache brings no bandwidth win.
-static size_t g_group_bytes = (size_t)-1;
-static size_t group_target_bytes() {
-    if (g_group_bytes == (size_t)-1) {
-        const char* e = getenv("AMP_GROUP_MB");
-        g_group_bytes = e ? (size_t)atol(e) << 20 : 0;
-    }
-    return g_group_bytes;
-}
+static size_t group_target_bytes() { return cfg().group_bytes; }
 
 static int gen_group_items(const amp_gen* g, int B, int T) {
     const size_t target = group_target_bytes();
@@ -1219,13 +1270,13 @@ size_t amp_gen_workspace_bytes(const amp_gen* g, int B, int T) {
 
 int amp_set_pair_strips(int on) {
     if (on < -1 || on > 1) { set_error("amp_set_pair_strips: %d", on); return AMP_ERR_INVALID; }
-    g_pair_strips = on;
+    cfg().pair_strips = on;
     return AMP_OK;
 }
 
 int amp_set_group_mb(int megabytes) {
     if (megabytes < 0) { set_error("amp_set_group_mb: %d", megabytes); return AMP_ERR_INVALID; }
-    g_group_bytes = (size_t)megabytes << 20;
+    cfg().group_bytes = (size_t)megabytes << 20;
     return AMP_OK;
 }
 
@@ -1321,7 +1372,6 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
     float* R = base + 3 * be;   // running x inside a resblock
     float* TMP = base + 4 * be; // xt between the two convs of a pair
     float* ACT = big ? base + 5 * be : nullptr;  // anti-aliased activation output
-    const bool conc = gen_concurrent(g);         // BigVGAN: the resblocks of a stage on separate streams (buffers 3 + 3 j ..)
     float* CB = base + (size_t)gen_num_bufs(g) * be;  // cond(g): [B, C0]
     const float slope = 0.1f;  // LRELU_SLOPE hifigan.py:14
 
@@ -1340,24 +1390,12 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
         t *= d.upsample_rates[i];
         lm *= d.upsample_rates[i];
         if (ev_mrf) AMP_HIP(hipEventRecord(ev_mrf[2 * i], st));
-        if (conc) AMP_HIP(hipEventRecord(g->ev_fork, st));
         for (int j = 0; j < nk; ++j) {
-            // BigVGAN with concurrent resblocks: resblock j runs on its own stream with its own R / TMP / ACT buffers
-            // (they all read U); only the last conv of each touches XS, and those are chained j-1 -> j by events
             hipStream_t sj = st;
             float* R_ = R;
             float* TMP_ = TMP;
             float* ACT_ = ACT;
-            if (conc) {
-                R_ = base + (size_t)(3 + 3 * j) * be;
-                TMP_ = R_ + be;
-                ACT_ = TMP_ + be;
-                if (j > 0) {
-                    sj = g->side[j - 1];
-                    AMP_HIP(hipStreamWaitEvent(sj, g->ev_fork, 0));
-                }
-            }
-            if (ev_rb && !conc) AMP_HIP(hipEventRecord(ev_rb[(size_t)i * (nk + 1) + j], sj));
+            if (ev_rb) AMP_HIP(hipEventRecord(ev_rb[(size_t)i * (nk + 1) + j], sj));
             // profiled forward: every launch of this resblock logs its kernel's name (note_kernel, amp_internal.h)
             struct LogScope { LogScope(std::string* p) { tl_kernel_log = p; if (p) p->clear(); } ~LogScope() { tl_kernel_log = nullptr; } }
                 log_scope(rb_names ? &(*rb_names)[(size_t)i * nk + j] : nullptr);
@@ -1365,10 +1403,13 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
             const int nd = (int)rb.dil.size();
             const int mode_last = (nk == 1) ? 0 : (j == 0 ? 0 : (j == nk - 1 ? 2 : 1));
             const float* cur = U;
+            if (d.resblock_type == 1 && !big && rb_supported(rb.c1, rb.c2, B, t)) {
+                // the whole resblock in one launch: U -> XS (x and the residual never leave the CU in between)
+                AMP_RC(rb_run(rb.c1, rb.c2, U, B, t, slope, XS, mode_last, (float)nk, sj, lens, lm));
+                continue;
+            }
             for (int p = 0; p < nd; ++p) {
                 const bool last = p == nd - 1;
-                // every launch of the last pair / conv comes after the previous resblock's accumulation into XS
-                if (conc && last && j > 0) AMP_HIP(hipStreamWaitEvent(sj, g->ev_last[j - 1], 0));
                 if (d.resblock_type == 1) {
                     if (!big && pair_supported(rb.c1[p].get(), rb.c2[p].get())) {
                         // the whole pair in one kernel; the output ping-pongs R_ <-> TMP_ (never in place:
@@ -1426,9 +1467,7 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
                     }
                 }
             }
-            if (conc) AMP_HIP(hipEventRecord(g->ev_last[j], sj));
         }
-        if (conc) AMP_HIP(hipStreamWaitEvent(st, g->ev_last[nk - 1], 0));   // join: the chain j-1 -> j orders every side stream before this
         if (ev_rb) AMP_HIP(hipEventRecord(ev_rb[(size_t)i * (nk + 1) + nk], st));
         if (ev_mrf) AMP_HIP(hipEventRecord(ev_mrf[2 * i + 1], st));
         float* tmp = X; X = XS; XS = tmp;  // x = xs / num_kernels
@@ -1522,23 +1561,23 @@ int amp_conv_create(int transposed, int cin, int cout, int k, int stride, int di
 }
 
 int amp_set_small_conv(int on) {
-    g_small_conv = on ? 1 : 0;
+    cfg().small_conv = on ? 1 : 0;
     return AMP_OK;
 }
 
 int amp_set_pingpong(int on) {
-    g_pingpong = on < 0 ? -1 : (on ? 1 : 0);   // -1: back to AMP_PINGPONG / the default
+    cfg().pingpong = on < 0 ? kPingPongDefault : (on ? 1 : 0);   // -1: back to the default
     return AMP_OK;
 }
 
 int amp_set_conv_rg_fast(int on) {
-    g_conv_rg_fast = on < 0 ? -1 : (on ? 1 : 0);   // -1: back to AMP_CONV_RG_FAST / the default
+    cfg().conv_rg_fast = on < 0 ? kConvRgFastDefault : (on ? 1 : 0);   // -1: back to the default
     return AMP_OK;
 }
 
 int amp_set_conv_blk(int mode) {
     if (mode < -1 || mode > 3) { set_error("amp_set_conv_blk: mode %d (0 off, 1 | 2 chunks per staging round, 3 = 2 + k = 7 / 11, -1 default)", mode); return AMP_ERR_INVALID; }
-    g_conv_blk = mode;
+    cfg().conv_blk = mode < 0 ? kConvBlkDefault : mode;
     return AMP_OK;
 }
 
@@ -1625,7 +1664,7 @@ int amp_wn_forward(const amp_conv* const* in_layers, const amp_conv* const* res_
 }
 
 int amp_set_fuse_act(int on) {
-    g_fuse_act = on ? 1 : 0;
+    cfg().fuse_act = on ? 1 : 0;
     return AMP_OK;
 }
 
@@ -1670,6 +1709,29 @@ int amp_pair_forward(const amp_conv* c1, const amp_conv* c2, const float* x_dev,
         return AMP_ERR_UNSUPPORTED;
     }
     return pair_run(c1, c2, x_dev, B, T, slope, y_dev, 0, 1.f, (hipStream_t)stream);
+}
+
+int amp_resblock_forward(const amp_conv* const* c1, const amp_conv* const* c2, int n_pairs, const float* x_dev, int B, int T,
+                         float slope, float* y_dev, void* stream) {
+    if (!c1 || !c2 || !x_dev || !y_dev) { set_error("amp_resblock_forward: null argument"); return AMP_ERR_INVALID; }
+    if (B <= 0 || T <= 0 || n_pairs < 1 || n_pairs > AMP_RB_MAX_PAIRS) { set_error("amp_resblock_forward: B=%d T=%d n_pairs=%d", B, T, n_pairs); return AMP_ERR_INVALID; }
+    // borrowed handles in the containers rb_supported / rb_run take; released (not destroyed) on every path
+    std::vector<std::unique_ptr<amp_conv>> v1, v2;
+    for (int p = 0; p < n_pairs; ++p) { v1.emplace_back(const_cast<amp_conv*>(c1[p])); v2.emplace_back(const_cast<amp_conv*>(c2[p])); }
+    struct Release { std::vector<std::unique_ptr<amp_conv>>&a, &b; ~Release() { for (auto& p : a) (void)p.release(); for (auto& p : b) (void)p.release(); } } rel{v1, v2};
+    for (int p = 0; p < n_pairs; ++p) if (!c1[p] || !c2[p]) { set_error("amp_resblock_forward: null conv handle"); return AMP_ERR_INVALID; }
+    if (!rb_supported(v1, v2, B, T)) {
+        set_error("amp_resblock_forward: block (C=%d k=%d, %d pairs, B=%d T=%d) is not covered by the whole-resblock kernel under the "
+                  "current amp_set_resblock_fusion mode", c1[0]->cin, c1[0]->k, n_pairs, B, T);
+        return AMP_ERR_UNSUPPORTED;
+    }
+    return rb_run(v1, v2, x_dev, B, T, slope, y_dev, 0, 1.f, (hipStream_t)stream);
+}
+
+int amp_set_resblock_fusion(int mode) {
+    if (mode < -1 || mode > 3) { set_error("amp_set_resblock_fusion: mode=%d", mode); return AMP_ERR_INVALID; }
+    cfg().rb_fusion = mode < 0 ? 1 : mode;
+    return AMP_OK;
 }
 
 int amp_conv_forward_mrf(const amp_conv* c, const float* x_dev, int B, int T, float slope_in, const float* res_dev,

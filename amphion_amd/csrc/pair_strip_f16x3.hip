@@ -21,8 +21,8 @@
 // operations (bias, chunks, taps, the three MFMAs of a term) is that of the per-tile kernel and of
 // conv_f16x3.hip, so the result has the same bits however the time axis is cut (tests/test_gpu_pair.py).
 //
-// WM x WN waves: C = 32 * WM channels (C = 256 runs 8 waves, one workgroup per CU: the xt tile of all 256
-// channels is 108 KB); compiled once per tap count:  -DAMP_KT=<3|5|7|11>.
+// WM x WN waves x MI row blocks per wave: C = 32 * WM * MI channels (C = 256 runs 8 waves, one workgroup per CU: the xt tile
+// of all 256 channels is 108 KB); compiled once per tap count:  -DAMP_KT=<3|5|7|11>.
 #include "amp_internal.h"
 
 #include <stdlib.h>
@@ -172,10 +172,6 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
     const int rd1 = hi * SX + colw;
     const int rd2 = hi * XT + colw;
 
-    if (a.stagger > 0) {   // experiment: de-phase co-resident workgroups
-        const int n = a.stagger_mode == 1 ? (((int)blockIdx.x >> 8) & 1) * a.stagger : ((((int)blockIdx.x >> 3) & 7) * a.stagger) >> 3;
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     int X = O - H2;                           // first xt column of the step
     stage_load(0, X - h1);
 #pragma unroll
@@ -436,23 +432,17 @@ static hipError_t launch_strip_one(const PairArgs& a, hipStream_t stream) {
 
 // Step width (xt columns = output columns per step) for C channels, or 0 when (C, KT, dilation) is not covered;
 // *wg_per_cu = resident workgroups per CU (LDS / register bound), used by the host to size the strips.
-// wide = 3: the 2 x 2-blocked form with an A-fragment ring and 256-column steps (C = 128, k >= 7).
-// wide = 1: 8-wave workgroups with twice the step width, one per CU -- waves (wm, 0) and (wm, 1) fetch the same A
-// fragments (the second hits L1), and the k - 1 seam columns / the dilated halo are paid once per 2 x the columns.
+// wide = 3: the 2 x 2-blocked form with an A-fragment ring -- C = 128, k >= 7: 4 waves x (64 rows x 128 columns), 256-column steps.
+// wide = 0: four waves x (32 rows x NI x 32 columns), two workgroups per CU; C = 256: eight waves, one workgroup per CU.
+// (Round 2's 8-wave double-width tiles and the whole-chunk 2 x 2 form were measured neutral or slower and are gone; so is the
+// C = 64 ring form -- a wave owning all 64 rows x 96 columns, 384-column steps: -5 % at k = 11, then overtaken by rb_f16x3.hip.)
 int AMP_CAT(strip_step_kt, AMP_KT)(int C, int dil, int wide, int* wg_per_cu) {
     constexpr int KT = AMP_KT;
     const int span = (KT - 1) * dil;   // staged halo = 2 * h1
     int n1 = 0, wg = 2;
     if (C == 256) { n1 = (96 + span <= 256) ? 96 : 0; wg = 1; }
-    else if (wide == 3 && C == 128) { n1 = (KT >= 7 && 256 + span <= 320) ? 256 : 0; wg = 1; }    // 4 waves x (64 rows x 128 columns), A ring
-    // C = 64 in the same form (a wave owns all 64 rows x 96 columns, 384-column steps, 130 KB of LDS): built as an experiment
-    // (AMP_STRIP_C64=8 | 9), NOT yet run on hardware and not in the policy
-    else if (wide == 3) { n1 = (C == 64 && KT >= 7 && 384 + span <= 448) ? 384 : 0; wg = 1; }
-    else if (wide == 2 && C == 128) { n1 = (192 + span <= 256) ? 192 : 0; wg = 1; }   // 4 waves x (64 rows x 96 columns)
-    else if (wide == 2 && C == 64) { n1 = (256 + span <= 320) ? 256 : 0; wg = 1; }    // 4 waves x (64 rows x 64 columns)
-    else if (wide && C == 128) { n1 = (192 + span <= 256) ? 192 : 0; wg = 1; }
-    else if (wide && C == 64) { n1 = (256 + span <= 384) ? 256 : 0; wg = 1; }
-    else if (wide && C == 32) { n1 = (512 + span <= 640) ? 512 : 0; wg = 1; }
+    else if (wide == 3 && C == 128) { n1 = (KT >= 7 && 256 + span <= 320) ? 256 : 0; wg = 1; }
+    else if (wide == 3) { n1 = 0; wg = 1; }
     else if (C == 128) n1 = (96 + span <= 192) ? 96 : 0;
     else if (C == 64) n1 = (128 + span <= 192) ? 128 : 0;
     else if (C == 32) n1 = (256 + span <= 320) ? 256 : 0;
@@ -467,16 +457,8 @@ hipError_t AMP_CAT(launch_strip_kt, AMP_KT)(const PairArgs& a, hipStream_t strea
     if (a.wide == 3) {
         if constexpr (KT >= 7) {
             if (a.C == 128) return launch_strip_one<KT, 2, 2, 4, 320, 2, 4, 1>(a, stream);
-            if (a.C == 64) return launch_strip_one<KT, 1, 4, 3, 448, 2, 4, 1>(a, stream);
         }
         return hipErrorInvalidValue;
-    }
-    if (a.wide == 2 && a.C == 128) return launch_strip_one<KT, 2, 2, 3, 256, 2>(a, stream);
-    if (a.wide == 2 && a.C == 64) return launch_strip_one<KT, 1, 4, 2, 320, 2>(a, stream);
-    if (a.wide) {
-        if (a.C == 128) return launch_strip_one<KT, 4, 2, 3, 256>(a, stream);
-        if (a.C == 64) return launch_strip_one<KT, 2, 4, 2, 384>(a, stream);
-        if (a.C == 32) return launch_strip_one<KT, 1, 8, 2, 640>(a, stream);
     }
     if (a.C == 128) return span <= 32 ? launch_strip_one<KT, 4, 1, 3, 128>(a, stream) : launch_strip_one<KT, 4, 1, 3, 192>(a, stream);
     if (a.C == 64) return launch_strip_one<KT, 2, 2, 2, 192>(a, stream);

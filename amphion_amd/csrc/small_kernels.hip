@@ -382,18 +382,10 @@ hipError_t launch_act1d(const float* x, float* y, int B, int C, int T, const flo
     // tiles per workgroup.  Measured on C3 (profiles/r2_uv_act1d.txt): 2 tiles (straight-line, both windows requested at
     // entry) 141 us per launch on average, rolled strips of 8 / 16 / 32 tiles 125.5 / 122.6 / 125.8 us: long-lived
     // workgroups stop paying their start-up 32 768 times per launch.  Strips need a grid that still fills the chip
-    // (2 048 workgroup slots), so small launches (single utterances) keep short ones.  AMP_ACT1D_TILES forces a value.
-    static const int forced = [] { const char* e = getenv("AMP_ACT1D_TILES"); return e ? atoi(e) : 0; }();
-    int ntile = forced;
-    if (ntile == 0) {
-        const long long total = (long long)B * C * ((T + A1_TT - 1) / A1_TT);
-        ntile = total >= 16 * 4096 ? 16 : (total >= 8 * 4096 ? 8 : 2);
-    }
-    if (ntile == 1) return launch_act1d_n<1>(x, y, B, C, T, a_dev, invb_dev, filt_up12, filt_dn12, lens, len_mul, stream, rev);
-    if (ntile == 4) return launch_act1d_n<4>(x, y, B, C, T, a_dev, invb_dev, filt_up12, filt_dn12, lens, len_mul, stream, rev);
-    if (ntile == 8) return launch_act1d_n<8>(x, y, B, C, T, a_dev, invb_dev, filt_up12, filt_dn12, lens, len_mul, stream, rev);
-    if (ntile == 16) return launch_act1d_n<16>(x, y, B, C, T, a_dev, invb_dev, filt_up12, filt_dn12, lens, len_mul, stream, rev);
-    if (ntile == 32) return launch_act1d_n<32>(x, y, B, C, T, a_dev, invb_dev, filt_up12, filt_dn12, lens, len_mul, stream, rev);
+    // (2 048 workgroup slots), so small launches (single utterances) keep short ones.
+    const long long total = (long long)B * C * ((T + A1_TT - 1) / A1_TT);
+    if (total >= 16 * 4096) return launch_act1d_n<16>(x, y, B, C, T, a_dev, invb_dev, filt_up12, filt_dn12, lens, len_mul, stream, rev);
+    if (total >= 8 * 4096) return launch_act1d_n<8>(x, y, B, C, T, a_dev, invb_dev, filt_up12, filt_dn12, lens, len_mul, stream, rev);
     return launch_act1d_n<2>(x, y, B, C, T, a_dev, invb_dev, filt_up12, filt_dn12, lens, len_mul, stream, rev);
 }
 

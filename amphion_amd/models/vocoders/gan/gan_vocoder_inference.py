@@ -25,6 +25,22 @@ def _reference_range(model, run, device):
     return out
 
 
+def _crops_to_host(model, out, lengths):
+    """``[out[i, :lengths[i]] for i]`` as host tensors.  ``out`` [B, L] (device) goes to the host in ONE DMA into a pinned
+    staging buffer kept on the model (grow-only) and the kept samples are cut out of it -- instead of ``out.cpu()``: a fresh
+    pageable [B, L] tensor per call (26 MB for 64 utterances: mmap + first-touch page faults + a bounce-buffered copy, which
+    measured as 58-98 ms outliers on one call in four, profiles/r3_c_list_api.txt) of which the padding is then thrown away."""
+    n = out.numel()
+    buf = getattr(model, "_amp_host_staging", None)
+    if buf is None or buf.numel() < n or buf.dtype != out.dtype:
+        buf = torch.empty(n, dtype=out.dtype, pin_memory=True)
+        model._amp_host_staging = buf
+    host = buf[:n].view(out.shape)
+    host.copy_(out, non_blocking=True)
+    torch.cuda.current_stream(out.device).synchronize()
+    return [host[i, : int(l)].clone() for i, l in enumerate(lengths)]
+
+
 def vocoder_inference(cfg, model, mels, f0s=None, device=None, fast_inference=False):
     """gan_vocoder_inference.py:11-38.  mels [B, n_mel, T] -> audios [B, T*hop] on the CPU."""
     model.eval()
@@ -76,9 +92,9 @@ def synthesis_audios(cfg, model, mels, f0s=None, batch_size=None, fast_inference
                 for r, i in enumerate(grp):
                     batch[r, :, : lens[r]] = torch.as_tensor(mels[i], dtype=torch.float32)
                 batch = batch.to(device)
-                out = _reference_range(model, lambda: model.forward_ragged(batch, lens), device).squeeze(1).cpu()
-                for r, i in enumerate(grp):
-                    audios[i] = out[r, : lens[r] * hop].clone()
+                out = _reference_range(model, lambda: model.forward_ragged(batch, lens), device).squeeze(1)
+                for i, a in zip(grp, _crops_to_host(model, out, [l * hop for l in lens])):
+                    audios[i] = a
         return audios
     mels = [torch.as_tensor(m, dtype=torch.float32).cpu() for m in mels]
     mel_batches, mel_frames = pad_mels_to_tensors(mels, batch_size)
@@ -103,9 +119,12 @@ def synthesis_audios(cfg, model, mels, f0s=None, batch_size=None, fast_inference
             model.eval()
             with torch.no_grad():
                 mel_dev = mel_batch.to(device)
-                out = _reference_range(model, lambda: model.forward_ragged(mel_dev, ext), device).squeeze(1).cpu()
-        else:
-            out = vocoder_inference(cfg, model, mel_batch, f0s=f0_batch, device=device, fast_inference=fast_inference)
+                out = _reference_range(model, lambda: model.forward_ragged(mel_dev, ext), device).squeeze(1)
+            for a in _crops_to_host(model, out, [int(f) * hop for f in mel_frame]):
+                audios[k] = a
+                k += 1
+            continue
+        out = vocoder_inference(cfg, model, mel_batch, f0s=f0_batch, device=device, fast_inference=fast_inference)
         for i in range(mel_batch.shape[0]):
             audios[k] = out[i][: int(mel_frame[i]) * hop]
             k += 1

@@ -288,6 +288,19 @@ int amp_conv_set_option(amp_conv* c, int option, int value);
 int amp_pair_forward(const amp_conv* c1, const amp_conv* c2, const float* x_dev, int B, int T, float slope,
                      float* y_dev, void* stream);
 
+/* ResBlock1.forward (hifigan.py:93-100) in ONE launch:  for p < n_pairs:  x = x + c2[p](lrelu(c1[p](lrelu(x)))), on the
+ * whole-resblock kernel (csrc/rb_f16x3.hip: x read once, y written once, the residual carried in registers).  Handles from
+ * amp_conv_create as for amp_pair_forward (same C and k for all pairs, c1[p] dilated, c2[p] dilation 1, 'same' padding);
+ * covered: C in {32, 64}, k in {3, 5, 7}, n_pairs <= 3, f16x3 arithmetic, under the shapes the current
+ * amp_set_resblock_fusion mode admits -- otherwise AMP_ERR_UNSUPPORTED (run amp_pair_forward n_pairs times: the same bits).
+ * y_dev must not alias x_dev. */
+int amp_resblock_forward(const amp_conv* const* c1, const amp_conv* const* c2, int n_pairs, const float* x_dev, int B, int T,
+                         float slope, float* y_dev, void* stream);
+/* 0: generators run every ResBlock1 as fused pairs; 1 (default): the measured policy (whole-resblock kernel for the narrow
+ * late stages when the launch fills the chip); 2: wherever the kernel is built, any grid; 3: as 2 with the four-wave
+ * 512-column tiles at C = 32.  Bit-identical results in every mode (tests/test_gpu_resblock.py); env AMP_RB_FUSION. */
+int amp_set_resblock_fusion(int mode);
+
 void amp_conv_destroy(amp_conv* c);
 
 /* Frame-rate convs (short contraction, small grid: the convs around the VITS decoder) run on a kernel that stages the

@@ -57,6 +57,41 @@ def pair_forward(w1, b1, w2, b2, x, *, dilation, slope=0.1):
             L.amp_conv_destroy(h)
 
 
+def resblock_forward(ws1, bs1, ws2, bs2, x, *, dilations, slope=0.1, fused=True):
+    """ResBlock1 on cuda:0 from per-pair weights: fused=True -> amp_resblock_forward (ONE launch, csrc/rb_f16x3.hip),
+    fused=False -> len(dilations) x amp_pair_forward (the fused pairs)."""
+    L = _lib.lib()
+    C, _, k = ws1[0].shape
+    n = len(dilations)
+    h1, h2 = [], []
+    try:
+        for ws, bs, hs, ds in ((ws1, bs1, h1, dilations), (ws2, bs2, h2, [1] * n)):
+            for w, b, d in zip(ws, bs, ds):
+                h = ctypes.c_void_p()
+                w, b = w.contiguous().float(), b.contiguous().float()
+                _lib.check(L.amp_conv_create(0, C, C, k, 1, d, (k * d - d) // 2, ctypes.c_void_p(w.data_ptr()),
+                                             ctypes.c_void_p(b.data_ptr()), ctypes.byref(h)))
+                hs.append(h)
+        xd = x.contiguous().float().cuda()
+        B, _, T = xd.shape
+        st = _lib.current_stream_ptr(xd.device)
+        if fused:
+            y = torch.full_like(xd, float("nan"))
+            a1, a2 = (ctypes.c_void_p * n)(*[h.value for h in h1]), (ctypes.c_void_p * n)(*[h.value for h in h2])
+            _lib.check(L.amp_resblock_forward(a1, a2, n, ctypes.c_void_p(xd.data_ptr()), B, T, slope, ctypes.c_void_p(y.data_ptr()), st))
+        else:
+            cur = xd
+            for p in range(n):
+                y = torch.full_like(xd, float("nan"))
+                _lib.check(L.amp_pair_forward(h1[p], h2[p], ctypes.c_void_p(cur.data_ptr()), B, T, slope, ctypes.c_void_p(y.data_ptr()), st))
+                cur = y
+        torch.cuda.synchronize()
+        return y.cpu()
+    finally:
+        for h in h1 + h2:
+            L.amp_conv_destroy(h)
+
+
 def act1d_forward(x, alpha, beta, logscale, fu, fd):
     L = _lib.lib()
     xd = x.contiguous().float().cuda()

@@ -98,9 +98,8 @@ def test_strip_kernel_equals_tile_kernel_bitwise(C, k, d, B, T, strips):
 
 @pytest.mark.parametrize("C,k,d,B,T", [c for c in PAIR_CASES + STRIP_CASES if c[0] in (64, 128)] + RING_CASES)
 def test_policy_kernel_equals_tile_kernel_bitwise(C, k, d, B, T, strips):
-    """Whatever kernel the per-shape policy picks (amp_set_pair_strips(-1): the default table, or an experiment variant
-    selected with AMP_STRIP_C128 / AMP_STRIP_K11 -- wide 8-wave tiles, the 2 x 2-blocked 4-wave variant, ...) gives the
-    bits of the per-tile kernel."""
+    """Whatever kernel the per-shape policy picks (amp_set_pair_strips(-1): per-tile kernel, or the A-ring strips at C = 128,
+    k in {7, 11} when the launch fills the chip) gives the bits of the per-tile kernel."""
     from amphion_amd import _lib
     from hip_helpers import pair_forward
 

@@ -1,0 +1,143 @@
+"""GPU parity: the whole-ResBlock1 kernel (csrc/rb_f16x3.hip: three (dilated, dilation-1) pairs in ONE launch, x and the
+residual never leaving the CU) against the chain of fused pairs bit for bit, against the oracle ops (hifigan.py:93-100), and
+inside the generators (HiFi-GAN V1 with the kernel forced on vs off, dense and ragged)."""
+from types import SimpleNamespace as NS
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _weights(C, k, n):
+    ws1 = [_rand(C, C, k, seed=10 + p, scale=(C * k) ** -0.5) for p in range(n)]
+    bs1 = [_rand(C, seed=20 + p, scale=0.1) for p in range(n)]
+    ws2 = [_rand(C, C, k, seed=30 + p, scale=(C * k) ** -0.5) for p in range(n)]
+    bs2 = [_rand(C, seed=40 + p, scale=0.1) for p in range(n)]
+    return ws1, bs1, ws2, bs2
+
+
+def _ref(ws1, bs1, ws2, bs2, x, dils, slope):
+    """ResBlock1.forward hifigan.py:93-100 in fp64"""
+    x = x.double()
+    for w1, b1, w2, b2, d in zip(ws1, bs1, ws2, bs2, dils):
+        k = w1.shape[2]
+        xt = F.conv1d(F.leaky_relu(x, slope), w1.double(), b1.double(), dilation=d, padding=(k * d - d) // 2)
+        xt = F.conv1d(F.leaky_relu(xt, slope), w2.double(), b2.double(), padding=(k - 1) // 2)
+        x = xt + x
+    return x
+
+
+@pytest.fixture
+def fusion():
+    """amp_set_resblock_fusion for one call sequence: 2 = the kernel wherever it is built (any grid), 3 = four-wave tiles."""
+    from amphion_amd import _lib
+
+    def use(mode):
+        _lib.check(_lib.lib().amp_set_resblock_fusion(mode))
+    yield use
+    _lib.check(_lib.lib().amp_set_resblock_fusion(-1))
+
+
+CASES = [
+    # C, k, dilations, B, T
+    (32, 3, (1, 3, 5), 2, 3000),      # three 1000-column tiles per item (W = 1024, RH = 12)
+    (32, 3, (1, 3, 5), 1, 1000),      # exactly one tile
+    (32, 3, (1, 3, 5), 1, 1001),      # one tile + 1 column
+    (32, 7, (1, 3, 5), 2, 2500),      # RH = 36
+    (32, 5, (1, 3, 5), 3, 777),
+    (32, 7, (1, 3, 5), 1, 7),         # T smaller than the receptive field
+    (32, 3, (1, 3, 5), 1, 1),         # T = 1
+    (32, 3, (2, 6), 2, 1500),         # two pairs, other dilations
+    (32, 7, (1,), 2, 1100),           # one pair
+    (64, 3, (1, 3, 5), 2, 1300),      # W = 512
+    (64, 7, (1, 3, 5), 1, 900),
+    (64, 5, (1, 3, 5), 2, 488),       # exactly one tile at k = 5?  (W - 2 * 24 = 464: one tile + 24)
+    (64, 3, (1, 3, 5), 1, 3),
+    (32, 11, (1, 3, 5), 2, 2000),     # RH = 60 (not in the policy: 23-31 % of every tile is halo)
+    (64, 11, (1, 3, 5), 1, 800),
+    (128, 3, (1, 3, 5), 2, 700),      # C = 128: 256-column tiles, 16 guard columns
+    (128, 5, (1, 3, 5), 1, 300),
+]
+
+
+@pytest.mark.parametrize("C,k,dils,B,T", CASES)
+@pytest.mark.parametrize("mode", [2, 3])
+def test_resblock_kernel_equals_pairs_bitwise(C, k, dils, B, T, mode, fusion):
+    """Per output element the whole-resblock kernel runs the operations of the fused pairs in the same order; the x that a
+    pair would have written to HBM and read back is the fp32 value the kernel keeps in registers -> the same bits, for both
+    tile forms and every cut of the time axis."""
+    from amphion_amd import _lib
+    from hip_helpers import resblock_forward
+
+    _lib.set_precision("f16x3")
+    ws1, bs1, ws2, bs2 = _weights(C, k, len(dils))
+    x = _rand(B, C, T, seed=5)
+    y_pairs = resblock_forward(ws1, bs1, ws2, bs2, x, dilations=dils, fused=False)
+    fusion(mode)
+    y_rb = resblock_forward(ws1, bs1, ws2, bs2, x, dilations=dils, fused=True)
+    assert not torch.isnan(y_rb).any()
+    assert torch.equal(y_rb, y_pairs)
+
+
+@pytest.mark.parametrize("C,k,dils,B,T", [CASES[0], CASES[3], CASES[9], CASES[10]])
+def test_resblock_kernel_vs_oracle(C, k, dils, B, T, fusion):
+    from amphion_amd import _lib
+    from hip_helpers import resblock_forward
+
+    _lib.set_precision("f16x3")
+    ws1, bs1, ws2, bs2 = _weights(C, k, len(dils))
+    x = _rand(B, C, T, seed=6)
+    fusion(2)
+    y = resblock_forward(ws1, bs1, ws2, bs2, x, dilations=dils, fused=True)
+    ref = _ref(ws1, bs1, ws2, bs2, x, dils, 0.1)
+    err = (y.double() - ref).abs().max().item()
+    print(f"\n[rb] C={C} k={k} T={T}: max |err| vs fp64 = {err:.2e} (|ref| max {ref.abs().max().item():.2f})")
+    assert err <= 5e-6 * max(1.0, ref.abs().max().item())
+
+
+def test_resblock_policy_falls_back_on_small_grids(fusion):
+    """Mode 1 (default) admits the kernel only when its grid fills the chip; the op-level entry then says UNSUPPORTED (the
+    generator runs the pairs: same bits)."""
+    from amphion_amd import _lib
+    from hip_helpers import resblock_forward
+
+    _lib.set_precision("f16x3")
+    ws1, bs1, ws2, bs2 = _weights(32, 3, 3)
+    fusion(1)
+    with pytest.raises(_lib.AmpError) as e:
+        resblock_forward(ws1, bs1, ws2, bs2, _rand(1, 32, 2000, seed=1), dilations=(1, 3, 5), fused=True)
+    assert e.value.status == _lib.AMP_ERR_UNSUPPORTED
+
+
+V1 = dict(resblock="1", upsample_rates=[8, 8, 2, 2], upsample_kernel_sizes=[16, 16, 4, 4], upsample_initial_channel=512,
+          resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5]] * 3)
+
+
+@pytest.mark.parametrize("mode", [2, 3])
+def test_generator_with_resblock_kernel_equals_pairs(mode, fusion):
+    """HiFi-GAN V1 (stages of 256 / 128 / 64 / 32 channels): forward and ragged forward with the whole-resblock kernel forced
+    on for every block it covers == the same forwards on fused pairs only, bit for bit (MRF accumulate / mean modes, tile
+    seams at the items' ends, utterances shorter than a tile)."""
+    from amphion_amd.models.vocoders.gan.generator.hifigan import HiFiGAN
+    from amphion_amd.utils.synthetic import randomize_, synthetic_mel
+
+    m = randomize_(HiFiGAN(NS(preprocess=NS(n_mel=80, hop_size=256), model=NS(hifigan=NS(**V1)))), 1234).cuda().eval()
+    mel = synthetic_mel(3, 80, 37, seed=3).cuda()
+    lens = [37, 20, 3]
+    with torch.no_grad():
+        fusion(0)
+        a = m(mel).cpu()
+        ar = m.forward_ragged(mel, lens).cpu()
+        fusion(mode)
+        b = m(mel).cpu()
+        br = m.forward_ragged(mel, lens).cpu()
+    assert torch.equal(a, b)
+    for i, n in enumerate(lens):
+        assert torch.equal(ar[i, :, : n * 256], br[i, :, : n * 256])
