@@ -9,7 +9,6 @@
 #include <map>
 #include <memory>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "amp_internal.h"
@@ -136,29 +135,15 @@ static int range_publish(RangeGuard* g, hipStream_t st) {
     return AMP_OK;
 }
 
-// Wait for everything queued on `st` WITHOUT the runtime's blocking wait: an event record + a polling loop (hipEventQuery,
-// yielding between polls).  The blocking forms (hipStreamSynchronize, a copy into pageable memory) hand the thread to the
-// interrupt path once the wait is long, and on the MI355X boxes of round 3 that path woke up ~21 ms late on every other call
-// when it was entered behind a whole generator forward: the list API's calls alternated 37 / 62 ms with the GPU idle in between
-// (profiles/r3_e_*: rocprofv3 timeline, the gap sits after the forward's last kernel) -- which is what the driver's single
-// round-2 sample of 66.5 ms against the README's 38 ms was.
-static int wait_stream_polling(RangeGuard* g, hipStream_t st) {
-    AMP_HIP(hipEventRecord(g->ev, st));
-    for (;;) {
-        const hipError_t q = hipEventQuery(g->ev);
-        if (q == hipSuccess) return AMP_OK;
-        if (q != hipErrorNotReady) { (void)hipGetLastError(); set_error("hipEventQuery: %s", hipGetErrorString(q)); return AMP_ERR_HIP; }
-        std::this_thread::yield();
-    }
-}
-
 // synchronising check of one guard
 static int range_check_sync(RangeGuard* g, hipStream_t st, const char* who) {
     if (!g || !g->dev) return AMP_OK;
     if (stream_is_capturing(st)) { set_error("%s: the stream is capturing", who); return AMP_ERR_STATE; }
-    AMP_HIP(hipMemcpyAsync(g->host, g->dev, sizeof(unsigned), hipMemcpyDeviceToHost, st));   // pinned mirror: truly asynchronous
-    const int rc = wait_stream_polling(g, st);
-    if (rc != AMP_OK) return rc;
+    // copy into the pinned mirror (a pageable destination would make the copy itself a second, staged wait), then ONE blocking
+    // wait: the thread sleeps until the stream drains -- it must not spin, CPU time is what a container's quota meters
+    // (profiles/r3_o_list_api_cgroup_throttle.txt: the list API's 37 / 60 ms alternation was the host being throttled)
+    AMP_HIP(hipMemcpyAsync(g->host, g->dev, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    AMP_HIP(hipStreamSynchronize(st));
     g->pending = false;
     const unsigned v = *g->host;
     *g->host = 0;

@@ -9,7 +9,7 @@ arithmetic, but runs each padded batch through the generator ONCE instead of one
 import torch
 
 from amphion_amd import _lib
-from amphion_amd.utils.util import pad_mels_to_tensors
+from amphion_amd.utils.util import few_host_threads, pad_mels_to_tensors
 
 
 def _reference_range(model, run, device):
@@ -28,8 +28,8 @@ def _reference_range(model, run, device):
 def _crops_to_host(model, out, lengths):
     """``[out[i, :lengths[i]] for i]`` as host tensors.  ``out`` [B, L] (device) goes to the host in ONE DMA into a pinned
     staging buffer kept on the model (grow-only) and the kept samples are cut out of it -- instead of ``out.cpu()``: a fresh
-    pageable [B, L] tensor per call (26 MB for 64 utterances: mmap + first-touch page faults + a bounce-buffered copy, which
-    measured as 58-98 ms outliers on one call in four, profiles/r3_c_list_api.txt) of which the padding is then thrown away."""
+    pageable [B, L] tensor per call (26 MB for 64 utterances: mmap + first-touch page faults + a bounce-buffered copy, 3-4 ms
+    against 0.5 ms for the pinned DMA) of which the padding is then thrown away."""
     n = out.numel()
     buf = getattr(model, "_amp_host_staging", None)
     if buf is None or buf.numel() < n or buf.dtype != out.dtype:
@@ -74,6 +74,11 @@ def synthesis_audios(cfg, model, mels, f0s=None, batch_size=None, fast_inference
     ``ragged=True``: utterances are sorted by length and run through ``forward_ragged`` -- every kernel pads at
     each utterance's own end, so each audio equals that utterance vocoded ALONE, independent of batching.
     """
+    with few_host_threads():      # the padding / cropping copies below must not wake torch's whole OpenMP pool (utils/util.py)
+        return _synthesis_audios(cfg, model, mels, f0s, batch_size, fast_inference, ragged)
+
+
+def _synthesis_audios(cfg, model, mels, f0s, batch_size, fast_inference, ragged):
     device = next(model.parameters()).device
     hop = model.cfg.preprocess.hop_size
     audios = [None] * len(mels)

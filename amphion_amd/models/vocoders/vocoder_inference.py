@@ -117,16 +117,19 @@ def inference_batches(cfg, model, batches, uids, output_dir, test_batch_size=Non
     hop, fs = cfg.preprocess.hop_size, cfg.preprocess.sample_rate
     preds = []
     k = 0
-    for batch in batches:
-        kw = {"f0s": batch["frame_pitch"].float()} if getattr(cfg.preprocess, "use_frame_pitch", False) else {}
-        audio_pred = fwd(cfg, model, batch["mel"].transpose(-1, -2), device=device, **kw)
-        lens = [int(l) * hop for l in batch["target_len"]]
-        names = [str(u) for u in uids[k:k + len(lens)]]
-        k += len(lens)
-        pred = (audio_pred.squeeze(1) if audio_pred.dim() == 3 else audio_pred).to(device)   # the forward func returns CPU audio (:38)
-        save_audios([os.path.join(output_dir, "pred", n + ".wav") for n in names], pred, lens, fs)
-        save_audios([os.path.join(output_dir, "gt", n + ".wav") for n in names], batch["audio"].to(device), lens, fs)
-        preds.extend(row[:l] for row, l in zip(pred, lens))
+    from amphion_amd.utils.util import few_host_threads
+
+    with few_host_threads():      # host-side copies of the loop (batch tensors, PCM files): a few threads, not the whole OpenMP pool
+        for batch in batches:
+            kw = {"f0s": batch["frame_pitch"].float()} if getattr(cfg.preprocess, "use_frame_pitch", False) else {}
+            audio_pred = fwd(cfg, model, batch["mel"].transpose(-1, -2), device=device, **kw)
+            lens = [int(l) * hop for l in batch["target_len"]]
+            names = [str(u) for u in uids[k:k + len(lens)]]
+            k += len(lens)
+            pred = (audio_pred.squeeze(1) if audio_pred.dim() == 3 else audio_pred).to(device)   # the forward func returns CPU audio (:38)
+            save_audios([os.path.join(output_dir, "pred", n + ".wav") for n in names], pred, lens, fs)
+            save_audios([os.path.join(output_dir, "gt", n + ".wav") for n in names], batch["audio"].to(device), lens, fs)
+            preds.extend(row[:l] for row, l in zip(pred, lens))
     return preds
 
 

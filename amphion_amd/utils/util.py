@@ -1,5 +1,48 @@
 """Host helpers mirrored from utils/util.py that the vocoder inference path calls."""
+import os
+
 import torch
+
+
+def _cpu_budget():
+    """CPUs this process may actually burn: the cgroup quota (cpu.max, cgroup v2; cfs_quota_us, v1) when there is one, else
+    its affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+class few_host_threads:
+    """Scope for the host-side tensor work of the list / batch entry points (padding, crops): at most ``n`` intra-op threads,
+    and never more than a quarter of the CPU budget.  torch sizes its OpenMP pool by the VISIBLE CPUs (128 threads on the 256-CPU
+    MI355X hosts) although a container may be allowed 16: every padded copy and crop then wakes 128 spinning threads, the
+    cgroup's quota for the 100-ms period is gone and the whole process is parked -- the list API alternated 37 / 60 ms per call with
+    the GPU idle (profiles/r3_o_list_api_cgroup_throttle.txt).  These copies are a few MB: four threads are plenty."""
+
+    def __init__(self, n=4):
+        self.n = max(1, min(n, _cpu_budget() // 4 or 1))
+
+    def __enter__(self):
+        self.prev = torch.get_num_threads()
+        if self.prev > self.n:
+            torch.set_num_threads(self.n)
+        return self
+
+    def __exit__(self, *exc):
+        if torch.get_num_threads() != self.prev:
+            torch.set_num_threads(self.prev)
+        return False
 
 
 def pad_mels_to_tensors(mels, batched=None):

@@ -64,6 +64,15 @@ CASES = [
     (64, 11, (1, 3, 5), 1, 800),
     (128, 3, (1, 3, 5), 2, 700),      # C = 128: 256-column tiles, 16 guard columns
     (128, 5, (1, 3, 5), 1, 300),
+    # large launches (thousands of tiles, every wave of the chip busy; these shapes also exercised the strip-walking variant of
+    # the kernel that was measured slower and not kept, tests/experiments/rb_strip_f16x3.hip.txt)
+    (32, 3, (1, 3, 5), 600, 2100),
+    (32, 7, (1, 3, 5), 40, 5000),
+    (32, 11, (1, 3, 5), 70, 4000),
+    (64, 11, (1, 3, 5), 33, 3000),
+    (64, 7, (1, 3, 5), 300, 1400),
+    (128, 3, (1, 3, 5), 300, 800),
+    (32, 5, (2, 6), 520, 1500),
 ]
 
 

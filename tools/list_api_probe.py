@@ -13,7 +13,44 @@ from amphion_amd.utils.util import pad_mels_to_tensors
 from amphion_amd.models.vocoders.gan import gan_vocoder_inference as gvi
 
 
+def elim():
+    """Leave one step of the sequence out at a time: which one brings the alternating +21 ms?"""
+    cfg, m = bc.hifigan()
+    lens = torch.randint(60, 400, (64,), generator=torch.Generator().manual_seed(3)).tolist()
+    mels = [synthetic_mel(1, 80, L, seed=i)[0] for i, L in enumerate(lens)]
+    dev = torch.device("cuda:0")
+    with torch.no_grad():
+        gvi.synthesis_audios(cfg, m, mels, batch_size=64); torch.cuda.synchronize()
+        m.set_profiling(1)
+        mb, mf = pad_mels_to_tensors([x.cpu() for x in mels], 64)
+        fixed_dev = mb[0].to(dev)
+        rf = m.receptive_frames(); T = int(mb[0].shape[-1])
+        ext = [min(T, int(f) + rf) for f in mf[0]]
+        for skip in ("nothing", "pad", "h2d", "d2h", "crops", "d2h+crops", "pad+h2d", "crops->views"):
+            rows = []
+            for call in range(10):
+                t0 = time.perf_counter()
+                if "pad" not in skip:
+                    mb, mf = pad_mels_to_tensors([x.cpu() for x in mels], 64)
+                mel_dev = fixed_dev if "h2d" in skip else mb[0].to(dev)
+                out = m.forward_ragged(mel_dev, ext)
+                m.check_range()
+                t1 = time.perf_counter()
+                o2 = out.squeeze(1)
+                if "d2h" not in skip:
+                    n = o2.numel(); host = m._amp_host_staging[:n].view(o2.shape); host.copy_(o2, non_blocking=True); torch.cuda.current_stream().synchronize()
+                    if skip == "crops->views":
+                        crops = [host[i, : int(f) * 256] for i, f in enumerate(mf[0])]
+                    elif "crops" not in skip:
+                        crops = [host[i, : int(f) * 256].clone() for i, f in enumerate(mf[0])]
+                rows.append(((t1 - t0) * 1e3, (time.perf_counter() - t0) * 1e3))
+            print(f"skip {skip:12s}: fwd+check " + " ".join(f"{a:5.1f}" for a, _ in rows) + "  | total " + " ".join(f"{b:5.1f}" for _, b in rows[:4]), flush=True)
+        m.set_profiling(0)
+
+
 def main():
+    if "--elim" in sys.argv:
+        return elim()
     cfg, m = bc.hifigan()
     lens = torch.randint(60, 400, (64,), generator=torch.Generator().manual_seed(3)).tolist()
     mels = [synthetic_mel(1, 80, L, seed=i)[0] for i, L in enumerate(lens)]

@@ -1,7 +1,7 @@
 export CMD='
-timeout 300 python tools/sync_probe.py
-echo "## HSA_ENABLE_INTERRUPT=0"; HSA_ENABLE_INTERRUPT=0 timeout 300 python tools/sync_probe.py | head -8
-timeout 300 python tools/rb_inforward.py --steps 20 --rounds 2 --modes 0 1
+python -c "import torch, os; print(\"threads\", torch.get_num_threads(), \"cpus\", os.cpu_count(), \"affinity\", len(os.sched_getaffinity(0)))"; cat /sys/fs/cgroup/cpu.max 2>/dev/null; cat /sys/fs/cgroup/cpu/cpu.cfs_quota_us 2>/dev/null; nproc
+echo "## OMP_NUM_THREADS=1"; OMP_NUM_THREADS=1 timeout 300 python tools/list_api_probe.py --elim | head -4
+echo "## OMP_NUM_THREADS=8"; OMP_NUM_THREADS=8 timeout 300 python tools/list_api_probe.py --elim | head -3
+echo "## default"; timeout 300 python tools/list_api_probe.py --elim | head -3
 '
-bash tools/gpu_round.sh r3_h cmd
-timeout 600 python -m pytest tests/test_gpu_c1_clips.py -m gpu -x -q -s 2>&1 | tail -8
+bash tools/gpu_round.sh r3_o cmd
