@@ -62,6 +62,10 @@ class amp_mel_desc(ctypes.Structure):
         ("mag_eps", c_float),
         ("log_clip", c_float),
         ("mel_bands_dev", c_void_p),
+        ("range_dev", c_void_p),
+        ("range_host", c_void_p),
+        ("range_reset_dev", c_void_p),
+        ("range_seq", c_int32),
     ]
 
 

@@ -16,13 +16,30 @@ __device__ __forceinline__ int reflect_index(int s, int L) {
     return s;
 }
 
+// utils/mel.py:21-24 wants the extreme samples when the audio leaves [-1, 1].  The front-end kernels fold what they read anyway:
+// `lo` / `hi` = the lane's running min / max; out-of-range lanes (rare) merge into range[0] / range[1] with an atomic max of the
+// int bits -- monotone in the value for floats below -1 (more negative = larger int) and for floats above +1.
+struct MelRange { int* range; int* reset; int seq; };
+__device__ __forceinline__ void mel_range_begin(const MelRange& r) {
+    if (r.range && blockIdx.x == 0 && threadIdx.x == 0) {
+        r.range[2] = r.seq;
+        if (r.reset) { r.reset[0] = __float_as_int(-1.0f); r.reset[1] = __float_as_int(1.0f); }
+    }
+}
+__device__ __forceinline__ void mel_range_end(const MelRange& r, float lo, float hi) {
+    if (!r.range) return;
+    if (lo < -1.0f) atomicMax(&r.range[0], __float_as_int(lo));
+    if (hi > 1.0f) atomicMax(&r.range[1], __float_as_int(hi));
+}
+
 __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ wav, const int* __restrict__ lens, int L, int F,
                                                   int n_fft, int log2n, int hop, int pad, int n_mel, float mag_eps,
                                                   float log_clip,
                                                   const float* __restrict__ window, const float* __restrict__ melbasis,
                                                   float* __restrict__ mel, float* __restrict__ mag,
-                                                  float* __restrict__ re_out, float* __restrict__ im_out) {
+                                                  float* __restrict__ re_out, float* __restrict__ im_out, const MelRange rng) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    mel_range_begin(rng);
     float2* buf0 = reinterpret_cast<float2*>(smem);   // [n_fft]
     float2* buf1 = buf0 + n_fft;                      // [n_fft]
     float2* tw = buf1 + n_fft;                        // [n_fft/2]  exp(-2*pi*i*m/n_fft)
@@ -38,10 +55,14 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ wav,
     int Li = L;
     if (lens) { Li = lens[b] < L ? lens[b] : L; if (f > (Li + 2 * pad - n_fft) / hop || Li <= pad) return; }
 
+    float rlo = 0.f, rhi = 0.f;
     for (int n = tid; n < n_fft; n += 256) {
         const int s = reflect_index(f * hop + n - pad, Li);
-        buf0[n] = make_float2(wb[s] * window[n], 0.f);
+        const float xv = wb[s];
+        rlo = fminf(rlo, xv); rhi = fmaxf(rhi, xv);
+        buf0[n] = make_float2(xv * window[n], 0.f);
     }
+    mel_range_end(rng, rlo, rhi);
     for (int m = tid; m < half; m += 256) {
         float sn, cs;
         sincospif(-2.0f * (float)m / (float)n_fft, &sn, &cs);
@@ -160,9 +181,10 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 4) void mel1024_kernel(const float*
                                                                   const float* __restrict__ melbasis,
                                                                   const int* __restrict__ bands, float* __restrict__ mel,
                                                                   float* __restrict__ mag, float* __restrict__ re_out,
-                                                                  float* __restrict__ im_out) {
+                                                                  float* __restrict__ im_out, const MelRange rng) {
     constexpr int N = 1024, M = 512, BINS = 513;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    mel_range_begin(rng);
     float2* const xch = reinterpret_cast<float2*>(smem);                      // [MEL_WAVES][64 * MEL_XROW]
     float* const magl = smem + 2 * MEL_WAVES * 64 * MEL_XROW;                 // [MEL_WAVES][MEL_MAGROW]
     float* const melt = magl + MEL_WAVES * MEL_MAGROW;                        // [n_mel][MEL_FPB + 1]
@@ -204,6 +226,7 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 4) void mel1024_kernel(const float*
     }
     float2* xw = xch + w * (64 * MEL_XROW);
     float* mg = magl + w * MEL_MAGROW;
+    float rlo = 0.f, rhi = 0.f;                    // extreme samples this lane read (utils/mel.py:21-24, mel_range_end)
 
     for (int fi = 0; fi < MEL_FPW; ++fi) {
         const int fl = w * MEL_FPW + fi;            // frame inside the workgroup tile
@@ -216,14 +239,18 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 4) void mel1024_kernel(const float*
             for (int q = 0; q < 8; ++q) {
                 const float* p = wb + s0 + 128 * q;
                 const float2 wq = win[64 * q];
-                v[q] = make_float2(p[0] * wq.x, p[1] * wq.y);
+                const float x0 = p[0], x1 = p[1];
+                rlo = fminf(rlo, fminf(x0, x1)); rhi = fmaxf(rhi, fmaxf(x0, x1));
+                v[q] = make_float2(x0 * wq.x, x1 * wq.y);
             }
         } else {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int s = s0 + 128 * q;
                 const float2 wq = win[64 * q];
-                v[q] = make_float2(wb[reflect_index(s, Li)] * wq.x, wb[reflect_index(s + 1, Li)] * wq.y);
+                const float x0 = wb[reflect_index(s, Li)], x1 = wb[reflect_index(s + 1, Li)];
+                rlo = fminf(rlo, fminf(x0, x1)); rhi = fmaxf(rhi, fmaxf(x0, x1));
+                v[q] = make_float2(x0 * wq.x, x1 * wq.y);
             }
         }
         // pass 0 (Ns = 1): no twiddles; out[8 j + q]
@@ -303,6 +330,7 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 4) void mel1024_kernel(const float*
         }
         __builtin_amdgcn_wave_barrier();
     }
+    mel_range_end(rng, rlo, rhi);
     if (!mel) return;
     __syncthreads();
     // melt [n_mel][32 frames] -> mel[b][m][f0 .. f0 + 32): one 128-B segment per channel
@@ -317,6 +345,7 @@ hipError_t launch_mel(const amp_mel_desc& d, const float* wav, const int* lens, 
                       const float* melbasis, float* mel, float* mag, float* re, float* im, hipStream_t stream) {
     const int pad = d.pad_mode == 0 ? (d.n_fft - d.hop_size) / 2 : d.n_fft / 2;
     const int n_mel = mel ? d.n_mel : 0;
+    const MelRange rng{d.range_dev, d.range_reset_dev, d.range_seq};
     if (d.n_fft == 1024 && n_mel <= MEL_MAXMEL && (pad & 1) == 0 && (d.hop_size & 1) == 0) {
         // wave-per-frame radix-8 real FFT (every shipped config of the reference)
         const size_t lds = (size_t)(2 * MEL_WAVES * 64 * MEL_XROW + MEL_WAVES * MEL_MAGROW + (size_t)n_mel * (MEL_FPB + 1)) * sizeof(float);
@@ -332,8 +361,11 @@ hipError_t launch_mel(const amp_mel_desc& d, const float* wav, const int* lens, 
         const int fblocks = (F + MEL_FPB - 1) / MEL_FPB;
         hipLaunchKernelGGL(mel1024_kernel, dim3((unsigned)((size_t)B * fblocks)), dim3(64 * MEL_WAVES), lds, stream, wav, lens, L, F,
                            d.hop_size, pad, n_mel, d.mag_eps, d.log_clip, window, melbasis,
-                           static_cast<const int*>(d.mel_bands_dev), mel, mag, re, im);
-        return hipGetLastError();
+                           static_cast<const int*>(d.mel_bands_dev), mel, mag, re, im, rng);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess && d.range_dev && d.range_host)
+            e = hipMemcpyAsync(d.range_host, d.range_dev, 3 * sizeof(int), hipMemcpyDeviceToHost, stream);
+        return e;
     }
     // generic power-of-two n_fft: one workgroup per frame, radix-2
     int log2n = 0;
@@ -341,8 +373,11 @@ hipError_t launch_mel(const amp_mel_desc& d, const float* wav, const int* lens, 
     const size_t lds = (size_t)(2 * d.n_fft + d.n_fft / 2) * sizeof(float2) + (size_t)(d.n_fft / 2 + 1) * sizeof(float);
     dim3 grid((unsigned)((size_t)B * F));
     hipLaunchKernelGGL(mel_kernel, grid, dim3(256), lds, stream, wav, lens, L, F, d.n_fft, log2n, d.hop_size, pad,
-                       n_mel, d.mag_eps, d.log_clip, window, melbasis, mel, mag, re, im);
-    return hipGetLastError();
+                       n_mel, d.mag_eps, d.log_clip, window, melbasis, mel, mag, re, im, rng);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && d.range_dev && d.range_host)
+        e = hipMemcpyAsync(d.range_host, d.range_dev, 3 * sizeof(int), hipMemcpyDeviceToHost, stream);
+    return e;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -85,41 +85,96 @@ def _window(cfg, device):
     return hann_window[wkey]
 
 
-_pending_range = []      # (event, pinned [2] tensor) of earlier calls whose min / max have not been looked at yet
+# ---- the reference's out-of-range notice (utils/mel.py:21-24) without a reduction pass of its own ----------------------
+# The front-end kernel folds the extreme samples it reads anyway into a 3-word slot (amp_mel_desc.range_dev) and the call copies
+# the slot to pinned memory behind itself; a LATER call (or flush_range_warnings()) prints what has landed.  Per device: a ring of
+# slots, each re-initialised by the kernel of the call before it -- no extra launch, no host synchronisation, no allocation per call
+# (round 2: torch.aminmax + stack + a fresh pinned tensor + copy + event = as much host time as the mel kernel takes on the GPU).
+_RANGE_SLOTS = 64
+_INIT = (int(np.float32(-1.0).view(np.int32)), int(np.float32(1.0).view(np.int32)), 0, 0)
+_range_rings = {}
+
+
+class _RangeRing:
+    def __init__(self, device):
+        self.dev = torch.tensor([_INIT] * _RANGE_SLOTS, dtype=torch.int32).to(device)           # [slots, 4] (16-B rows)
+        self.host = torch.zeros((_RANGE_SLOTS, 4), dtype=torch.int32).pin_memory()
+        self.host_np = self.host.numpy()
+        self.dev_ptr, self.host_ptr = self.dev.data_ptr(), self.host.data_ptr()
+        self.seq = 0                       # calls issued
+        self.done = 0                      # calls whose slot has been looked at
+        self.stream_dev = device
+
+    def next(self):
+        """(range_dev, range_host, range_reset_dev, seq) for the next call."""
+        if self.seq - self.done >= _RANGE_SLOTS - 1:            # ring full: the oldest copy must land before its slot is re-used
+            self.flush(block=True)
+        self.seq += 1
+        i, n = self.seq % _RANGE_SLOTS, (self.seq + 1) % _RANGE_SLOTS
+        return self.dev_ptr + 16 * i, self.host_ptr + 16 * i, self.dev_ptr + 16 * n, self.seq
+
+    def flush(self, block):
+        while self.done < self.seq:
+            k = self.done + 1
+            row = self.host_np[k % _RANGE_SLOTS]
+            if int(row[2]) != (k & 0x7FFFFFFF):                 # copy of call k not landed yet
+                if not block:
+                    return
+                torch.cuda.synchronize(self.stream_dev)
+                if int(row[2]) != (k & 0x7FFFFFFF):             # still nothing after a device-wide wait: call k raised before its
+                    self.done = k                               # launch (bad shape, short audio) -- there is no notice to wait for
+                    continue
+            self.done = k
+            mn = float(np.int32(row[0]).view(np.float32))
+            mx = float(np.int32(row[1]).view(np.float32))
+            if mn < -1.0:
+                print("min value is ", mn)
+            if mx > 1.0:
+                print("max value is ", mx)
+
+
+def _range_slot(device):
+    ring = _range_rings.get(device)
+    if ring is None:
+        ring = _range_rings[device] = _RangeRing(device)
+    ring.flush(block=False)
+    return ring.next()
 
 
 def _range_warning(y):
-    """utils/mel.py:21-24: the reference prints when the audio leaves [-1, 1].  Reading min / max on the host would
-    stall the stream on every call (the comparison needs the value); here the pair is copied to pinned memory behind
-    the reduction and looked at by a LATER call (or ``flush_range_warnings()``), once its copy has landed."""
+    """Kept for callers of the round-2 name: the notice now rides on the front-end launch itself (``report_range=True``)."""
     flush_range_warnings(block=False)
-    if not (isinstance(y, torch.Tensor) and y.is_cuda):
-        return                                     # the kernel call that follows refuses CPU tensors
-    mm = torch.stack(torch.aminmax(y.detach()))
-    host = torch.empty(2, dtype=mm.dtype, pin_memory=True)
-    host.copy_(mm, non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream(y.device))
-    _pending_range.append((ev, host))
 
 
 def flush_range_warnings(block=True):
     """Print the pending out-of-range notices (``block=True`` waits for the copies still in flight)."""
-    while _pending_range:
-        ev, host = _pending_range[0]
-        if not ev.query():
-            if not block:
-                return
-            ev.synchronize()
-        _pending_range.pop(0)
-        mn, mx = float(host[0]), float(host[1])
-        if mn < -1.0:
-            print("min value is ", mn)
-        if mx > 1.0:
-            print("max value is ", mx)
+    for ring in _range_rings.values():
+        ring.flush(block)
 
 
-def _run(y, cfg, *, n_mel, pad_mode, mag_eps, log_clip, want=("mel",), basis=None, window=None, lengths=None):
+# ---- per (config, device) launch plan: everything a call needs that does not depend on the audio ----------------------------
+_plans = {}
+
+
+class _Plan:
+    __slots__ = ("basis", "window", "bands", "descs", "n_fft", "win_size", "hop_size", "bins")
+
+
+def _plan(cfg, device):
+    key = (cfg.sample_rate, cfg.n_fft, cfg.win_size, cfg.hop_size, cfg.n_mel, float(cfg.fmin),
+           None if cfg.fmax is None else float(cfg.fmax), device)
+    p = _plans.get(key)
+    if p is None:
+        p = _Plan()
+        p.basis, p.window = _basis_and_window(cfg, device)
+        p.bands = mel_bands[p.basis.data_ptr()][1]
+        p.descs = {}
+        p.n_fft, p.win_size, p.hop_size, p.bins = cfg.n_fft, cfg.win_size, cfg.hop_size, cfg.n_fft // 2 + 1
+        _plans[key] = p
+    return p
+
+
+def _run(y, cfg, *, n_mel, pad_mode, mag_eps, log_clip, want=("mel",), basis=None, window=None, lengths=None, report_range=False):
     y = _lib.require_device_tensor(y, "audio")
     if y.dim() == 1:
         y = y.unsqueeze(0)
@@ -129,6 +184,8 @@ def _run(y, cfg, *, n_mel, pad_mode, mag_eps, log_clip, want=("mel",), basis=Non
     bands = mel_bands.get(basis.data_ptr()) if basis is not None else None       # (basis kept alive, bands) of a cached basis
     d = _lib.amp_mel_desc(cfg.n_fft, cfg.win_size, cfg.hop_size, n_mel, pad_mode, mag_eps, log_clip,
                           bands[1].data_ptr() if bands is not None and bands[0] is basis else None)
+    if report_range:
+        d.range_dev, d.range_host, d.range_reset_dev, d.range_seq = _range_slot(y.device)
     L = _lib.lib()
     F = L.amp_mel_num_frames(ctypes.byref(d), Lh)
     bins = cfg.n_fft // 2 + 1
@@ -179,6 +236,34 @@ def extract_mel_features_batch(wavs, cfg, device=None):
     return [mel[i, :, : num_frames(lens[i], cfg)] for i in range(len(wavs))]
 
 
+def _logmel_fast(y, cfg, mag_eps):
+    """log-mel [B, n_mel, F] of a device tensor: the two hot entry points (``extract_mel_features``, ``mel_spectrogram_torch``) as
+    ONE ctypes call -- basis / window / band table / descriptor come from the per-(config, device) plan, the range notice rides on
+    the launch (``_range_slot``)."""
+    if y.dim() == 1:
+        y = y.unsqueeze(0)
+    if y.dim() != 2:
+        raise ValueError(f"expected audio of shape [B, L], got {tuple(y.shape)}")
+    dev = y.device
+    p = _plan(cfg, dev)
+    d = p.descs.get(mag_eps)
+    if d is None:
+        d = p.descs[mag_eps] = _lib.amp_mel_desc(p.n_fft, p.win_size, p.hop_size, cfg.n_mel, 0, mag_eps, 1e-5, p.bands.data_ptr())
+    B, Lh = y.shape
+    pad = (p.n_fft - p.hop_size) // 2
+    if Lh <= pad:      # too short for the reflection padding: let the library say so (AmpError), through the general path
+        return _run(y, cfg, n_mel=cfg.n_mel, pad_mode=0, mag_eps=mag_eps, log_clip=1e-5, basis=p.basis, window=p.window)["mel"]
+    d.range_dev, d.range_host, d.range_reset_dev, d.range_seq = _range_slot(dev)
+    F = (Lh + 2 * pad - p.n_fft) // p.hop_size + 1
+    if not y.is_contiguous() or y.dtype != torch.float32:
+        y = y.contiguous().float()
+    out = torch.empty((B, cfg.n_mel, F), device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().amp_mel_forward_ragged(ctypes.byref(d), y.data_ptr(), None, B, Lh, p.window.data_ptr(), p.basis.data_ptr(),
+                                                     out.data_ptr(), None, None, None, _lib.current_stream_ptr(dev)))
+    return out
+
+
 def dynamic_range_compression_torch(x, C=1, clip_val=1e-5):
     """utils/mel.py:10-12"""
     return torch.log(torch.clamp(x, min=clip_val) * C)
@@ -192,8 +277,7 @@ def extract_linear_features(y, cfg, center=False):
     """utils/mel.py:20-52: |STFT| with eps 1e-9 -> [bins, F] (batch dim squeezed when B == 1)."""
     if center:
         raise NotImplementedError("center=True is never used by the reference callers")
-    _range_warning(y)
-    out = _run(y, cfg, n_mel=0, pad_mode=0, mag_eps=1e-9, log_clip=0.0, want=("mag",), window=_window(cfg, y.device))
+    out = _run(y, cfg, n_mel=0, pad_mode=0, mag_eps=1e-9, log_clip=0.0, want=("mag",), window=_window(cfg, y.device), report_range=True)
     return torch.squeeze(out["mag"], 0)
 
 
@@ -201,9 +285,8 @@ def mel_spectrogram_torch(y, cfg, center=False):
     """utils/mel.py:55-104: log-mel with eps 1e-6 -> [B, n_mel, F]."""
     if center:
         raise NotImplementedError("center=True is never used by the reference callers")
-    _range_warning(y)
-    basis, window = _basis_and_window(cfg, y.device)
-    return _run(y, cfg, n_mel=cfg.n_mel, pad_mode=0, mag_eps=1e-6, log_clip=1e-5, basis=basis, window=window)["mel"]
+    y = _lib.require_device_tensor(y, "audio")
+    return _logmel_fast(y, cfg, 1e-6)
 
 
 class _LogMelFunction(torch.autograd.Function):
@@ -248,14 +331,11 @@ def extract_mel_features(y, cfg, center=False):
     tensor that requires grad): the backward runs on ``amp_mel_backward``."""
     if center:
         raise NotImplementedError("center=True is never used by the reference callers")
-    _range_warning(y)
-    if torch.is_grad_enabled() and isinstance(y, torch.Tensor) and y.requires_grad:
-        y2 = _lib.require_device_tensor(y, "audio")
-        out = _LogMelFunction.apply(y2 if y2.dim() == 2 else y2.unsqueeze(0), cfg, 1e-9, 1e-5)
+    y = _lib.require_device_tensor(y, "audio")
+    if torch.is_grad_enabled() and y.requires_grad:
+        out = _LogMelFunction.apply(y if y.dim() == 2 else y.unsqueeze(0), cfg, 1e-9, 1e-5)
         return out.squeeze(0)
-    basis, window = _basis_and_window(cfg, y.device)
-    out = _run(y, cfg, n_mel=cfg.n_mel, pad_mode=0, mag_eps=1e-9, log_clip=1e-5, basis=basis, window=window)["mel"]
-    return out.squeeze(0)
+    return _logmel_fast(y, cfg, 1e-9).squeeze(0)
 
 
 class mel_criterion(torch.nn.Module):

@@ -176,6 +176,8 @@ def other_configs(reps=5):
                   "frac_of_f16x3_mfma_peak": flop / r["ms_per_step"] / 1e9 / (PEAK_F16_TFLOPS / 3.0)})
         out["c5_vits_decode"] = r
         torch.cuda.empty_cache()
+        out["vits_text_to_wave"] = bc.vits(reps)[0]       # full SynthesizerTrn.infer at config/vits.json dimensions
+        torch.cuda.empty_cache()
         r = bc.mel(max(reps, 10))[0]
         r.update({"algorithmic_bytes": 64 * 65536 * 4 + 64 * 80 * 256 * 4, "frac_of_hbm_peak": r["algorithmic_GBps"] / PEAK_HBM_GBS})
         out["mel_front_end"] = r

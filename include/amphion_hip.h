@@ -405,6 +405,17 @@ typedef struct amp_mel_desc {
     const int32_t* mel_bands_dev; /* optional, device: [n_mel][2] = first and one-past-last FFT bin with a non-zero
                             weight in each row of melbasis (librosa's triangular filters touch 2..40 of the 513 bins);
                             NULL = every row is summed over all bins.  Must cover every non-zero of the basis. */
+    /* Optional sample-range report of utils/mel.py:21-24 ("min value is" / "max value is" when the audio leaves [-1, 1])
+     * without a reduction pass of its own.  range_dev: device int32[3] = { bits of the smallest sample < -1 seen
+     * (initialised to the bits of -1.0f = nothing seen), bits of the largest sample > 1 (initialised to +1.0f), range_seq };
+     * the kernel folds the samples it reads anyway into the first two (atomic max of the int bits: monotone for both) and
+     * stores range_seq into the third.  range_host (pinned host memory, 3 x int32): the call enqueues a copy of the three
+     * words behind the kernel; the caller knows it has landed when word 2 equals range_seq.  range_reset_dev: another
+     * int32[3] the kernel re-initialises for a LATER call (a ring of slots then needs no reset launch).  NULL = off. */
+    int32_t* range_dev;
+    int32_t* range_host;
+    int32_t* range_reset_dev;
+    int32_t range_seq;
 } amp_mel_desc;
 
 /* Number of frames produced for L samples. */

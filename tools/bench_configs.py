@@ -56,6 +56,37 @@ def c5(reps):
     return [{"config": "C5 VITS enc_q -> flow -> flow(reverse) -> HiFi-GAN decoder, B=16, T=256", "ms_per_step": ms, "samples_per_s": n / ms * 1e3, "x_realtime": n / ms * 1e3 / 22050}]
 
 
+def vits(reps):
+    """Full VITS inference, text -> wave (SynthesizerTrn.infer, vits.py:320-369) at config/vits.json dimensions: B = 16 token sequences
+    of 100 -> durations -> ~400 frames each -> HiFi-GAN decoder.  Host to host (infer synchronises once for the frame count and once
+    for the operand-range check); the decoder's share comes from its own HIP events."""
+    from amphion_amd.models.tts.vits.vits import SynthesizerTrn
+    full = dict(inter_channels=192, hidden_channels=192, filter_channels=768, n_heads=2, n_layers=6, kernel_size=3, p_dropout=0.1,
+                resblock="1", resblock_kernel_sizes=V1["resblock_kernel_sizes"], resblock_dilation_sizes=V1["resblock_dilation_sizes"],
+                upsample_rates=V1["upsample_rates"], upsample_initial_channel=512, upsample_kernel_sizes=V1["upsample_kernel_sizes"],
+                n_speakers=0, gin_channels=256, use_sdp=True)
+    net = randomize_(SynthesizerTrn(512, 513, 32, **full), 77, g_gain=0.5).to(DEV).eval()
+    B, Tx = 16, 100
+    g = torch.Generator().manual_seed(13)
+    x = torch.randint(0, 512, (B, Tx), generator=g).to(DEV)
+    xl = torch.full((B,), Tx)
+    n_dp = torch.randn(B, 2, Tx, generator=g).to(DEV)
+    kw = dict(noise_scale=0.667, length_scale=1.0, noise_scale_w=0.8, noise_dp=n_dp)
+    o = net.infer(x, xl, **kw)
+    frames = o["mask"].sum(dim=(1, 2))
+    n_z = torch.randn(B, 192, int(frames.max()), generator=g).to(DEV)
+    fn = lambda: net.infer(x, xl, noise_z=n_z, **kw)
+    ms = timed(fn, reps)
+    net.dec.set_profiling(1)
+    fn(); torch.cuda.synchronize()
+    dec_ms = net.dec.last_timing_ms(0)
+    net.dec.set_profiling(0)
+    n = int(frames.sum().item()) * 256
+    return [{"config": f"VITS text -> wave (SynthesizerTrn.infer, config/vits.json dimensions), B={B} x {Tx} tokens -> {int(frames.sum().item())} frames",
+             "ms_per_step": ms, "samples_per_s": n / ms * 1e3, "x_realtime": n / ms * 1e3 / 22050, "decoder_gpu_ms": dec_ms,
+             "share_outside_decoder": 1.0 - dec_ms / ms, "frames_per_item": [int(f) for f in frames.tolist()]}]
+
+
 def mel(reps):
     from amphion_amd.utils.mel import mel_spectrogram_torch
     pp = NS(sample_rate=22050, n_fft=1024, win_size=1024, hop_size=256, n_mel=80, fmin=0, fmax=8000)
@@ -126,9 +157,9 @@ def lat(reps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--only", default="", choices=["", "c3", "c5", "mel", "pcm", "list", "lat"])
+    ap.add_argument("--only", default="", choices=["", "c3", "c5", "vits", "mel", "pcm", "list", "lat"])
     a = ap.parse_args()
-    runs = {"c3": c3, "c5": c5, "mel": mel, "pcm": pcm, "list": lst, "lat": lat}
+    runs = {"c3": c3, "c5": c5, "vits": vits, "mel": mel, "pcm": pcm, "list": lst, "lat": lat}
     with torch.no_grad():
         for name, fn in runs.items():
             if a.only in ("", name):
