@@ -198,7 +198,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void rb_f16x3_kernel(const RbArgs 
     __syncthreads();
 
     const int np = a.np;
-#pragma unroll
+    // ROLLED over the pairs (the arguments of pair p are picked out of the kernel-argument arrays with scalar loads): one copy of
+    // the pair's code instead of three -- the unrolled k = 3 kernel is 43 KB of instructions against a 64-KB instruction cache
+    // shared by two CUs whose waves sit in different phases of it
+#pragma unroll 1
     for (int p = 0; p < AMP_RB_MAX_PAIRS; ++p) {
         if (p < np) {   // workgroup-uniform
             const bool last = (p + 1 == np);

@@ -159,8 +159,19 @@ def other_configs(reps=5):
         r = bc.c3(reps)[0]
         n = 32 * 256 * 256
         flop = (FLOP_PER_SAMPLE_ALL + 2.0 * (100 - N_MEL) * 512 * 7 / 256) * n
+        # byte side: the convs' layer-wise minimum 15 830 B/sample + the 73 anti-aliased activations at their fused
+        # minimum of one read and one write each, 15 232 B/sample = 31 062 B/sample; the time is the sum of a conv part that is
+        # MFMA-bound and an activation part that is HBM-bound, so both fractions are of the SAME step time
+        act_bytes, conv_bytes = 15_232.0 * n, 15_830.0 * n
         r.update({"algorithmic_conv_tflop": flop / 1e12, "conv_tflops": flop / r["ms_per_step"] / 1e9,
-                  "frac_of_f16x3_mfma_peak": flop / r["ms_per_step"] / 1e9 / (PEAK_F16_TFLOPS / 3.0)})
+                  "frac_of_f16x3_mfma_peak": flop / r["ms_per_step"] / 1e9 / (PEAK_F16_TFLOPS / 3.0),
+                  "activation_algorithmic_GB": act_bytes / 1e9, "conv_layerwise_min_GB": conv_bytes / 1e9,
+                  "algorithmic_GBps": (act_bytes + conv_bytes) / r["ms_per_step"] / 1e6,
+                  "frac_of_hbm_peak": (act_bytes + conv_bytes) / r["ms_per_step"] / 1e6 / PEAK_HBM_GBS,
+                  "roofline_floor_ms": {"convs_at_f16x3_mfma_peak": flop / (PEAK_F16_TFLOPS / 3.0) / 1e9,
+                                        "activations_at_hbm_peak": act_bytes / PEAK_HBM_GBS / 1e6},
+                  "note": "73 act1d launches are ~1/3 of the step (8.9 ms at 3-3.6 TB/s, profiles/r2_uv_act1d.txt); the convs run "
+                          "unfused around them (an AMPBlock has an activation between its two convs)"})
         out["c3_bigvgan"] = r
         torch.cuda.empty_cache()
         # C5 VITS decode path B=16: enc_q (513 -> 192, WN 16 x k5) + flow both ways (4 couplings x WN 4 x k5, twice) + decoder

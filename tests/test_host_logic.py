@@ -319,3 +319,68 @@ def test_bench_relaunch_command_and_cli_guards():
     if not torch.cuda.is_available():
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300)
         assert r.returncode != 0 and "ROCm device" in (r.stderr + r.stdout) and "Traceback" not in r.stderr
+
+
+def test_few_host_threads_scope_and_cpu_budget():
+    """The list / batch entry points cap torch's intra-op threads while they pad and crop on the host (a 128-thread OpenMP pool
+    under a 16-CPU cgroup quota got the whole process throttled: profiles/r3_o_list_api_cgroup_throttle.txt) and restore the
+    setting afterwards, also when the body raises."""
+    import torch
+
+    from amphion_amd.utils.util import _cpu_budget, few_host_threads
+
+    assert 1 <= _cpu_budget() <= (os.cpu_count() or 1)
+    before = torch.get_num_threads()
+    with few_host_threads(4) as scope:
+        assert torch.get_num_threads() <= max(1, min(4, before))
+        assert 1 <= scope.n <= 4
+    assert torch.get_num_threads() == before
+    try:
+        with few_host_threads(2):
+            raise KeyError("boom")
+    except KeyError:
+        pass
+    assert torch.get_num_threads() == before
+    torch.set_num_threads(1)                  # already below the cap: left alone
+    try:
+        with few_host_threads(4):
+            assert torch.get_num_threads() == 1
+        assert torch.get_num_threads() == 1
+    finally:
+        torch.set_num_threads(before)
+
+
+def test_mel_range_ring_reports_and_skips_calls_that_never_launched():
+    """amphion_amd.utils.mel._RangeRing bookkeeping without a GPU: a slot whose copy landed is decoded (min below -1 / max above 1
+    printed, in-range values silent); a call that raised before its launch (sequence word never written) is skipped after the
+    blocking wait instead of holding every later notice back."""
+    import numpy as np
+
+    from amphion_amd.utils import mel as M
+
+    ring = M._RangeRing.__new__(M._RangeRing)
+    ring.host_np = np.zeros((M._RANGE_SLOTS, 4), np.int32)
+    ring.seq, ring.done, ring.stream_dev = 0, 0, None
+    ring.dev_ptr, ring.host_ptr = 1 << 20, 1 << 21
+    synced = []
+    real = M.torch.cuda.synchronize
+    M.torch.cuda.synchronize = lambda dev=None: synced.append(dev)
+    try:
+        d0, h0, r0, s0 = ring.next()
+        assert (d0, h0, r0, s0) == ((1 << 20) + 16, (1 << 21) + 16, (1 << 20) + 32, 1)
+        ring.next(); ring.next()
+        # call 1 landed out of range, call 2 never launched, call 3 landed in range
+        ring.host_np[1] = [np.float32(-2.5).view(np.int32), np.float32(1.0).view(np.int32), 1, 0]
+        ring.host_np[3] = [np.float32(-1.0).view(np.int32), np.float32(1.0).view(np.int32), 3, 0]
+        import contextlib, io
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            ring.flush(block=False)
+        assert "min value is  -2.5" in buf.getvalue() and "max value" not in buf.getvalue()
+        assert ring.done == 1 and not synced                       # stuck on call 2 without blocking
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            ring.flush(block=True)
+        assert ring.done == 3 and len(synced) == 1 and buf.getvalue() == ""
+    finally:
+        M.torch.cuda.synchronize = real
