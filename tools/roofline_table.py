@@ -4,7 +4,7 @@ profiles/<name>_kernel_stats.csv (rocprofv3 --kernel-trace --stats over bench.py
 FETCH_SIZE / WRITE_SIZE passes).  Algorithmic FLOPs per launch come from the kernel's template arguments and the layer
 shapes of SURVEY.md Appendix B; peaks from MI355X_MICROARCH.md (f16 MFMA 2516.6 TFLOP/s / 3 MFMAs per term, HBM 8 TB/s).
 
-    python tools/roofline_table.py [profiles/r2] > profiles/r2_roofline_table.txt
+    python tools/roofline_table.py [profiles/r3] > profiles/r3_roofline_table.txt
 """
 import csv
 import re
@@ -25,6 +25,12 @@ def shape(name):
         if "strip" in name and wm == 8:
             C = 256
         return f"fused pair C={C} k={k}", 2 * 2.0 * C * C * k * STAGE[C] * B / 1e9, 2 * TENSOR_MB(C)
+    m = re.search(r"rb_f16x3_kernel<(\d+), (\d+), (\d+), (\d+)", name)
+    if m:   # whole ResBlock1 (rb_f16x3.hip): three pairs = six convs per launch, x read once and y written once
+        k, wm, wn = int(m.group(1)), int(m.group(2)), int(m.group(3))
+        C = 32 * wm
+        form = "8 waves" if wm * wn == 8 else "4 waves"
+        return f"whole resblock C={C} k={k} ({form})", 6 * 2.0 * C * C * k * STAGE[C] * B / 1e9, 2 * TENSOR_MB(C)
     m = re.search(r"conv_f16x3_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)", name)
     if m:
         k, wm = int(m.group(1)), int(m.group(2))
