@@ -167,24 +167,36 @@ hipError_t launch_conv_post(const float* x, const float* w_dev, const float* bia
 //   s[n]  = u + invb * sin(a*u)^2                                               (snake.py:56-61)
 //   y[t]  = sum_j f[j] * s[clamp(2t + j - 5, 0, 2T-1)]                          (filter.py:92-99)
 // ---------------------------------------------------------------------------------------------
-constexpr int A1_TT = 1024;
+constexpr int A1_TT = 1024;   // outputs per workgroup tile (grid granularity) ...
+constexpr int A1_WT = 256;    // ... of which every WAVE owns a quarter, with a window and Snake buffer of its own (round 3)
 
-// NTILE consecutive tiles per workgroup.  When all of them lie inside the row, their windows are requested at
-// kernel entry by straight-line code (no register is renamed while its load is pending); otherwise a rolled loop
-// with the next tile's window in flight.  First / last / ragged tiles stage a clamped window and then run the same
-// packed arithmetic as interior tiles, with the out-of-range Snake values replicated afterwards.  NTILE = 2 keeps
-// the kernel at 64 VGPRs (8 workgroups per CU); measured on C3: NTILE 4 -> 29.0 ms, NTILE 2 -> 27.9 ms.
+// NTILE consecutive 1024-output tiles per workgroup.  Round 3: the four waves of a workgroup are INDEPENDENT -- wave w handles outputs
+// [256 w, 256 w + 256) of every tile from its own LDS slices (window 256 + 16 floats, Snake values 512 + 16), so nothing in the tile
+// loop is a workgroup barrier: LDS operations of one wave execute in order, a wave only needs its own earlier writes.  Rounds 1-2
+// staged one 1024-output tile per workgroup behind three __syncthreads per tile and the SQ counters showed the waves parked 58 % of
+// their life (profiles/r2_uv_act1d.txt); the price of independence is a 16-float window halo and 10 Snake values per 256 outputs
+// instead of per 1024.  Per element the operation sequence is unchanged (act1d_math.h): same bits.
+// When all tiles lie inside the row their windows are requested at kernel entry by straight-line code (NTILE <= 4); otherwise a rolled
+// loop with the next tile's window in flight.  First / last / ragged wave tiles stage a clamped window and then run the same packed
+// arithmetic, with the out-of-range Snake values replicated afterwards.
+// (94 registers in the strip forms = 5 waves per SIMD.  A budget for 6 / 8 waves spills 5 / 14 registers and is slower: C3 26.5 ->
+// 28.1 / 28.7 ms, profiles/r3_tu_act1d_waves.txt.)
 template <int NTILE>
 __global__ __launch_bounds__(256) void act1d_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int T,
                                                     const float* __restrict__ a_dev,
                                                     const float* __restrict__ invb_dev, const float* __restrict__ fu,
                                                     const float* __restrict__ fd, const int* __restrict__ lens,
                                                     int len_mul, int rev) {
-    // staged window xl[i] = x[clamp(t0 - 8 + i)], i < A1_TT + 16 (starts 8 before the tile: 16-B aligned rows)
-    __shared__ __attribute__((aligned(16))) float xl[A1_TT + 16];
-    __shared__ __attribute__((aligned(16))) float sl[2 * A1_TT + 16];   // swizzled (sl_pos): whole float4 pairs
-    __shared__ float ful[12];                      // up taps for the one-value-at-a-time paths: indexed by parity
+    // per wave: staged window xl[i] = x[clamp(t0w - 8 + i)], i < A1_WT + 16 (starts 8 before the wave tile: 16-B aligned rows)
+    __shared__ __attribute__((aligned(16))) float xl_all[4][A1_WT + 16];
+    __shared__ __attribute__((aligned(16))) float sl_all[4][2 * A1_WT + 16];   // swizzled (sl_pos): whole float4 pairs
+    __shared__ float ful_all[4][12];               // up taps for the one-value-at-a-time paths: indexed by parity
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* const xl = xl_all[wave];
+    float* const sl = sl_all[wave];
+    float* const ful = ful_all[wave];
     const int ntiles = (T + A1_TT - 1) / A1_TT;   // T = row stride (padded length)
     const int ngroups = (ntiles + NTILE - 1) / NTILE;
     // rev: descending workgroup order (this launch starts on what the previous one wrote last, ConvArgs::rev)
@@ -204,13 +216,14 @@ __global__ __launch_bounds__(256) void act1d_kernel(const float* __restrict__ x,
     float fu2[12], fdr[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) { fu2[k] = 2.f * fu[k]; fdr[k] = fd[k]; }
-    if (tid < 12) ful[tid] = 2.f * fu[tid];
+    if (lane < 12) ful[lane] = 2.f * fu[lane];
     const int twoT = 2 * Tv;
     const bool vec_rows = (T & 3) == 0;            // rows start 16-B aligned (x and y come from the workspace)
-    // interior tile: no index is clamped anywhere in it, and its window can be loaded as aligned float4
-    auto is_interior = [&](int t0) { return vec_rows && (t0 >= 8) && (t0 + A1_TT + 8 <= Tv); };
-    auto tile_live = [&](int tl) { return tl < NTILE && tile_first + tl < ntiles && (tile_first + tl) * A1_TT < Tv; };
-    // one Snake value from the staged window: s-index i of the tile has its k = 0 tap at xl[top], parity par
+    const int woff = A1_WT * wave;                 // this wave's quarter of a workgroup tile
+    // interior wave tile: no index is clamped anywhere in it, and its window can be loaded as aligned float4
+    auto is_interior = [&](int t0) { return vec_rows && (t0 >= 8) && (t0 + A1_WT + 8 <= Tv); };
+    auto tile_live = [&](int tl) { return tl < NTILE && tile_first + tl < ntiles && (tile_first + tl) * A1_TT + woff < Tv; };
+    // one Snake value from the staged window: s-index i of the wave tile has its k = 0 tap at xl[top], parity par
     auto snake_scalar = [&](int i) {
         const int top = ((i + 10) >> 1) + 3, par = i & 1;
         float u = 0.f;
@@ -218,33 +231,33 @@ __global__ __launch_bounds__(256) void act1d_kernel(const float* __restrict__ x,
         for (int k = 0; k < 6; ++k) u = fmaf(xl[top - k], ful[par + 2 * k], u);
         return fmaf(invb, snake_sin2(u * a), u);
     };
-    auto load_window = [&](int tl, float4& w0, float4& w1) {      // issue the global loads of an interior tile
-        const int t0 = (tile_first + tl) * A1_TT;
+    auto load_window = [&](int tl, float4& w0, float4& w1) {      // issue the global loads of an interior wave tile
+        const int t0 = (tile_first + tl) * A1_TT + woff;
         if (tile_live(tl) && is_interior(t0)) {
-            w0 = *reinterpret_cast<const float4*>(xr + t0 - 8 + 4 * tid);
-            if (tid < 4) w1 = *reinterpret_cast<const float4*>(xr + t0 - 8 + A1_TT + 4 * tid);
+            w0 = *reinterpret_cast<const float4*>(xr + t0 - 8 + 4 * lane);
+            if (lane < 4) w1 = *reinterpret_cast<const float4*>(xr + t0 - 8 + A1_WT + 4 * lane);
         }
     };
 
-    // ---- one tile: v0 / v1 = its window when it is interior ----
+    // ---- one wave tile: v0 / v1 = its window when it is interior ----
     auto process_tile = [&](const int t0, const bool interior, const float4 v0, const float4 v1) __attribute__((always_inline)) {
         if (interior) {
-            *reinterpret_cast<float4*>(&xl[4 * tid]) = v0;
-            if (tid < 4) *reinterpret_cast<float4*>(&xl[A1_TT + 4 * tid]) = v1;
+            *reinterpret_cast<float4*>(&xl[4 * lane]) = v0;
+            if (lane < 4) *reinterpret_cast<float4*>(&xl[A1_WT + 4 * lane]) = v1;
         } else {
             // the replicate-padded window itself: every tap below then reads x[clamp(.)] as resample.py:36 does
-            for (int i = tid; i < A1_TT + 16; i += 256) {
+            for (int i = lane; i < A1_WT + 16; i += 64) {
                 int t = t0 - 8 + i;
                 t = t < 0 ? 0 : (t > Tv - 1 ? Tv - 1 : t);
                 xl[i] = xr[t];
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         {
-            // Snake values i = 8*tid + e, e < 8 (n = 2*t0 + i - 5) need x[((n + 15) >> 1) - k - 5], k = 0..5
-            //   = xl[4*tid + ((e + 10) >> 1) + 3 - k]: a 12-float window at xl[4*tid].  Values e = 2q, 2q+1
+            // Snake values i = 8*lane + e, e < 8 (n = 2*t0 + i - 5) need x[((n + 15) >> 1) - k - 5], k = 0..5
+            //   = xl[4*lane + ((e + 10) >> 1) + 3 - k]: a 12-float window at xl[4*lane].  Values e = 2q, 2q+1
             // share their six x taps and take the even / odd phase of the filter: one packed chain.
-            const int xb = 4 * tid;
+            const int xb = 4 * lane;
             const float4 w0 = *reinterpret_cast<const float4*>(&xl[xb]);
             const float4 w1 = *reinterpret_cast<const float4*>(&xl[xb + 4]);
             const float4 w2 = *reinterpret_cast<const float4*>(&xl[xb + 8]);
@@ -264,47 +277,47 @@ __global__ __launch_bounds__(256) void act1d_kernel(const float* __restrict__ x,
             snake_sin2_pk4(xa, sv);
 #pragma unroll
             for (int q = 0; q < 4; ++q) sv[q] = pk_fma(pk_splat(invb), sv[q], uv[q]);
-            *reinterpret_cast<float4*>(&sl[4 * sl_pos4(2 * tid)]) = make_float4(sv[0].x, sv[0].y, sv[1].x, sv[1].y);
-            *reinterpret_cast<float4*>(&sl[4 * sl_pos4(2 * tid + 1)]) = make_float4(sv[2].x, sv[2].y, sv[3].x, sv[3].y);
+            *reinterpret_cast<float4*>(&sl[4 * sl_pos4(2 * lane)]) = make_float4(sv[0].x, sv[0].y, sv[1].x, sv[1].y);
+            *reinterpret_cast<float4*>(&sl[4 * sl_pos4(2 * lane + 1)]) = make_float4(sv[2].x, sv[2].y, sv[3].x, sv[3].y);
             if (__builtin_expect(big > 1.0e5f, 0)) {
                 // beyond the fast range reduction: redo this lane's eight values one at a time through
                 // snake_sin2 (libm sine above 1e5, the identical operation sequence below it)
 #pragma nounroll
-                for (int e = 0; e < 8; ++e) sl[sl_pos(8 * tid + e)] = snake_scalar(8 * tid + e);
+                for (int e = 0; e < 8; ++e) sl[sl_pos(8 * lane + e)] = snake_scalar(8 * lane + e);
             }
-            // the 10 values past the 2048 (the down filter's right halo): one lane each in the last wave
-            if (tid >= 256 - 10) {
-                const int i = 2 * A1_TT + (tid - (256 - 10));
+            // the 10 values past the 512 (the down filter's right halo): one lane each
+            if (lane >= 64 - 10) {
+                const int i = 2 * A1_WT + (lane - (64 - 10));
                 sl[sl_pos(i)] = snake_scalar(i);
             }
         }
         if (!interior) {
             // DownSample1d pads the SNAKE OUTPUT by replication (filter.py:92-99): values whose n = 2*t0 + i - 5
             // lies outside [0, 2*Tv - 1] are copies of the first / last valid one, not filter results
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
             const int ilo = 5 - 2 * t0;                       // i of n = 0
             const int ihi = twoT + 4 - 2 * t0;                // i of n = 2*Tv - 1  (>= 6: t0 < Tv)
             const float slo = sl[sl_pos(ilo > 0 ? ilo : 0)];
-            const float shi = sl[sl_pos(ihi < 2 * A1_TT + 9 ? ihi : 2 * A1_TT + 9)];
-            __syncthreads();
+            const float shi = sl[sl_pos(ihi < 2 * A1_WT + 9 ? ihi : 2 * A1_WT + 9)];
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const int i = 8 * tid + e;
+                const int i = 8 * lane + e;
                 if (i < ilo) sl[sl_pos(i)] = slo;
                 else if (i > ihi) sl[sl_pos(i)] = shi;
             }
-            if (tid >= 256 - 10) {
-                const int i = 2 * A1_TT + (tid - (256 - 10));
+            if (lane >= 64 - 10) {
+                const int i = 2 * A1_WT + (lane - (64 - 10));
                 if (i > ihi) sl[sl_pos(i)] = shi;
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         {
-            const int k0 = 4 * tid;                           // outputs k0..k0+3 need sl[2*k0 .. 2*k0 + 17]
+            const int k0 = 4 * lane;                          // outputs k0..k0+3 need sl[2*k0 .. 2*k0 + 17]
             f32x2 sw[10];
 #pragma unroll
             for (int v = 0; v < 5; ++v) {
-                const float4 q = *reinterpret_cast<const float4*>(&sl[4 * sl_pos4(2 * tid + v)]);
+                const float4 q = *reinterpret_cast<const float4*>(&sl[4 * sl_pos4(2 * lane + v)]);
                 sw[2 * v] = (f32x2){q.x, q.y};
                 sw[2 * v + 1] = (f32x2){q.z, q.w};
             }
@@ -325,24 +338,24 @@ __global__ __launch_bounds__(256) void act1d_kernel(const float* __restrict__ x,
                     if (t0 + k0 + e < Tv) yr[t0 + k0 + e] = op[e];
             }
         }
-        __syncthreads();   // xl / sl are rewritten by the next tile
+        __builtin_amdgcn_wave_barrier();   // xl / sl are rewritten by this wave's next tile
     };
 
-    // do all NTILE tiles of this workgroup exist and lie inside the row (block-uniform)?
+    // do all NTILE tiles of this workgroup exist and lie inside the row?  (per wave: its quarter of the first and the last tile)
     // NTILE >= 8: always the rolled loop -- a workgroup lives long enough (8+ tiles) for its start-up (scalar loads of
     // the taps, the first window's latency: 40 % of a 2-tile workgroup's life, visit U) to stop mattering, with the
     // next window always in flight
-    const bool all_interior = NTILE <= 4 && tile_first + NTILE <= ntiles && is_interior(tile_first * A1_TT) &&
-                              is_interior((tile_first + NTILE - 1) * A1_TT);
+    const bool all_interior = NTILE <= 4 && tile_first + NTILE <= ntiles && is_interior(tile_first * A1_TT + woff) &&
+                              is_interior((tile_first + NTILE - 1) * A1_TT + woff);
     if (all_interior) {
         // straight-line path: every window requested now, by every lane (lanes >= 4 repeat the halo address of
         // lane & 3, so no load is conditional and none has to be waited for before its tile comes up)
         float4 w0[NTILE], w1[NTILE];
 #pragma unroll
         for (int tl = 0; tl < NTILE; ++tl) {
-            const float* wp = xr + (tile_first + tl) * A1_TT - 8;
-            w0[tl] = *reinterpret_cast<const float4*>(wp + 4 * tid);
-            w1[tl] = *reinterpret_cast<const float4*>(wp + A1_TT + 4 * (tid & 3));
+            const float* wp = xr + (tile_first + tl) * A1_TT + woff - 8;
+            w0[tl] = *reinterpret_cast<const float4*>(wp + 4 * lane);
+            w1[tl] = *reinterpret_cast<const float4*>(wp + A1_WT + 4 * (lane & 3));
             // keep the requests together at the top (the machine scheduler would otherwise interleave them with
             // address arithmetic).  hipcc still sinks tile 0's pair below the others, to its first use: harmless,
             // loads return in issue order and tile 0 has to wait one full latency either way.
@@ -350,13 +363,14 @@ __global__ __launch_bounds__(256) void act1d_kernel(const float* __restrict__ x,
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int tl = 0; tl < NTILE; ++tl) process_tile((tile_first + tl) * A1_TT, true, w0[tl], w1[tl]);
+        for (int tl = 0; tl < NTILE; ++tl) process_tile((tile_first + tl) * A1_TT + woff, true, w0[tl], w1[tl]);
     } else {
         float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
         load_window(0, p0, p1);
         for (int tl = 0; tl < NTILE; ++tl) {
-            const int t0 = (tile_first + tl) * A1_TT;
-            if (!tile_live(tl)) break;             // nothing valid from here on (block-uniform)
+            if (tile_first + tl >= ntiles) break;             // no tile left in the row (block-uniform)
+            const int t0 = (tile_first + tl) * A1_TT + woff;
+            if (t0 >= Tv) break;                              // nothing valid for this wave from here on (wave-uniform)
             const float4 v0 = p0, v1 = p1;
             load_window(tl + 1, p0, p1);           // in flight under this tile's arithmetic
             process_tile(t0, is_interior(t0), v0, v1);

@@ -1,1 +1,1 @@
-bash tools/gpu_round.sh r3_final tests bench prof pmc sq configs f32 smoke
+bash tools/gpu_round.sh r3_v tests
