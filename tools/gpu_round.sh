@@ -5,7 +5,7 @@
 #           bench     the full bench.py line (CPU / library baselines, other configs)            -> bench.json
 #           prof      rocprofv3 --kernel-trace --stats over bench.py --no-cpu-baseline           -> prof/kt_kernel_stats.csv
 #           pmc       FETCH_SIZE and WRITE_SIZE passes (separate runs, kernel-trace only)         -> pmc_fetch/, pmc_write/
-#           sq        four SQ counter passes over ONE config-2 forward                            -> sq_table.csv
+#           sq        four SQ counter passes over ONE config-2 forward (or $SQCMD)                -> sq_table.csv, sq_summary.txt
 #           configs   tools/bench_configs.py (C3, C5, mel, list API, latency)                     -> other_configs.jsonl
 #           f32       bench.py --precision f32 --no-cpu-baseline                                  -> bench_f32.json
 #           smoke     __graft_entry__.py --smoke
@@ -33,7 +33,7 @@ for STEP in $STEPS; do
       ( cd /tmp && timeout 600 $PROF --pmc FETCH_SIZE -d $REPO/$OUT/pmc_fetch -o pf -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $REPO/$OUT/pmc_fetch.err )
       ( cd /tmp && timeout 600 $PROF --pmc WRITE_SIZE -d $REPO/$OUT/pmc_write -o pw -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $REPO/$OUT/pmc_write.err ) ;;
     sq)
-      SQCMD="python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline"
+      SQCMD=${SQCMD:-"python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline"}     # SQCMD=<other command>: counters of another workload
       ( cd /tmp
         timeout 300 $PROF --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $REPO/$OUT/sq_a -o a -- $SQCMD > /dev/null 2> $REPO/$OUT/sq_a.err
         timeout 300 $PROF --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU_MFMA_MOPS_F16 -d $REPO/$OUT/sq_b -o b -- $SQCMD > /dev/null 2> $REPO/$OUT/sq_b.err
