@@ -796,9 +796,10 @@ static int rb_form(int C, int k) {
     if (C == 64 || C == 128) return 1;           // C = 128: k <= 5 only (rb_tile)
     return -1;
 }
-// the workgroups of a launch must fill the chip (256 CUs) at least twice over; a single utterance keeps the pairs' 4x more
-// numerous tiles (same bits)
-constexpr long long kRbMinWorkgroups = 512;
+// the workgroups of a launch must at least fill the chip (256 CUs): a short single utterance keeps the pairs' 4x more numerous
+// tiles (same bits).  One utterance, forced either way (profiles/r3_lat_rb_threshold.txt): 3 s (134 tiles at stage 3) 1.07 ms on
+// pairs against 1.11-1.17 on this kernel; 10 s (451 tiles) 2.31 against 2.23.
+constexpr long long kRbMinWorkgroups = 256;
 
 static bool rb_supported(const std::vector<std::unique_ptr<amp_conv>>& c1, const std::vector<std::unique_ptr<amp_conv>>& c2, int B, int T) {
     const int np = (int)c1.size();
