@@ -412,9 +412,14 @@ def main():
             result["gather_check"] = gather_check
         if not args.no_cpu_baseline and world == 1:
             del out
-            result["other_configs"] = other_configs()
-            result["library_baseline"] = library_baseline(sd, hp, device)
-            result["cpu_baseline"] = cpu_baseline(sd, hp)
+            # the side legs must never cost the headline line: a failure is reported in place of the figure
+            for key, leg in (("other_configs", other_configs), ("library_baseline", lambda: library_baseline(sd, hp, device)),
+                             ("cpu_baseline", lambda: cpu_baseline(sd, hp))):
+                try:
+                    result[key] = leg()
+                except Exception as e:  # noqa: BLE001
+                    result[key] = {"error": f"{type(e).__name__}: {e}"[:500]}
+                    torch.cuda.empty_cache()
         print(json.dumps(result))
     if world > 1:
         dist.barrier()
