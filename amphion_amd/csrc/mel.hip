@@ -125,8 +125,9 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ wav,
 //   X[k] = E - i W^k O with the partner Z[512 - k] fetched by a lane permute  ->  |X| -> LDS  ->  mel filterbank
 //   over each filter's non-zero band  ->  log  ->  LDS tile [mel][32 frames]  ->  128-B row stores.
 //
-// The twiddles of passes 1 / 2 and of the split depend only on (lane, q): computed once per wave with sincospif
-// and held in registers for all its frames, like the 16 window values of the lane's sample slots.  A workgroup is
+// The twiddles of passes 1 / 2 and of the split depend only on (lane, q): read once per wave from a 4.5-KB device table
+// (g_mel_tw, filled from the host with correctly rounded values at the first launch on each device -- 15 sincospif calls per
+// lane were a fifth of the kernel's VALU work) and held in registers for all its frames.  A workgroup is
 // 8 waves x 4 frames = 32 consecutive frames of one utterance: the samples are read straight from global memory
 // (each lane 2 consecutive samples per slot = one 512-B wave access; the 4x frame overlap is served by L1 / L2).
 // mag / re / im outputs (extract_linear_features, amplitude_phase_spectrum) are written per frame at stride F.
@@ -168,12 +169,53 @@ __device__ constexpr float kC16[8] = {1.f, 0.92387953251128674f, 0.7071067811865
 __device__ constexpr float kS16[8] = {0.f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f,
                                       1.f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f};
 
+// twiddle table of mel1024_kernel: tw1[q - 1][k] = exp(-2 pi i q k / 64), tw2[q - 1][j] = exp(-2 pi i q j / 512),
+// wsp[j] = exp(-2 pi i j / 1024)
+struct MelTwiddles {
+    float2 tw1[7][8];
+    float2 tw2[7][64];
+    float2 wsp[64];
+};
+__device__ MelTwiddles g_mel_tw;
+
+// exp(-2 pi i n / N) rounded to fp32 from long double; the multiples of an eighth turn come out exact
+static float2 unit_root(int n, int N) {
+    n %= N;
+    if ((8 * n) % N == 0) {
+        const float h = 0.70710678118654752440f;
+        const float c[8] = {1.f, h, 0.f, -h, -1.f, -h, 0.f, h};
+        const float sn[8] = {0.f, -h, -1.f, -h, 0.f, h, 1.f, h};
+        return make_float2(c[8 * n / N], sn[8 * n / N]);
+    }
+    const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)n / (long double)N;
+    return make_float2((float)cosl(a), (float)sinl(a));
+}
+
+static hipError_t upload_mel_twiddles() {
+    MelTwiddles t;
+    for (int q = 1; q < 8; ++q) {
+        for (int k = 0; k < 8; ++k) t.tw1[q - 1][k] = unit_root(q * k, 64);
+        for (int j = 0; j < 64; ++j) t.tw2[q - 1][j] = unit_root(q * j, 512);
+    }
+    for (int j = 0; j < 64; ++j) t.wsp[j] = unit_root(j, 1024);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_mel_tw), &t, sizeof(t), 0, hipMemcpyHostToDevice);
+}
+
 constexpr int MEL_WAVES = 8;       // waves per workgroup
 constexpr int MEL_FPW = 4;         // frames per wave
 constexpr int MEL_FPB = MEL_WAVES * MEL_FPW;   // 32 frames per workgroup: one 128-B row of every mel channel
 constexpr int MEL_XROW = 10;       // exchange-buffer row: 8 complex + 2 pad (80 B: the 16-B stores of pass 0 stay aligned)
 constexpr int MEL_MAGROW = 520;    // 513 bins, padded
 constexpr int MEL_MAXMEL = 256;
+constexpr int MEL_WCAP = 1664;     // packed filter weights kept in LDS, every band padded to a multiple of 8 (triangular filters
+                                   // on 513 bins hold <= ~1030 non-zeros; + <= 7 per filter: 1600 for 128 filters)
+
+// LDS floats of mel1024_kernel for n_mel filters: packed weights, magnitude rows, exchange buffers, mel tile, band tables
+// ([n_mel + 1] + [n_mel] 16-bit entries + the 32-bit total)
+constexpr size_t mel1024_lds_floats(int n_mel) {
+    return (size_t)(MEL_WCAP + 4) + (size_t)(MEL_WAVES * MEL_MAGROW + 2 * MEL_WAVES * 64 * MEL_XROW)
+           + (size_t)n_mel * (MEL_FPB + 1) + (size_t)(1 + (2 * n_mel + 2) / 2);
+}
 
 __global__ __launch_bounds__(64 * MEL_WAVES, 4) void mel1024_kernel(const float* __restrict__ wav, const int* __restrict__ lens,
                                                                   int L, int F, int hop, int pad, int n_mel, float mag_eps,
@@ -185,9 +227,10 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 4) void mel1024_kernel(const float*
     constexpr int N = 1024, M = 512, BINS = 513;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     mel_range_begin(rng);
-    float2* const xch = reinterpret_cast<float2*>(smem);                      // [MEL_WAVES][64 * MEL_XROW]
-    float* const magl = smem + 2 * MEL_WAVES * 64 * MEL_XROW;                 // [MEL_WAVES][MEL_MAGROW]
-    float* const melt = magl + MEL_WAVES * MEL_MAGROW;                        // [n_mel][MEL_FPB + 1]
+    float* const wl = smem;                                                   // [MEL_WCAP + 4] packed filter weights
+    float* const magl = wl + MEL_WCAP + 4;                                    // [MEL_WAVES][MEL_MAGROW]
+    float2* const xch = reinterpret_cast<float2*>(magl + MEL_WAVES * MEL_MAGROW);   // [MEL_WAVES][64 * MEL_XROW]
+    float* const melt = magl + MEL_WAVES * MEL_MAGROW + 2 * MEL_WAVES * 64 * MEL_XROW;   // [n_mel][MEL_FPB + 1]
     const int tid = threadIdx.x;
     const int j = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -205,6 +248,61 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 4) void mel1024_kernel(const float*
     }
     if (f0 >= Fi) return;   // workgroup-uniform
 
+    // mel projection tables: the non-zero band of every filter is copied ONCE per workgroup into LDS, filter after filter, each
+    // padded with zeros to a multiple of eight (wl[offs[m] + i] = basis[m][lo_m + i]), so the per-frame projection reads LDS
+    // instead of one cache line per lane and step from L2.  Same products in the same order (k ascending inside the band) as
+    // the loop over the global rows it replaces; the padding adds 0 * (a finite magnitude) = nothing.
+    int* const total_p = reinterpret_cast<int*>(melt + n_mel * (MEL_FPB + 1));  // sum of the padded widths
+    unsigned short* const offs = reinterpret_cast<unsigned short*>(total_p + 1);  // [n_mel + 1] exclusive prefix of padded widths
+    unsigned short* const los = offs + n_mel + 1;                                 // [n_mel] first bin of each band
+    bool packed = false;                                                          // workgroup-uniform
+    if (mel && bands) {
+        if (w == 0) {                                // one wave: exclusive scan over the widths, four filters per lane
+            int wd[4], sum = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int m = 4 * j + t;
+                wd[t] = 0;
+                if (m < n_mel) {
+                    const int lo = bands[2 * m], hi = bands[2 * m + 1];
+                    wd[t] = hi > lo ? (hi - lo + 7) & ~7 : 0;
+                    los[m] = (unsigned short)lo;
+                }
+                sum += wd[t];
+            }
+            int incl = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(incl, d, 64);
+                if (j >= d) incl += o;
+            }
+            int base = incl - sum;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int m = 4 * j + t;
+                if (m <= n_mel) offs[m] = (unsigned short)base;       // (wraps only when the total exceeds MEL_WCAP: unused then)
+                base += wd[t];
+            }
+            if (j == 63) { *total_p = incl; if (n_mel == MEL_MAXMEL) offs[n_mel] = (unsigned short)incl; }
+        }
+        if (j < MEL_MAGROW - BINS) magl[w * MEL_MAGROW + BINS + j] = 0.f;      // the row's pad: read under a zero weight
+        __syncthreads();
+        const int total = *total_p;
+        packed = total <= MEL_WCAP;
+        if (packed) {
+            for (int e = tid; e < total; e += 64 * MEL_WAVES) {
+                int ml = 0, mh = n_mel;              // offs[ml] <= e < offs[mh]
+                while (mh - ml > 1) {
+                    const int mid = (ml + mh) >> 1;
+                    if ((int)offs[mid] <= e) ml = mid; else mh = mid;
+                }
+                const int k = (int)los[ml] + (e - (int)offs[ml]);
+                wl[e] = k < bands[2 * ml + 1] ? melbasis[(size_t)ml * BINS + k] : 0.f;
+            }
+        }
+        __syncthreads();
+    }
+
     // lane constants: twiddles (the 16 window values of the lane's sample slots are re-read per frame: L1 hits,
     // and 16 registers fewer keep two workgroups per CU)
     const float2* win = reinterpret_cast<const float2*>(window) + j;
@@ -212,18 +310,10 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 4) void mel1024_kernel(const float*
     const int k1 = j & 7;
 #pragma unroll
     for (int q = 1; q < 8; ++q) {
-        float sn, cs;
-        sincospif(-2.0f * (float)(q * k1) / 64.0f, &sn, &cs);     // pass 1: exp(-2 pi i q k / 64),  k = j mod 8
-        tw1[q] = make_float2(cs, sn);
-        sincospif(-2.0f * (float)(q * j) / 512.0f, &sn, &cs);     // pass 2: exp(-2 pi i q j / 512)
-        tw2[q] = make_float2(cs, sn);
+        tw1[q] = g_mel_tw.tw1[q - 1][k1];                         // pass 1: exp(-2 pi i q k / 64),  k = j mod 8
+        tw2[q] = g_mel_tw.tw2[q - 1][j];                          // pass 2: exp(-2 pi i q j / 512)
     }
-    float2 wsp;                                                   // split: exp(-2 pi i j / 1024)
-    {
-        float sn, cs;
-        sincospif(-2.0f * (float)j / 1024.0f, &sn, &cs);
-        wsp = make_float2(cs, sn);
-    }
+    const float2 wsp = g_mel_tw.wsp[j];                           // split: exp(-2 pi i j / 1024)
     float2* xw = xch + w * (64 * MEL_XROW);
     float* mg = magl + w * MEL_MAGROW;
     float rlo = 0.f, rhi = 0.f;                    // extreme samples this lane read (utils/mel.py:21-24, mel_range_end)
@@ -317,7 +407,35 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 4) void mel1024_kernel(const float*
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if (mel) {
+        if (mel && packed) {
+            // a lane runs filter m, then filter m + 64, as ONE stream of eight-step trips (the narrow low filters share a lane
+            // with the wide high ones, and a lane that is through leaves the loop: no reads past a band)
+            for (int m0 = j; m0 < n_mel; m0 += 128) {
+                const int m1 = m0 + 64;
+                const int oa = offs[m0], na = (int)offs[m0 + 1] - oa;
+                int ob = 0, nb = 0, lb = 0;
+                if (m1 < n_mel) { ob = offs[m1]; nb = (int)offs[m1 + 1] - ob; lb = los[m1]; }
+                const int nt = na + nb;
+                const float* pw = wl + oa;
+                const float* pg = mg + (int)los[m0];
+                float acc = 0.f, acca = 0.f;
+                for (int i = 0; i < nt; i += 8) {
+                    if (i == na) { acca = acc; acc = 0.f; pw = wl + ob; pg = mg + lb; }     // first filter done
+                    const float4 w4 = *reinterpret_cast<const float4*>(pw), w8 = *reinterpret_cast<const float4*>(pw + 4);
+                    float x[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) x[u] = pg[u];
+                    acc = fmaf(w4.x, x[0], acc); acc = fmaf(w4.y, x[1], acc); acc = fmaf(w4.z, x[2], acc); acc = fmaf(w4.w, x[3], acc);
+                    acc = fmaf(w8.x, x[4], acc); acc = fmaf(w8.y, x[5], acc); acc = fmaf(w8.z, x[6], acc); acc = fmaf(w8.w, x[7], acc);
+                    pw += 8; pg += 8;
+                }
+                float accb = 0.f;
+                if (nb > 0) accb = acc; else acca = acc;
+                if (log_clip > 0.f) { acca = logf(fmaxf(acca, log_clip)); accb = logf(fmaxf(accb, log_clip)); }
+                melt[m0 * (MEL_FPB + 1) + fl] = acca;
+                if (m1 < n_mel) melt[m1 * (MEL_FPB + 1) + fl] = accb;
+            }
+        } else if (mel) {
             for (int m = j; m < n_mel; m += 64) {
                 const int lo = bands ? bands[2 * m] : 0;
                 const int hi = bands ? bands[2 * m + 1] : BINS;
@@ -348,13 +466,15 @@ hipError_t launch_mel(const amp_mel_desc& d, const float* wav, const int* lens, 
     const MelRange rng{d.range_dev, d.range_reset_dev, d.range_seq};
     if (d.n_fft == 1024 && n_mel <= MEL_MAXMEL && (pad & 1) == 0 && (d.hop_size & 1) == 0) {
         // wave-per-frame radix-8 real FFT (every shipped config of the reference)
-        const size_t lds = (size_t)(2 * MEL_WAVES * 64 * MEL_XROW + MEL_WAVES * MEL_MAGROW + (size_t)n_mel * (MEL_FPB + 1)) * sizeof(float);
+        const size_t lds = mel1024_lds_floats(n_mel) * sizeof(float);
         static unsigned long long attr_set = 0;   // per device
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
         if (!((attr_set >> dev) & 1ull)) {
-            const size_t mx = (size_t)(2 * MEL_WAVES * 64 * MEL_XROW + MEL_WAVES * MEL_MAGROW + (size_t)MEL_MAXMEL * (MEL_FPB + 1)) * sizeof(float);
+            const size_t mx = mel1024_lds_floats(MEL_MAXMEL) * sizeof(float);
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mel1024_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx);
+            if (e != hipSuccess) return e;
+            e = upload_mel_twiddles();      // synchronous, once per device (so: not inside a stream capture)
             if (e != hipSuccess) return e;
             attr_set |= 1ull << dev;
         }
