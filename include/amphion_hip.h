@@ -424,7 +424,9 @@ int amp_mel_num_frames(const amp_mel_desc* d, int L);
  * and TacotronSTFT.mel_spectrogram (utils/stft.py:259-278).
  * wav_dev [B, L]; window_dev [n_fft] (already centre-padded to n_fft); melbasis_dev [n_mel, n_fft/2+1]
  * (may be NULL when n_mel == 0).  Outputs (any may be NULL): mel_dev [B, n_mel, F] (log-mel),
- * mag_dev [B, n_fft/2+1, F] (magnitude), re_dev/im_dev [B, n_fft/2+1, F]. */
+ * mag_dev [B, n_fft/2+1, F] (magnitude), re_dev/im_dev [B, n_fft/2+1, F].
+ * The first n_fft = 1024 call on a device uploads a 4.5-KB twiddle table synchronously (hipMemcpyToSymbol): make that call
+ * outside a stream capture. */
 int amp_mel_forward(const amp_mel_desc* d, const float* wav_dev, int B, int L, const float* window_dev,
                     const float* melbasis_dev, float* mel_dev, float* mag_dev, float* re_dev, float* im_dev,
                     void* stream);
