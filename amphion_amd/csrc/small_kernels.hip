@@ -182,7 +182,7 @@ constexpr int A1_WT = 256;    // ... of which every WAVE owns a quarter, with a 
 // (94 registers in the strip forms = 5 waves per SIMD.  A budget for 6 / 8 waves spills 5 / 14 registers and is slower: C3 26.5 ->
 // 28.1 / 28.7 ms, profiles/r3_tu_act1d_waves.txt.)
 template <int NTILE>
-__global__ __launch_bounds__(256) void act1d_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int T,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void act1d_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int T,
                                                     const float* __restrict__ a_dev,
                                                     const float* __restrict__ invb_dev, const float* __restrict__ fu,
                                                     const float* __restrict__ fd, const int* __restrict__ lens,
@@ -239,8 +239,8 @@ __global__ __launch_bounds__(256) void act1d_kernel(const float* __restrict__ x,
         }
     };
 
-    // ---- one wave tile: v0 / v1 = its window when it is interior ----
-    auto process_tile = [&](const int t0, const bool interior, const float4 v0, const float4 v1) __attribute__((always_inline)) {
+    // ---- one wave tile, in two steps: the window into LDS (v0 / v1 = the window when the tile is interior) ... ----
+    auto stage_window = [&](const int t0, const bool interior, const float4 v0, const float4 v1) __attribute__((always_inline)) {
         if (interior) {
             *reinterpret_cast<float4*>(&xl[4 * lane]) = v0;
             if (lane < 4) *reinterpret_cast<float4*>(&xl[A1_WT + 4 * lane]) = v1;
@@ -253,6 +253,9 @@ __global__ __launch_bounds__(256) void act1d_kernel(const float* __restrict__ x,
             }
         }
         __builtin_amdgcn_wave_barrier();
+    };
+    // ---- ... and the arithmetic from there to the store ----
+    auto compute_tile = [&](const int t0, const bool interior) __attribute__((always_inline)) {
         {
             // Snake values i = 8*lane + e, e < 8 (n = 2*t0 + i - 5) need x[((n + 15) >> 1) - k - 5], k = 0..5
             //   = xl[4*lane + ((e + 10) >> 1) + 3 - k]: a 12-float window at xl[4*lane].  Values e = 2q, 2q+1
@@ -340,6 +343,10 @@ __global__ __launch_bounds__(256) void act1d_kernel(const float* __restrict__ x,
         }
         __builtin_amdgcn_wave_barrier();   // xl / sl are rewritten by this wave's next tile
     };
+    auto process_tile = [&](const int t0, const bool interior, const float4 v0, const float4 v1) __attribute__((always_inline)) {
+        stage_window(t0, interior, v0, v1);
+        compute_tile(t0, interior);
+    };
 
     // do all NTILE tiles of this workgroup exist and lie inside the row?  (per wave: its quarter of the first and the last tile)
     // NTILE >= 8: always the rolled loop -- a workgroup lives long enough (8+ tiles) for its start-up (scalar loads of
@@ -365,15 +372,43 @@ __global__ __launch_bounds__(256) void act1d_kernel(const float* __restrict__ x,
 #pragma unroll
         for (int tl = 0; tl < NTILE; ++tl) process_tile((tile_first + tl) * A1_TT + woff, true, w0[tl], w1[tl]);
     } else {
-        float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
-        load_window(0, p0, p1);
-        for (int tl = 0; tl < NTILE; ++tl) {
+        // Rolled strip.  Runs of interior tiles go through a loop of their own whose body is: window registers -> LDS, the NEXT
+        // window's loads into the same registers, arithmetic, ONE store.  On this hardware stores count in vmcnt like loads, so
+        // the wait for a window at the top of the loop is "all but the one younger store" -- the previous form (next window
+        // requested before the current one was staged, so the registers were copied at the loop's latch) waited for vmcnt(0)
+        // there and parked every wave on the acknowledgement of its own store once per tile.  The row's first / last / ragged
+        // tiles (clamped windows, conditional stores) stay outside that loop, one at a time.
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        int tl = 0;
+        while (tl < NTILE) {
             if (tile_first + tl >= ntiles) break;             // no tile left in the row (block-uniform)
-            const int t0 = (tile_first + tl) * A1_TT + woff;
+            int t0 = (tile_first + tl) * A1_TT + woff;
             if (t0 >= Tv) break;                              // nothing valid for this wave from here on (wave-uniform)
-            const float4 v0 = p0, v1 = p1;
-            load_window(tl + 1, p0, p1);           // in flight under this tile's arithmetic
-            process_tile(t0, is_interior(t0), v0, v1);
+            if (!is_interior(t0)) { process_tile(t0, false, z4, z4); ++tl; continue; }
+            const float* wp = xr + t0 - 8;
+            float4 p0 = *reinterpret_cast<const float4*>(wp + 4 * lane);
+            float4 p1 = *reinterpret_cast<const float4*>(wp + A1_WT + 4 * (lane & 3));     // (every lane: no conditional load)
+            // (the run's first tile is peeled: every way into the loop below then has the same memory operations behind it --
+            //  two loads, one store -- and the compiler's wait counts come out exact instead of the conservative zero)
+            auto next_is_interior = [&]() { return tl + 1 < NTILE && tile_first + tl + 1 < ntiles && is_interior(t0 + A1_TT); };
+            auto request_next = [&]() {                       // in flight under this tile's arithmetic
+                p0 = *reinterpret_cast<const float4*>(wp + A1_TT + 4 * lane);
+                p1 = *reinterpret_cast<const float4*>(wp + A1_TT + A1_WT + 4 * (lane & 3));
+            };
+            stage_window(t0, true, p0, p1);
+            bool more = next_is_interior();
+            if (more) request_next();
+            compute_tile(t0, true);
+            ++tl;
+            while (more) {
+                t0 += A1_TT;
+                wp += A1_TT;
+                stage_window(t0, true, p0, p1);
+                more = next_is_interior();
+                if (more) request_next();
+                compute_tile(t0, true);
+                ++tl;
+            }
         }
     }
 }
