@@ -13,33 +13,67 @@ __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + e
 
 // LayerNorm over the CHANNEL axis (modules/base/base_module.py:20-23), optionally of x + res (Encoder's
 // norm(x + y), modules/transformer/attentions.py:69,73) and optionally followed by GELU (DDSConv,
-// modules/flow/modules.py:64-68) and by "+ post" (DDSConv's x = x + y, :70).  One thread per (b, t): mean, biased
-// variance, normalise.
+// modules/flow/modules.py:64-68) and by "+ post" (DDSConv's x = x + y, :70).
+// A workgroup = 32 time columns x 8 channel groups: thread (tx, g) holds channels g, g + 8, ... of column tx in registers (up to
+// 32 of them = C <= 256; more are re-read), rows are read as 128-B segments, and the two reductions over C (mean, then the biased
+// variance of the centred values -- two passes, like the op it replaces) go through LDS in a fixed order.  Round 3: the first
+// version ran ONE thread per (b, t) with three serial loops over C -- 120 us per call at B = 16, C = 192, T = 150 (16 workgroups
+// of 150 live threads, 576 dependent loads each), a third of VITS text -> wave.
+constexpr int LN_TT = 32, LN_G = 8, LN_NC = 32;
 __global__ __launch_bounds__(256) void layer_norm_c_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ post,
                                                            float* __restrict__ y, int C, int T, float eps, int gelu) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float red[LN_G][LN_TT + 1];
+    const int tx = threadIdx.x & (LN_TT - 1), g = threadIdx.x / LN_TT;
+    const int t = blockIdx.x * LN_TT + tx;
     const int b = blockIdx.y;
-    if (t >= T) return;
-    const float* xb = x + (size_t)b * C * T + t;
-    const float* rb = res ? res + (size_t)b * C * T + t : nullptr;
-    float mu = 0.f;
-    for (int c = 0; c < C; ++c) mu += xb[(size_t)c * T] + (rb ? rb[(size_t)c * T] : 0.f);
-    mu /= (float)C;
-    float var = 0.f;
-    for (int c = 0; c < C; ++c) {
-        const float d = xb[(size_t)c * T] + (rb ? rb[(size_t)c * T] : 0.f) - mu;
-        var += d * d;
+    const bool ok = t < T;
+    const size_t base = (size_t)b * C * T + (ok ? t : 0);
+    const float* xb = x + base;
+    const float* rb = res ? res + base : nullptr;
+    auto value = [&](int c) { return xb[(size_t)c * T] + (rb ? rb[(size_t)c * T] : 0.f); };
+    auto reduce = [&](float part) {                      // sum over the 8 channel groups of column tx, same order in every thread
+        red[g][tx] = part;
+        __syncthreads();
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_G; ++k) s += red[k][tx];
+        __syncthreads();
+        return s;
+    };
+    float v[LN_NC];
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_NC; ++i) {
+        const int c = g + LN_G * i;
+        v[i] = (ok && c < C) ? value(c) : 0.f;
+        part += v[i];
     }
-    const float rstd = 1.0f / sqrtf(var / (float)C + eps);
-    float* yb = y + (size_t)b * C * T + t;
-    for (int c = 0; c < C; ++c) {
-        float v = (xb[(size_t)c * T] + (rb ? rb[(size_t)c * T] : 0.f) - mu) * rstd * gamma[c] + beta[c];
-        if (gelu) v = gelu_erf(v);
-        if (post) v += post[(size_t)b * C * T + (size_t)c * T + t];
-        yb[(size_t)c * T] = v;
+    for (int c = g + LN_G * LN_NC; c < C; c += LN_G) part += ok ? value(c) : 0.f;
+    const float mu = reduce(part) / (float)C;
+    part = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_NC; ++i) {
+        const float d = v[i] - mu;
+        part += (g + LN_G * i < C) ? d * d : 0.f;
     }
+    for (int c = g + LN_G * LN_NC; c < C; c += LN_G) { const float d = (ok ? value(c) : 0.f) - mu; part += d * d; }
+    const float rstd = 1.0f / sqrtf(reduce(part) / (float)C + eps);
+    if (!ok) return;
+    float* yb = y + base;
+    auto emit = [&](int c, float xv) {
+        float o = (xv - mu) * rstd * gamma[c] + beta[c];
+        if (gelu) o = gelu_erf(o);
+        if (post) o += post[base + (size_t)c * T];
+        yb[(size_t)c * T] = o;
+    };
+#pragma unroll
+    for (int i = 0; i < LN_NC; ++i) {
+        const int c = g + LN_G * i;
+        if (c < C) emit(c, v[i]);
+    }
+    for (int c = g + LN_G * LN_NC; c < C; c += LN_G) emit(c, value(c));
 }
 
 // Self-attention with windowed relative-position embeddings, heads_share = True
@@ -282,7 +316,7 @@ extern "C" {
 int amp_layer_norm_c(const float* x_dev, const float* res_dev, const float* gamma_dev, const float* beta_dev,
                      const float* post_dev, int B, int C, int T, float eps, int gelu, float* y_dev, void* stream) {
     VT_CHECK(x_dev && gamma_dev && beta_dev && y_dev && B > 0 && C > 0 && T > 0 && B <= 65535, "amp_layer_norm_c: bad argument");
-    hipLaunchKernelGGL(layer_norm_c_kernel, dim3((T + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x_dev, res_dev,
+    hipLaunchKernelGGL(layer_norm_c_kernel, dim3((T + LN_TT - 1) / LN_TT, B), dim3(256), 0, (hipStream_t)stream, x_dev, res_dev,
                        gamma_dev, beta_dev, post_dev, y_dev, C, T, eps, gelu);
     VT_LAUNCHED("amp_layer_norm_c");
     return AMP_OK;
