@@ -126,6 +126,30 @@ def test_mel_bands_equal_the_dense_basis_sum():
     assert (got.double() - want).abs().max().item() <= 1e-5 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("sr,n_mel,fmax", [(16000, 40, 7600), (24000, 100, 12000), (44100, 128, None), (48000, 136, None), (48000, 160, None), (48000, 256, None)])
+def test_mel_filter_counts_on_every_projection_path(sr, n_mel, fmax):
+    """The n_fft = 1024 kernel keeps the filters' non-zero bands packed in LDS (1 664 floats, bands padded to 8): up to 128 filters a
+    lane runs filters m and m + 64 as one stream, 136 (1 640 floats) add a second round read from the tables per frame, and 160 / 256
+    filters on 513 bins no longer fit (1 792 / 2 184 floats) and take the loop over the global rows.  All against the oracle, and against the dense sum without a band
+    table."""
+    from types import SimpleNamespace as NS
+
+    from amphion_amd.utils import mel as M
+
+    pp = NS(sample_rate=sr, n_fft=1024, win_size=1024, hop_size=256, n_mel=n_mel, fmin=0, fmax=fmax)
+    g = torch.Generator().manual_seed(n_mel)
+    y = (torch.rand(2, 256 * 37 + 11, generator=g) * 2 - 1) * 0.8
+    out = M.mel_spectrogram_torch(y.cuda(), pp)
+    _check_logmel(out.cpu().numpy(), vo.mel_spectrogram_torch(y, pp).numpy(), f"{sr} Hz, {n_mel} filters vs oracle")
+    basis, window = M._basis_and_window(pp, out.device)
+    bands = M.basis_bands(basis.cpu().numpy()).numpy()
+    padded = int((((bands[:, 1] - bands[:, 0]) + 7) // 8 * 8).sum())
+    print(f"[mel] {n_mel} filters: {padded} packed floats ({'LDS' if padded <= 1664 else 'global rows'})")
+    dense = M._run(y.cuda(), pp, n_mel=n_mel, pad_mode=0, mag_eps=1e-6, log_clip=1e-5, basis=basis.clone(), window=window)["mel"]   # a copy: no band table
+    ref = M._run(y.cuda(), pp, n_mel=n_mel, pad_mode=0, mag_eps=1e-6, log_clip=1e-5, basis=basis, window=window)["mel"]
+    assert (dense - ref).abs().max().item() <= 5e-6
+
+
 def test_mel_small_nfft_and_window_shorter_than_fft():
     from types import SimpleNamespace as NS
 

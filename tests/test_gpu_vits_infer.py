@@ -142,6 +142,15 @@ def test_ops_vs_oracle():
     ref = x + torch.nn.functional.gelu(vio.layer_norm_channels(x + r, gamma, beta))
     got = hip_ops.layer_norm_c(x.cuda(), gamma.cuda(), beta.cuda(), res=r.cuda(), post=x.cuda(), gelu=True).cpu()
     assert (got - ref).abs().max().item() <= 1e-5
+    # ... on shapes off the kernel's 32-column x 8-channel-group tiling: channel counts that are no multiple of 8, more than the 256
+    # channels a thread keeps in registers, column counts around 32; plain (no residual, no GELU, no post)
+    for Cn, Tn in ((7, 1), (192, 33), (300, 70), (513, 31)):
+        xs, rs = torch.randn(2, Cn, Tn, generator=g), torch.randn(2, Cn, Tn, generator=g)
+        gm, bt = 1 + 0.2 * torch.randn(Cn, generator=g), 0.1 * torch.randn(Cn, generator=g)
+        got = hip_ops.layer_norm_c(xs.cuda(), gm.cuda(), bt.cuda()).cpu()
+        assert (got - vio.layer_norm_channels(xs, gm, bt)).abs().max().item() <= 2e-5, (Cn, Tn)
+        got = hip_ops.layer_norm_c(xs.cuda(), gm.cuda(), bt.cuda(), res=rs.cuda()).cpu()
+        assert (got - vio.layer_norm_channels(xs + rs, gm, bt)).abs().max().item() <= 2e-5, (Cn, Tn, "res")
     # depthwise dilated conv of x * mask
     for K, d in ((3, 1), (3, 3), (3, 9), (5, 2)):
         w, b = torch.randn(C, 1, K, generator=g), torch.randn(C, generator=g)
