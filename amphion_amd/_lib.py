@@ -53,7 +53,10 @@ class amp_gen_desc(ctypes.Structure):
 
 
 class amp_mel_desc(ctypes.Structure):
+    """``amp_mel_desc(n_fft, win_size, hop_size, n_mel, pad_mode, mag_eps, log_clip[, mel_bands_dev, ...])``: ``struct_size`` (the
+    header's first field since amp_version 140) is filled in here."""
     _fields_ = [
+        ("struct_size", ctypes.c_uint32),
         ("n_fft", c_int32),
         ("win_size", c_int32),
         ("hop_size", c_int32),
@@ -67,6 +70,9 @@ class amp_mel_desc(ctypes.Structure):
         ("range_reset_dev", c_void_p),
         ("range_seq", c_int32),
     ]
+
+    def __init__(self, *args, **kw):
+        super().__init__(ctypes.sizeof(type(self)), *args, **kw)
 
 
 _SIGNATURES = {
@@ -122,6 +128,9 @@ _SIGNATURES = {
     "amp_set_conv_rg_fast": (c_int, [c_int]),
     "amp_set_pingpong": (c_int, [c_int]),
     "amp_set_fuse_act": (c_int, [c_int]),
+    "amp_ampblock_forward": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                     c_void_p, c_int, c_int, c_void_p, c_int, c_float, c_void_p]),
+    "amp_set_ampblock_fusion": (c_int, [c_int]),
     "amp_conv_act_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "amp_conv_create_gated": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, POINTER(c_void_p)]),
     "amp_wn_forward": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_int, c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_int, c_int,
@@ -135,6 +144,7 @@ _SIGNATURES = {
     "amp_antialias_snake": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "amp_istft_forward": (c_int, [POINTER(amp_mel_desc), c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "amp_mel_num_frames": (c_int, [POINTER(amp_mel_desc), c_int]),
+    "amp_mel_init": (c_int, []),
     "amp_mel_forward_ragged": (c_int, [POINTER(amp_mel_desc), c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "amp_mel_backward": (c_int, [POINTER(amp_mel_desc), c_void_p, c_int, c_int] + [c_void_p] * 11),
     "amp_mel_forward": (c_int, [POINTER(amp_mel_desc), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

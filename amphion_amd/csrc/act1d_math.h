@@ -11,13 +11,25 @@ namespace amp {
 // sin-bound with the full-range libm sinf (Payne-Hanek branch + ~40 instructions): a 3-term Cody-Waite
 // reduction by pi (exact k * PI_A for |k| < 2^16) and the odd Taylor polynomial through r^13 on
 // [-pi/2, pi/2] costs 13 FMAs and stays within 1.1e-7 of the exact sine for |x| <= 1e5 (libm: 0.7e-7);
-// the sign lost by reducing modulo pi does not matter under the square.  Larger arguments take sinf.
+// the sign lost by reducing modulo pi does not matter under the square.  Larger arguments are reduced in
+// fp64 (snake_reduce_slow: a dozen instructions, so that the whole-AMPBlock kernel can carry the rare path
+// inline) and then take the same polynomial: every kernel of the library evaluates exactly this function.
+__device__ __forceinline__ float snake_reduce_slow(float x) {
+    const double xd = (double)x;
+    const double k = __builtin_rint(xd * 0.31830988618379067154);
+    double r = __builtin_fma(-k, 3.14159265358979311600, xd);     // pi rounded to fp64 ...
+    r = __builtin_fma(-k, 1.22464679914735317723e-16, r);         // ... and what that rounding dropped
+    const float rf = (float)r;
+    // |x| beyond ~1e15 has no phase left in fp64 either: 0 for finite arguments, NaN for inf / NaN (as sin does)
+    return __builtin_fabsf(rf) <= 1.6f ? rf : (x - x);
+}
+
 __device__ __forceinline__ float snake_sin2(float x) {
-    if (fabsf(x) > 1.0e5f) { const float s = sinf(x); return s * s; }
     const float k = rintf(x * 0.31830988618379067f);
     float r = fmaf(-k, 3.140625f, x);
     r = fmaf(-k, 9.67502593994140625e-4f, r);
     r = fmaf(-k, 1.509957990978376432e-07f, r);
+    if (__builtin_expect(fabsf(x) > 1.0e5f, 0)) r = snake_reduce_slow(x);
     const float r2 = r * r;
     float p = 1.0f / 6227020800.0f;
     p = fmaf(p, r2, -1.0f / 39916800.0f);

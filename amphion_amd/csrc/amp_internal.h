@@ -120,6 +120,33 @@ struct RbArgs {
     unsigned* range_flag;      // see ConvArgs
 };
 
+// Arguments of the whole-AMPBlock kernel (ampb_f16x3.hip), BigVGAN's AMPBlock1.forward (bigvgan.py:137-146):
+//   for p < np:  x = x + c2_p( a_{2p+1}( c1_p( a_{2p}(x) ) ) )     [then the MRF modes]
+// as ns = 2 * np STEPS  "Activation1d, then conv":  step s = 2p is (a_{2p}, c1_p), step s = 2p + 1 is (a_{2p+1}, c2_p) + residual.
+constexpr int AMP_AMPB_MAX_STEPS = 6;
+struct AmpbArgs {
+    const float* x;            // [B, C, T] input of the block
+    float* y;                  // [B, C, T] output (mode != 0: also the running MRF sum); must NOT alias x
+    const void* wp[AMP_AMPB_MAX_STEPS];        // conv of step s: packed f16x3 A fragments (conv_build)
+    const float* bias[AMP_AMPB_MAX_STEPS];
+    float sc[AMP_AMPB_MAX_STEPS], isc[AMP_AMPB_MAX_STEPS];   // 16 * 2^s operand scaling of each conv and its reciprocal
+    int dil[AMP_AMPB_MAX_STEPS];
+    const float* act_a[AMP_AMPB_MAX_STEPS];    // Activation1d of step s: alpha (exp'ed when logscale), [C]
+    const float* act_invb[AMP_AMPB_MAX_STEPS]; // 1 / (beta + 1e-9), [C]
+    const float* act_fu[AMP_AMPB_MAX_STEPS];   // 12 up-sampling taps, each x 2 (the gain of UpSample1d folded in on the host: exact)
+    const float* act_fd[AMP_AMPB_MAX_STEPS];   // 12 down-sampling taps
+    int ns;                    // steps (2 per pair)
+    int rh;                    // tile halo either side: the block's one-sided receptive field rounded up to a multiple of 4
+    int B, C, T;               // T % 4 == 0 (16-B rows)
+    int tiles_per_item;        // ceil(T / (W - 2 * rh))
+    int rev;                   // 1: descending tile order, see ConvArgs::rev
+    int mode;                  // 0: y = v   1: y = y + v   2: y = (y + v) / div   (the LAST conv's MRF mode)
+    float div;
+    const int* lens;           // ragged batches, see ConvArgs
+    int len_mul;
+    unsigned* range_flag;      // see ConvArgs
+};
+
 struct ConvPlan {
     int KT;      // taps compiled into the kernel (1,2,3,5,7,11)
     int WM, WN;  // waves along M / N (WM*WN == 4)
@@ -149,6 +176,10 @@ hipError_t launch_strip(int k, const PairArgs& a, hipStream_t stream);
 // whole ResBlock1 (rb_f16x3.hip): tile width for (C, k, max dilation) in form `wide`, 0 = not covered; launch
 int rb_tile(int k, int C, int max_dil, int wide);
 hipError_t launch_rb(int k, const RbArgs& a, int wide, hipStream_t stream);
+
+// whole AMPBlock1 (ampb_f16x3.hip): tile width for (C, k, max dilation) in form `wide`, 0 = not covered; launch
+int ampb_tile(int k, int C, int max_dil, int wide);
+hipError_t launch_ampb(int k, const AmpbArgs& a, int wide, hipStream_t stream);
 
 // conv_post: y[b,0,t] = tanh( bias + sum_i sum_j w[i][j] * act_in(x[b,i,t+j-pad]) )   (Cout == 1)
 hipError_t launch_conv_post(const float* x, const float* w_dev /*[Cin*K]*/, const float* bias_dev /*[1] or null*/,

@@ -1,0 +1,547 @@
+// A whole AMPBlock1 of BigVGAN in one launch on the gfx950 f16 matrix cores (split-f16 operands, see conv_f16x3.hip) -- round 4:
+//
+//     for p in 0 .. n-1:   x = x + c2_p( a_{2p+1}( c1_p( a_{2p}(x) ) ) )      [last pair: + the running MRF sum, / num_kernels]
+//
+// i.e. AMPBlock1.forward (bigvgan.py:137-146) with a_i = Activation1d(Snake | SnakeBeta) = 12-tap 2x up-sampling FIR -> Snake
+// -> 12-tap 2x down-sampling FIR, replicate-padded at the utterance's own ends (modules/anti_aliasing/act.py:31-36,
+// resample.py:36-65, filter.py:92-99, modules/activation_functions/snake.py:51-61).  Unfused, the block is 6 conv launches
+// (conv_f16x3.hip) and 6 act1d launches (small_kernels.hip): 27 passes of the [B, C, T] tensor through HBM with the convs'
+// matrix pipe 9-49 % busy (profiles/r3_c3_kernel_stats.csv).  Here the tensor is read once and written once.
+//
+// What makes the activation fusable is the TRANSPOSED product.  rb_f16x3.hip (HiFi-GAN's whole ResBlock) keeps the wave's tile
+// in the MFMA C layout "lane = column, registers = channels"; a FIR along time would cross lanes there.  This kernel issues
+// every MFMA with its operands exchanged,  D^T[time, channel] = X^T[time, k] * W^T[k, channel]  -- the same fragments from the
+// same LDS tile and the same packed weights (the A and B operand layouts of v_mfma_f32_32x32x16_f16 are mirror images), the
+// same products summed in the same order, so the same bits -- and gets "lane = channel, registers = time":
+//
+//   C layout   acc[t][r] of lane (m = lane & 31, h = lane >> 5): channel 32 * wm + m, wave column 32 t + 8 (r >> 2) + 4 h + (r & 3)
+//   P layout   after 32 v_permlane32_swap (acc[t][r] <-> acc[t + 2][r], t < 2): lane (m, h) owns the 64 CONSECUTIVE columns
+//              64 h + c of its channel, c = 32 t + 8 i + 4 b + j in register acc[t + 2 b][4 i + j].
+//
+// In the P layout Activation1d is register arithmetic: act1d_kernel's operation sequence (act1d_math.h) on a run of 64 columns,
+// in place, with a sliding window of Snake pairs; only the 5 columns either side of a run come from elsewhere -- the other half
+// wave (5 more swaps) or the neighbouring wave (a 1.25-KB LDS exchange per wave).  No LDS traffic, no bank conflicts, no
+// redundant Snake evaluations beyond the 5 + 3 per 64 of the run's ends.  The activation's output then has to become the next
+// conv's operand tile [16-channel chunk][plane hi|lo][octet][column][8 x f16] (rb_f16x3.hip's layout): the eight lanes of a channel
+// octet transpose 8 x 8 blocks among themselves with three DPP butterfly stages (quad_perm / row_shl:4 / row_shr:4), after which a
+// lane holds the 8 channels of ONE column = one 16-B ds_write_b128 per plane, conflict-free.
+//
+//   step s (6 per block):  [x or xt in registers, P layout] -> halo exchange -> Activation1d a_s -> x16, hi / lo -> LDS tile
+//                          -> conv s (K loop over the tile, all waves) -> un-scale (+ residual: odd steps) -> P layout
+//   tile      all C channels x W = 128 * WN columns of one item, every op evaluated on all of them; the `rh` columns either side
+//             (the block's receptive field: 5 per activation + (k-1)/2 * d per conv) are never stored.
+//   edges     the reference pads x AND the Snake output by replication at the utterance's ends; the conv pads with zeros.  Columns
+//             outside [0, Tv) are zeroed when the tile is written; the 5 outputs next to either end are recomputed from scratch
+//             (act_edge_value: act1d's edge semantics, the same operation order) by two lanes per channel from an fp32 copy of the
+//             tile and patched into the operand tile -- in the (at most two) tiles per utterance that contain an end.
+//
+// Per output element the operation order of every conv (accumulator start (bias + residual + MRF sum) * scale, chunks, taps,
+// the three MFMAs of a term, un-scale, divide) is conv_f16x3.hip's and that of every activation is act1d_kernel's, so the block is
+// bit-identical to the 12 launches it replaces (tests/test_gpu_ampblock.py).
+//
+// Compiled once per tap count:  -DAMP_KT=<3|5|7|11>.
+#include "act1d_math.h"
+#include "amp_internal.h"
+
+#ifndef AMP_KT
+#error "compile with -DAMP_KT=<taps>"
+#endif
+
+namespace amp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+union FragQ {
+    uint4 u;
+    f16x8 h;
+};
+
+#define AMP_PIN_VMEM() __builtin_amdgcn_sched_barrier(0x386)
+
+// P layout: run column c (0 .. 63) of a lane lives in v[AMP_PT(c)][AMP_PR(c)]
+#define AMP_PT(c) (((c) >> 5) + 2 * (((c) >> 2) & 1))
+#define AMP_PR(c) (4 * (((c) >> 3) & 3) + ((c) & 3))
+
+// C layout <-> P layout (an involution): lanes 32-63 of v[t][r] swap with lanes 0-31 of v[t + 2][r]
+__device__ __forceinline__ void swap_layout(f32x16 (&v)[4]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const auto s = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v[t][r]), __builtin_bit_cast(unsigned, v[t + 2][r]), false, false);
+            v[t][r] = __builtin_bit_cast(float, s[0]);
+            v[t + 2][r] = __builtin_bit_cast(float, s[1]);
+        }
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// 8 x 8 transpose among the 8 lanes of an octet (lane e = lane & 7 holds R[j] = M[e][j]; afterwards M[j][e]): three butterfly
+// stages, partner e ^ 4 (row_shr:4 for the upper four lanes, row_shl:4 for the lower), e ^ 2 and e ^ 1 (quad_perm)
+__device__ __forceinline__ void transpose8(float (&R)[8], bool b4, bool b2, bool b1) {
+    // (the DPP moves are evaluated by EVERY lane, then selected: inside a conditional they would run under a partial EXEC mask and
+    //  read disabled lanes)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float lo = R[j], hi = R[j + 4];
+        const float from_below = dpp_mov<0x114>(hi), from_above = dpp_mov<0x104>(lo);
+        R[j] = b4 ? from_below : lo;
+        R[j + 4] = b4 ? hi : from_above;
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int j = (jj & 1) + 4 * (jj >> 1);
+        const float lo = R[j], hi = R[j + 2];
+        const float phi = dpp_mov<0x4E>(hi), plo = dpp_mov<0x4E>(lo);
+        R[j] = b2 ? phi : lo;
+        R[j + 2] = b2 ? hi : plo;
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int j = 2 * jj;
+        const float lo = R[j], hi = R[j + 1];
+        const float phi = dpp_mov<0xB1>(hi), plo = dpp_mov<0xB1>(lo);
+        R[j] = b1 ? phi : lo;
+        R[j + 1] = b1 ? hi : plo;
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ T opaque(T v) {   // a value the optimiser cannot hoist out of the step loop (and then spill)
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// Activation1d on a lane's run, in place: v (P layout) holds x[0 .. 63] of one channel, hl = x[-5 .. -1], hr = x[64 .. 68].
+//   Snake pair P[Q] = (s[2Q - 5], s[2Q - 4]),  s[n] = u + invb * sin(a u)^2,  u = sum_k x[Q - k] * 2 f_up[2k (+1)]   (k = 0 .. 5)
+//   y[t] = sum_m f_dn[2m] * P[t + m].x  +  sum_m f_dn[2m + 1] * P[t + m].y                                            (m = 0 .. 5)
+// -- act1d_kernel's chains (small_kernels.hip), term for term.  Groups of four pairs; after group g the outputs 4g - 5 .. 4g - 2 are
+// complete and overwrite inputs that no later pair reads (pair Q reads x[Q - 5 .. Q]).
+__device__ __forceinline__ void act_run(f32x16 (&v)[4], const float (&hl)[5], const float (&hr)[5], const float a, const float invb,
+                                        const float (&fu2)[12], const float (&fd)[12]) {
+    f32x2 P[72];
+#pragma unroll
+    for (int g = 0; g < 18; ++g) {
+        f32x2 uv[4], xa[4], sv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int Q = 4 * g + q;
+            f32x2 u = pk_splat(0.f);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int c = Q - k;
+                const float xv = c < 0 ? hl[c + 5 < 0 ? 0 : c + 5] : (c > 63 ? hr[c - 64 > 4 ? 4 : c - 64] : v[AMP_PT(c & 63)][AMP_PR(c & 63)]);
+                u = pk_fma(pk_splat(xv), (f32x2){fu2[2 * k], fu2[2 * k + 1]}, u);
+            }
+            uv[q] = u;
+            xa[q] = u * a;
+        }
+        snake_sin2_pk4(xa, sv);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) P[4 * g + q] = pk_fma(pk_splat(invb), sv[q], uv[q]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int t = 4 * g - 5 + e;
+            if (t >= 0 && t < 64) {
+                f32x2 acc = pk_splat(0.f);
+#pragma unroll
+                for (int m = 0; m < 6; ++m) acc = pk_fma((f32x2){fd[2 * m], fd[2 * m + 1]}, P[(t + m) < 72 ? (t + m) : 71], acc);
+                v[AMP_PT(t & 63)][AMP_PR(t & 63)] = acc.x + acc.y;
+            }
+        }
+        // One group at a time.  The 18 groups are independent until their outputs, and instruction selection linearises the block
+        // with all of them interleaved (a sched_barrier only fences the machine scheduler: 200 spilled registers).  An empty asm that
+        // "rewrites" the next group's first inputs together with this group's outputs is a true data dependence: group g + 1 cannot
+        // start before group g's outputs exist.
+        if (g >= 1 && g < 17) {
+            asm volatile("" : "+v"(v[AMP_PT((4 * g + 4) & 63)][AMP_PR((4 * g + 4) & 63)]), "+v"(v[AMP_PT((4 * g + 5) & 63)][AMP_PR((4 * g + 5) & 63)]),
+                              "+v"(v[AMP_PT((4 * g + 6) & 63)][AMP_PR((4 * g + 6) & 63)]), "+v"(v[AMP_PT((4 * g + 7) & 63)][AMP_PR((4 * g + 7) & 63)]),
+                              "+v"(v[AMP_PT((4 * g - 5) & 63)][AMP_PR((4 * g - 5) & 63)]), "+v"(v[AMP_PT((4 * g - 4) & 63)][AMP_PR((4 * g - 4) & 63)]),
+                              "+v"(v[AMP_PT((4 * g - 3) & 63)][AMP_PR((4 * g - 3) & 63)]), "+v"(v[AMP_PT((4 * g - 2) & 63)][AMP_PR((4 * g - 2) & 63)]));
+        }
+    }
+}
+
+// One output of Activation1d next to an utterance end, from scratch: y[t] with x read from the fp32 row `frow` of the tile
+// (tile column = global column - q0), x clamped to [0, Tv - 1] and Snake values to [0, 2 Tv - 1] (resample.py:36-45,
+// filter.py:92-99) -- the values and the operation order of act1d_kernel's edge tiles.  Rolled loops, taps from memory: this runs in
+// two lanes per channel of at most two tiles per utterance and must not cost the common path registers.
+__device__ __forceinline__ float act_edge_value(const float* frow, const int q0, const int W, const int Tv, const int t, const float a,
+                                               const float invb, const float* __restrict__ fu2p, const float* __restrict__ fdp) {
+    float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll 1
+    for (int j = 0; j < 12; ++j) {            // tap j = 2 m + half of the down filter
+        int n = 2 * t - 5 + j;
+        n = n < 0 ? 0 : (n > 2 * Tv - 1 ? 2 * Tv - 1 : n);
+        const int Q = (n + 5) >> 1;
+        const int odd = (n + 5) & 1;
+        float u = 0.f;
+#pragma unroll 1
+        for (int k = 0; k < 6; ++k) {
+            int q = Q - k;
+            q = q < 0 ? 0 : (q > Tv - 1 ? Tv - 1 : q);
+            int col = q - q0;
+            col = col < 0 ? 0 : (col > W - 1 ? W - 1 : col);
+            u = fmaf(frow[col], fu2p[2 * k + odd], u);
+        }
+        const float s = fmaf(invb, snake_sin2(u * a), u);
+        const float f = fdp[j];
+        if (j & 1) acc1 = fmaf(f, s, acc1);
+        else acc0 = fmaf(f, s, acc0);
+    }
+    return acc0 + acc1;
+}
+
+// RING = D > 0: the weight fragments as a ring of D taps (rb_f16x3.hip / conv_blk_f16x3.hip)
+template <int KT, int WM, int WN, int RING, int G>
+__global__ __launch_bounds__(64 * WM * WN, 2) void ampb_f16x3_kernel(const AmpbArgs a) {
+    static_assert(RING == 0 || RING < KT, "a ring shorter than one chunk");
+    constexpr int NTHR = 64 * WM * WN;
+    constexpr int W = 128 * WN;               // columns per tile (every op is evaluated on all of them)
+    constexpr int WL = W + 2 * G;             // LDS row length
+    constexpr int H2 = (KT - 1) / 2;
+    constexpr int NCH = 2 * WM;               // 16-channel chunks (C = 32 * WM)
+    constexpr int CHS = 4 * WL;               // uint4 per chunk [plane][octet][WL]
+    constexpr int C = 32 * WM;
+    constexpr int FS = W + 4;                 // row stride of the fp32 copy of the tile (edge tiles; aliases the operand tile)
+    extern __shared__ __attribute__((aligned(16))) uint4 smem4[];   // [NCH][plane][octet][WL] | exchange [wave][side][32][5] | fix [C][2][5]
+    float* const xch = reinterpret_cast<float*>(smem4 + NCH * CHS);
+    float* const fixb = xch + WM * WN * 320;
+    float* const F = reinterpret_cast<float*>(smem4);
+    static_assert(C * FS * 4 <= NCH * CHS * 16, "the fp32 copy must fit the operand tile");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int h = lane >> 5, m = lane & 31;
+    const int nbx = gridDim.x;  // XCD-contiguous tile runs, see conv_f16x3.hip (ragged batches keep the dispatch order)
+    int bx = ((nbx & 7) == 0 && !a.lens) ? (int)(blockIdx.x & 7) * (nbx >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (a.rev) bx = nbx - 1 - bx;
+    const int item = bx / a.tiles_per_item;
+    const int tile = bx - item * a.tiles_per_item;
+    const int T = a.T;
+    const int RH = a.rh;
+    const int NT = W - 2 * RH;                // output columns per tile
+    const int O0 = tile * NT;                 // first output column
+    int Tv = T;                               // valid columns of this item (ragged batch)
+    if (a.lens) { const int l = a.lens[item] * a.len_mul; Tv = l < Tv ? l : Tv; }
+    if (O0 >= Tv) return;                     // tile beyond the utterance: unspecified by contract (workgroup-uniform)
+    const int q0 = O0 - RH;                   // global column of tile column 0 (a multiple of 4)
+    const int qw = q0 + 128 * wn + 64 * h;    // global column of this lane's run
+    const int ch = 32 * wm + m;               // this lane's channel
+    // a tile that contains an end of the utterance: zero padding, replicate padding (workgroup-uniform)
+    const bool has_lo = q0 <= 0, has_hi = Tv - 1 < q0 + W;
+    const bool edge = has_lo || has_hi;
+
+    auto zero_guards = [&]() {
+        for (int i = tid; i < NCH * 4 * 2 * G; i += NTHR) {
+            const int row = i / (2 * G), g = i - row * (2 * G);
+            smem4[row * WL + (g < G ? g : W + g)] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    zero_guards();
+
+    // a tensor row in the P layout: 16 aligned float4 per lane (T % 4 == 0, q0 % 4 == 0: a group lies inside [0, T) or outside)
+    const size_t rowoff = ((size_t)item * C + ch) * T;
+    auto load_rows = [&](const float* base, const int qrun, f32x16 (&dst)[4]) __attribute__((always_inline)) {
+        const float* row = base + rowoff;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int qg = qrun + 4 * i;
+            const bool inb = qg >= 0 && qg < T;
+            const float4 f = *reinterpret_cast<const float4*>(row + (inb ? qg : 0));
+            dst[AMP_PT(4 * i)][AMP_PR(4 * i) + 0] = inb ? f.x : 0.f;
+            dst[AMP_PT(4 * i)][AMP_PR(4 * i) + 1] = inb ? f.y : 0.f;
+            dst[AMP_PT(4 * i)][AMP_PR(4 * i) + 2] = inb ? f.z : 0.f;
+            dst[AMP_PT(4 * i)][AMP_PR(4 * i) + 3] = inb ? f.w : 0.f;
+        }
+    };
+
+    f32x16 xv[4];                             // x (then x + pair_0(x), ...): the residual, P layout
+    f32x16 acc[4];                            // accumulators (C layout) / the activation's operand and result (P layout)
+    load_rows(a.x, qw, xv);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = xv[t];
+
+    // weight fragments [mb][chunk][tap][plane][lane] x uint4 (conv_build); as the B operand of the transposed product a lane holds
+    // exactly what it holds as the A operand of the plain one
+    constexpr size_t MBS = (size_t)NCH * (KT * 128);
+    constexpr int NA = RING > 0 ? RING : KT;
+    FragQ w_h[NA], w_l[NA];
+
+    float range_max = 0.f;       // largest |staged operand| (x16 applied): beyond 65504 it left the f16 range (a.range_flag)
+    const int e8 = lane & 7, o4 = (lane >> 3) & 3;
+    const bool b4 = (lane & 4) != 0, b2 = (lane & 2) != 0, b1 = (lane & 1) != 0;
+
+    const int ns = a.ns;
+#pragma unroll 1
+    for (int s = 0; s < AMP_AMPB_MAX_STEPS; ++s) {
+        if (s >= ns) break;                       // workgroup-uniform
+        const bool odd = (s & 1) != 0;
+        const bool last = s + 1 == ns;
+        // ---------------- halo exchange: 5 columns either side of every run ----------------
+        float hl[5], hr[5];
+        {
+            float* my = xch + ((wave * 2 + h) * 32 + m) * 5;      // side 0: my first five (h = 0), side 1: my last five (h = 1)
+#pragma unroll
+            for (int i = 0; i < 5; ++i) my[i] = h ? acc[AMP_PT(59 + i)][AMP_PR(59 + i)] : acc[AMP_PT(i)][AMP_PR(i)];
+        }
+        __syncthreads();                          // ... and every wave is through the previous conv: the tile may be overwritten
+        {
+            const int wl = wn > 0 ? wave - 1 : wave, wr = wn + 1 < WN ? wave + 1 : wave;   // (tile edges: finite filler)
+            const float* nb = h ? xch + ((wr * 2 + 0) * 32 + m) * 5 : xch + ((wl * 2 + 1) * 32 + m) * 5;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, acc[AMP_PT(i)][AMP_PR(i)]),
+                                                                 __builtin_bit_cast(unsigned, acc[AMP_PT(59 + i)][AMP_PR(59 + i)]), false, false);
+                // sw[0] in lanes h = 1: the last five of lane (m, 0); sw[1] in lanes h = 0: the first five of lane (m, 1)
+                const float other = nb[i];
+                hl[i] = h ? __builtin_bit_cast(float, sw[0]) : other;
+                hr[i] = h ? other : __builtin_bit_cast(float, sw[1]);
+            }
+        }
+        // wave-uniform filter taps (scalar loads -> SGPR operands); the up taps arrive doubled (UpSample1d's gain, resample.py:41:
+        // act1d_kernel folds the same exact x2 into them)
+        float fu2[12], fd[12];
+        {
+            const float* fup = a.act_fu[s];
+            const float* fdp = a.act_fd[s];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                fu2[k] = fup[k];
+                fd[k] = fdp[k];
+            }
+        }
+        const float aa = a.act_a[s][ch], invb = a.act_invb[s][ch];
+
+        if (edge) {
+            // fp32 copy of the tile (over the operand tile, which nobody reads now), then the outputs next to the utterance's ends
+            // from it: lane (m, 0) of the wn = 0 waves the low end of channel m, lane (m, 1) the high end
+            float* frow = F + (size_t)ch * FS + 128 * wn + 64 * h;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                *reinterpret_cast<float4*>(frow + 4 * i) = make_float4(acc[AMP_PT(4 * i)][AMP_PR(4 * i)], acc[AMP_PT(4 * i)][AMP_PR(4 * i) + 1],
+                                                                       acc[AMP_PT(4 * i)][AMP_PR(4 * i) + 2], acc[AMP_PT(4 * i)][AMP_PR(4 * i) + 3]);
+            __syncthreads();
+            if (wn == 0 && (h ? has_hi : has_lo)) {
+                const int tb = h ? (Tv - 5 > 5 ? Tv - 5 : 5) : 0;          // low end: t = 0 .. 4, high end: the last five beyond those
+                const int te = h ? Tv : (Tv < 5 ? Tv : 5);
+                const float* fr = F + (size_t)ch * FS;
+#pragma unroll 1
+                for (int e = 0; e < 5; ++e) {
+                    const int t = tb + e;
+                    if (t < te) fixb[(ch * 2 + h) * 5 + e] = act_edge_value(fr, q0, W, Tv, t, aa, invb, a.act_fu[s], a.act_fd[s]);
+                }
+            }
+            __syncthreads();
+            zero_guards();                        // the copy ran over them
+        }
+
+        // ---------------- Activation1d, in place ----------------
+        act_run(acc, hl, hr, aa, invb, fu2, fd);
+
+        // the conv's first weight fragments: in flight under the transposes
+        {
+            const uint4* w0 = static_cast<const uint4*>(a.wp[s]) + (size_t)wm * MBS + lane;
+#pragma unroll
+            for (int g = 0; g < NA; ++g) {
+                w_h[g].u = w0[g * 128];
+                w_l[g].u = w0[g * 128 + 64];
+            }
+        }
+        AMP_PIN_VMEM();
+
+        // ---------------- lane = channel -> lane = column, x16, hi / lo, the conv's zero padding -> the operand tile ----------------
+        {
+            const int qws = opaque(qw);           // (not hoisted: eight loop-invariant k16 pairs cost 16 registers for the whole kernel)
+            const int colb = G + 128 * wn + 64 * h + e8;
+            uint4* dst = smem4 + (2 * wm + (o4 >> 1)) * CHS + (o4 & 1) * WL + colb;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                float R[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) R[j] = acc[AMP_PT(8 * b + j)][AMP_PR(8 * b + j)];
+                transpose8(R, b4, b2, b1);        // R[j]: channel 8 * o4 + j of the octet at run column 8 * b + e8
+                const int q = qws + 8 * b + e8;
+                const float k16 = (!edge || (q >= 0 && q < Tv)) ? 16.f : 0.f;
+                const amp_f32x2 v01 = (amp_f32x2){R[0], R[1]} * k16, v23 = (amp_f32x2){R[2], R[3]} * k16;
+                const amp_f32x2 v45 = (amp_f32x2){R[4], R[5]} * k16, v67 = (amp_f32x2){R[6], R[7]} * k16;
+                range_max = __builtin_fmaxf(range_max, __builtin_fmaxf(__builtin_fabsf(v01.x), __builtin_fabsf(v01.y)));
+                range_max = __builtin_fmaxf(range_max, __builtin_fmaxf(__builtin_fabsf(v23.x), __builtin_fabsf(v23.y)));
+                range_max = __builtin_fmaxf(range_max, __builtin_fmaxf(__builtin_fabsf(v45.x), __builtin_fabsf(v45.y)));
+                range_max = __builtin_fmaxf(range_max, __builtin_fmaxf(__builtin_fabsf(v67.x), __builtin_fabsf(v67.y)));
+                uint2 ha, la, hb, lb;
+                split4_f16(v01, v23, ha, la);
+                split4_f16(v45, v67, hb, lb);
+                dst[8 * b] = make_uint4(ha.x, ha.y, hb.x, hb.y);
+                dst[8 * b + 2 * WL] = make_uint4(la.x, la.y, lb.x, lb.y);
+            }
+        }
+        if (edge) {
+            __syncthreads();                      // the patched columns belong to other lanes' writes
+            if (wn == 0 && (h ? has_hi : has_lo)) {
+                const int tb = h ? (Tv - 5 > 5 ? Tv - 5 : 5) : 0;
+                const int te = h ? Tv : (Tv < 5 ? Tv : 5);
+                _Float16* const t16 = reinterpret_cast<_Float16*>(smem4);
+                const size_t rowoff = ((size_t)((ch >> 4) * CHS + ((ch >> 3) & 1) * WL + G) << 3) + (ch & 7);
+#pragma unroll 1
+                for (int e = 0; e < 5; ++e) {
+                    const int t = tb + e;
+                    const int col = t - q0;
+                    if (t < te && col >= 0 && col < W) {
+                        const float v = fixb[(ch * 2 + h) * 5 + e] * 16.f;
+                        range_max = __builtin_fmaxf(range_max, __builtin_fabsf(v));
+                        _Float16 vh, vl;
+                        split_f16(v, vh, vl);
+                        t16[rowoff + ((size_t)col << 3)] = vh;
+                        t16[rowoff + ((size_t)(col + 2 * WL) << 3)] = vl;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---------------- conv s over the tile (transposed product): acc = init + sum over chunks, taps ----------------
+        {
+            const float bv = a.bias[s][ch];
+            const float sc = a.sc[s];
+            if (!odd) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] = bv * sc;
+            } else {
+                // (bias + residual [+ running MRF sum]) * scale, conv_f16x3.hip's accumulator start; formed in the P layout
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = xv[t] + bv;
+                if (last && a.mode != 0) {
+                    f32x16 yv[4];
+                    load_rows(a.y, opaque(qw), yv);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] += yv[t];
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] *= sc;
+                swap_layout(acc);
+            }
+            const int d = a.dil[s];
+            const uint4* wa = static_cast<const uint4*>(a.wp[s]) + (size_t)wm * MBS + lane;
+            const int rd = h * WL + G + 128 * wn + m - H2 * d;
+#pragma unroll 1
+            for (int c = 0; c < NCH; ++c) {
+                const uint4* wcur = wa + (size_t)c * (KT * 128);
+                const uint4* wan = (c + 1) < NCH ? wa + (size_t)(c + 1) * (KT * 128) : wa;   // (last chunk: a reload nobody uses)
+                const uint4* base = smem4 + c * CHS + rd;
+#pragma unroll
+                for (int g = 0; g < KT; ++g) {
+                    const int v = RING > 0 ? g % NA : g;
+                    const uint4* bg = base + g * d;
+#pragma unroll
+                    for (int th = 0; th < 2; ++th) {      // the tap's x fragments in two halves (16 registers instead of 32)
+                        FragQ xh[2], xl[2];
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            xh[t].u = bg[32 * (th * 2 + t)];
+                            xl[t].u = bg[2 * WL + 32 * (th * 2 + t)];
+                        }
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+                            acc[th * 2 + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[t].h, w_h[v].h, acc[th * 2 + t], 0, 0, 0);
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+                            acc[th * 2 + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[t].h, w_h[v].h, acc[th * 2 + t], 0, 0, 0);
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+                            acc[th * 2 + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[t].h, w_l[v].h, acc[th * 2 + t], 0, 0, 0);
+                    }
+                    {   // this tap's register set is free: fetch the tap it serves next
+                        const bool same = RING > 0 && g + RING < KT;
+                        const uint4* src = same ? wcur + (size_t)(g + RING) * 128 : wan + (size_t)v * 128;
+                        w_h[v].u = src[0];
+                        w_l[v].u = src[64];
+                    }
+                    AMP_PIN_VMEM();
+                }
+            }
+            // un-scale (conv_f16x3.hip's epilogue), back to the P layout
+            const float isc = a.isc[s];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] *= isc;
+            if (odd && last && a.mode == 2) {
+                const float dv = a.div;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] = acc[t][r] / dv;
+            }
+            swap_layout(acc);
+            if (odd) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) xv[t] = acc[t];
+            }
+        }
+    }
+
+    // ---------------- store the NT output columns of the tile ----------------
+    {
+        float* row = a.y + rowoff;
+        const int colr = opaque(128 * wn + 64 * h);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int col = colr + 4 * i;
+            const int q = q0 + col;
+            if (col >= RH && col < W - RH && q < T)
+                *reinterpret_cast<float4*>(row + q) = make_float4(xv[AMP_PT(4 * i)][AMP_PR(4 * i)], xv[AMP_PT(4 * i)][AMP_PR(4 * i) + 1],
+                                                                  xv[AMP_PT(4 * i)][AMP_PR(4 * i) + 2], xv[AMP_PT(4 * i)][AMP_PR(4 * i) + 3]);
+        }
+    }
+    if (a.range_flag && __any(range_max > 65504.f) && lane == 0) atomicOr(a.range_flag, 1u);
+}
+
+template <int KT, int WM, int WN, int RING, int G>
+static hipError_t launch_ampb_one(const AmpbArgs& a, hipStream_t stream) {
+    constexpr int W = 128 * WN;
+    const size_t lds = (size_t)2 * WM * 4 * (W + 2 * G) * sizeof(uint4) + (size_t)WM * WN * 320 * sizeof(float) + (size_t)32 * WM * 10 * sizeof(float);
+    static unsigned long long attr_set = 0;   // per device: the attribute belongs to that device's copy of the function
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!((attr_set >> dev) & 1ull) && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ampb_f16x3_kernel<KT, WM, WN, RING, G>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set |= 1ull << dev;
+    }
+    dim3 grid((unsigned)(a.B * a.tiles_per_item));
+    note_kernel("ampb_f16x3_kernel", KT, WM, WN, RING, G);
+    hipLaunchKernelGGL((ampb_f16x3_kernel<KT, WM, WN, RING, G>), grid, dim3(64 * WM * WN), lds, stream, a);
+    return hipGetLastError();
+}
+
+#define AMP_CAT2(a, b) a##b
+#define AMP_CAT(a, b) AMP_CAT2(a, b)
+
+// Tile width W (columns evaluated per workgroup; outputs per tile = W - 2 * rh) for C channels in form `wide`
+// (1: eight waves, one workgroup per CU; 0: four waves, two per CU), or 0 when not covered.
+int AMP_CAT(ampb_tile_kt, AMP_KT)(int C, int max_dil, int wide) {
+    constexpr int KT = AMP_KT;
+    const int reach = (KT - 1) / 2 * max_dil;
+    if (reach > 32) return 0;
+    if (C == 32) return wide ? 1024 : 512;
+    if (C == 64) return wide ? 512 : 0;
+    return 0;
+}
+
+hipError_t AMP_CAT(launch_ampb_kt, AMP_KT)(const AmpbArgs& a, int wide, hipStream_t stream) {
+    constexpr int KT = AMP_KT;
+    constexpr int RING = KT >= 7 ? 4 : 0;
+    if (a.C == 32) return wide ? launch_ampb_one<KT, 1, 8, RING, 32>(a, stream) : launch_ampb_one<KT, 1, 4, RING, 32>(a, stream);
+    if (a.C == 64 && wide) return launch_ampb_one<KT, 2, 4, RING, 32>(a, stream);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace amp

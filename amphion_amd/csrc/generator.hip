@@ -280,6 +280,35 @@ hipError_t launch_rb(int k, const RbArgs& a, int wide, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
+int ampb_tile_kt3(int, int, int);
+int ampb_tile_kt5(int, int, int);
+int ampb_tile_kt7(int, int, int);
+int ampb_tile_kt11(int, int, int);
+hipError_t launch_ampb_kt3(const AmpbArgs&, int, hipStream_t);
+hipError_t launch_ampb_kt5(const AmpbArgs&, int, hipStream_t);
+hipError_t launch_ampb_kt7(const AmpbArgs&, int, hipStream_t);
+hipError_t launch_ampb_kt11(const AmpbArgs&, int, hipStream_t);
+
+int ampb_tile(int k, int C, int max_dil, int wide) {
+    switch (k) {
+        case 3: return ampb_tile_kt3(C, max_dil, wide);
+        case 5: return ampb_tile_kt5(C, max_dil, wide);
+        case 7: return ampb_tile_kt7(C, max_dil, wide);
+        case 11: return ampb_tile_kt11(C, max_dil, wide);
+    }
+    return 0;
+}
+
+hipError_t launch_ampb(int k, const AmpbArgs& a, int wide, hipStream_t s) {
+    switch (k) {
+        case 3: return launch_ampb_kt3(a, wide, s);
+        case 5: return launch_ampb_kt5(a, wide, s);
+        case 7: return launch_ampb_kt7(a, wide, s);
+        case 11: return launch_ampb_kt11(a, wide, s);
+    }
+    return hipErrorInvalidValue;
+}
+
 // ---- launch-policy switches: ONE configuration, read from the environment once (first use) and changed afterwards only
 // through the amp_set_* entry points the tests use for their bitwise A/B comparisons.  Nothing on a launch path calls getenv.
 //   AMP_PRECISION     f32 | f16x3       arithmetic of the conv contractions (amp_set_precision), read in precision()
@@ -287,12 +316,14 @@ hipError_t launch_rb(int k, const RbArgs& a, int wide, hipStream_t s) {
 //   AMP_PAIR_STRIP    0 | 1             per-tile pair kernel everywhere | four-wave strips wherever built (default: the policy)
 //   AMP_RB_FUSION     0 .. 3            whole-ResBlock kernel: off | policy (default) | wherever built | + four-wave tiles
 //   AMP_CONV_BLK      0 .. 3            row-blocked conv kernel forms (default 3)
+//   AMP_AMPB_FUSION   0 .. 3            whole-AMPBlock kernel (BigVGAN): off | policy (default) | wherever built | + four-wave tiles
 //   AMP_GROUP_MB      n                 depth-first batch groups of n MB (default 0 = off)
 constexpr int kConvBlkDefault = 3;
 struct Config {
     int fuse_pairs = 1;
     int pair_strips = -1;      // -1 policy, 0 per-tile kernel, 1 four-wave strips
     int rb_fusion = 1;
+    int ampb_fusion = 1;
     int conv_blk = kConvBlkDefault;
     size_t group_bytes = 0;
     // no environment form: bit-identical A/B switches for the tests (amp_set_small_conv / _conv_rg_fast / _pingpong / _fuse_act)
@@ -310,6 +341,7 @@ struct Config {
         fuse_pairs = num("AMP_FUSE_PAIRS", 0, 1, 1);
         pair_strips = num("AMP_PAIR_STRIP", 0, 1, -1);
         rb_fusion = num("AMP_RB_FUSION", 0, 3, 1);
+        ampb_fusion = num("AMP_AMPB_FUSION", 0, 3, 1);
         conv_blk = num("AMP_CONV_BLK", 0, 3, kConvBlkDefault);
         const char* e = getenv("AMP_GROUP_MB");
         group_bytes = (e && atol(e) > 0) ? (size_t)atol(e) << 20 : 0;
@@ -866,6 +898,8 @@ struct ActParams {  // one Activation1d
     float* invb_dev = nullptr;  // 1 / (beta + 1e-9)
     float* fu_dev = nullptr;    // 12 taps
     float* fd_dev = nullptr;
+    float* fu2_dev = nullptr;   // 2 * the up taps (UpSample1d's gain folded in, resample.py:41): what ampb_f16x3.hip reads into SGPRs
+    float a_max = 0.f;          // max_c |alpha_c| (host copy: ampb_supported)
 };
 
 struct ResBlock {
@@ -874,6 +908,88 @@ struct ResBlock {
     std::vector<std::unique_ptr<amp_conv>> c1, c2;  // type 2 uses c1 only
     std::vector<ActParams> acts;
 };
+
+// Whole AMPBlock1 in one launch (ampb_f16x3.hip): x read once, y written once per block, the six activations in registers;
+// bit-identical to the 6 conv + 6 act1d launches.  amp_set_ampblock_fusion / AMP_AMPB_FUSION: 0 off, 1 (default) the policy
+// below, 2 every shape the kernel is built for (any grid), 3 = 2 with the four-wave 512-column tiles at C = 32.
+static int ampb_fusion_mode() { return cfg().ampb_fusion; }
+static int ampb_form(int C, int /*k*/) {
+    const int m = ampb_fusion_mode();
+    if (m == 0) return -1;
+    if (m == 3) return C == 32 ? 0 : 1;
+    if (m == 2) return 1;
+    if (C == 32 || C == 64) return 1;
+    return -1;
+}
+constexpr long long kAmpbMinWorkgroups = 256;
+
+// one-sided receptive field of the block: 5 columns per activation, (k - 1) / 2 * dilation per conv; rounded up to whole float4
+static int ampb_halo(const amp_conv* const* c1, int np) {
+    int rh = 0;
+    for (int p = 0; p < np; ++p) rh += 10 + (c1[p]->k - 1) / 2 * (c1[p]->dilation + 1);
+    return (rh + 3) & ~3;
+}
+
+// Snake's fast range reduction (act1d_math.h) holds for |alpha * u| <= 1e5, where the stand-alone kernels switch to the fp64 reduction;
+// this kernel carries only the fast path (18 inlined branches to the slow one cost 200 spilled registers).  With alpha <= 16 an
+// argument beyond 1e5 needs |u| > 6250, i.e. activations that leave the f16x3 operand range (4094) on the very next staging and trip
+// the range guard, which repeats the forward on the exact-fp32 path.  Larger alphas keep the unfused launches.
+constexpr float kAmpbMaxAlpha = 16.f;
+static bool ampb_supported(const amp_conv* const* c1, const amp_conv* const* c2, int np, const ActParams* acts, size_t nacts, int B, int T) {
+    if (np < 1 || 2 * np > AMP_AMPB_MAX_STEPS || nacts != (size_t)(2 * np)) return false;
+    for (size_t i = 0; i < nacts; ++i)
+        if (!(acts[i].a_max <= kAmpbMaxAlpha) || !acts[i].fu2_dev) return false;
+    if ((T & 3) != 0) return false;                               // rows are moved as aligned float4
+    int max_dil = 1;
+    for (int p = 0; p < np; ++p) {
+        const amp_conv *a = c1[p], *b = c2[p];
+        if (!a || !b || a->precision != PREC_F16X3 || b->precision != PREC_F16X3) return false;
+        if (a->pad_reflect || b->pad_reflect || a->tanh_out || b->tanh_out || a->transposed || b->transposed) return false;
+        if (a->cin != a->cout || b->cin != b->cout || a->cin != b->cin || a->cin != c1[0]->cin) return false;
+        if (a->k != c1[0]->k || b->k != a->k || b->dilation != 1 || a->k != a->KT) return false;
+        if (a->padding != (a->k - 1) / 2 * a->dilation || b->padding != (b->k - 1) / 2) return false;
+        if (!a->bias_dev || !b->bias_dev) return false;
+        max_dil = a->dilation > max_dil ? a->dilation : max_dil;
+    }
+    const int form = ampb_form(c1[0]->cin, c1[0]->k);
+    if (form < 0) return false;
+    const int W = ampb_tile(c1[0]->k, c1[0]->cin, max_dil, form);
+    const int rh = ampb_halo(c1, np);
+    if (W <= 0 || W - 2 * rh < W / 2) return false;              // at least half of every tile must be output
+    const int NT = W - 2 * rh;
+    if (ampb_fusion_mode() == 1 && (long long)B * ((T + NT - 1) / NT) < kAmpbMinWorkgroups) return false;
+    return true;
+}
+
+static int ampb_run(const amp_conv* const* c1, const amp_conv* const* c2, int np, const ActParams* acts, const float* x, int B, int T,
+                    float* y, int mode, float div, hipStream_t stream, const int* lens = nullptr, int len_mul = 1) {
+    if (x == y) { set_error("ampb_run: x and y must not alias"); return AMP_ERR_INVALID; }
+    AmpbArgs a{};
+    a.x = x; a.y = y;
+    a.ns = 2 * np;
+    int max_dil = 1;
+    for (int s = 0; s < AMP_AMPB_MAX_STEPS; ++s) {
+        const int sv = s < a.ns ? s : 0;                          // unused slots: valid pointers all the same
+        const amp_conv* c = (sv & 1) ? c2[sv >> 1] : c1[sv >> 1];
+        a.wp[s] = c->wp_dev; a.bias[s] = c->bias_dev;
+        a.sc[s] = 16.f * c->wscale; a.isc[s] = 1.f / a.sc[s];
+        a.dil[s] = c->dilation;
+        a.act_a[s] = acts[sv].a_dev; a.act_invb[s] = acts[sv].invb_dev; a.act_fu[s] = acts[sv].fu2_dev; a.act_fd[s] = acts[sv].fd_dev;
+        max_dil = c->dilation > max_dil ? c->dilation : max_dil;
+    }
+    a.rh = ampb_halo(c1, np);
+    a.B = B; a.C = c1[0]->cin; a.T = T;
+    const int form = ampb_form(a.C, c1[0]->k);
+    const int W = ampb_tile(c1[0]->k, a.C, max_dil, form);
+    const int NT = W - 2 * a.rh;
+    a.tiles_per_item = (T + NT - 1) / NT;
+    a.mode = mode; a.div = div;
+    a.lens = lens; a.len_mul = len_mul;
+    a.range_flag = range_flag_for_current_device();
+    a.rev = next_rev(lens);
+    AMP_HIP(launch_ampb(c1[0]->k, a, form, stream));
+    return AMP_OK;
+}
 
 struct amp_gen {
     amp_gen_desc d{};
@@ -938,9 +1054,9 @@ static std::string ups_key(const amp_gen* g, int i) {
 }
 
 // Op-level convenience (tests): derive a = alpha (exp'ed when logscale) and 1 / (beta + 1e-9) on the host and upload them
-// with the two 12-tap filters: scratch = [a (C) | invb (C) | up taps (12) | down taps (12)].  The caller frees `*out`.
+// with the two 12-tap filters: scratch = [a (C) | invb (C) | up taps (12) | down taps (12) | 2 * up taps (12)].  The caller frees `*out`.
 static int act_params_upload(const float* alpha_dev, const float* beta_dev, int C, int logscale, const float* filt_up_host,
-                             const float* filt_down_host, float** out) {
+                             const float* filt_down_host, float** out, float* a_max = nullptr) {
     std::vector<float> al(C), be(C), a(C), ib(C);
     AMP_HIP(hipMemcpy(al.data(), alpha_dev, C * sizeof(float), hipMemcpyDeviceToHost));
     if (beta_dev) AMP_HIP(hipMemcpy(be.data(), beta_dev, C * sizeof(float), hipMemcpyDeviceToHost));
@@ -949,13 +1065,17 @@ static int act_params_upload(const float* alpha_dev, const float* beta_dev, int 
         if (logscale) { av = expf(av); bv = expf(bv); }
         a[i] = av;
         ib[i] = 1.0f / (bv + 0.000000001f);
+        if (a_max) *a_max = fmaxf(*a_max, fabsf(av));
     }
     float* scratch = nullptr;
-    AMP_HIP(hipMalloc((void**)&scratch, (2 * (size_t)C + 24) * sizeof(float)));
+    AMP_HIP(hipMalloc((void**)&scratch, (2 * (size_t)C + 36) * sizeof(float)));
+    float fu2[12];
+    for (int i = 0; i < 12; ++i) fu2[i] = 2.f * filt_up_host[i];
     hipError_t e = hipMemcpy(scratch, a.data(), C * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(scratch + C, ib.data(), C * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(scratch + 2 * C, filt_up_host, 12 * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(scratch + 2 * C + 12, filt_down_host, 12 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(scratch + 2 * C + 24, fu2, 12 * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(scratch); set_error("act_params_upload: %s", hipGetErrorString(e)); return AMP_ERR_HIP; }
     *out = scratch;
     return AMP_OK;
@@ -963,7 +1083,10 @@ static int act_params_upload(const float* alpha_dev, const float* beta_dev, int 
 
 extern "C" {
 
-int amp_version(void) { return 122; }   // 100: round 1; 120: + amp_conv_create_gated / amp_wn_forward / amp_conv_act_forward, switches; 122: + amp_set_conv_blk / _conv_rg_fast / _pingpong
+// 100: round 1; 120: + amp_conv_create_gated / amp_wn_forward / amp_conv_act_forward, switches; 122: + amp_set_conv_blk / _conv_rg_fast /
+// _pingpong; 130 (round 3's ABI, numbered in round 4): amp_mel_desc grew four trailing fields, + amp_resblock_forward /
+// amp_set_resblock_fusion / amp_gen_kernel_name; 140: amp_mel_desc.struct_size, + amp_ampblock_forward / amp_set_ampblock_fusion / amp_mel_init
+int amp_version(void) { return 140; }
 const char* amp_last_error(void) { return g_err; }
 
 int amp_set_precision(int precision) {
@@ -1126,12 +1249,16 @@ static int build_act(amp_gen* g, const std::string& p, int c, ActParams* out) {
         if (g->d.snake_logscale) { al = expf(al); be = expf(be); }  // snake.py:57-58,116-118
         a[i] = al;
         ib[i] = 1.0f / (be + 0.000000001f);                          // snake.py:59,119
+        out->a_max = fmaxf(out->a_max, fabsf(al));
     }
     int rc;
     if ((rc = upload(g, a.data(), c, &out->a_dev)) != AMP_OK) return rc;
     if ((rc = upload(g, ib.data(), c, &out->invb_dev)) != AMP_OK) return rc;
     if ((rc = upload(g, iu->second.data.data(), 12, &out->fu_dev)) != AMP_OK) return rc;
     if ((rc = upload(g, idn->second.data.data(), 12, &out->fd_dev)) != AMP_OK) return rc;
+    float fu2[12];
+    for (int i = 0; i < 12; ++i) fu2[i] = 2.f * iu->second.data[i];
+    if ((rc = upload(g, fu2, 12, &out->fu2_dev)) != AMP_OK) return rc;
     return AMP_OK;
 }
 
@@ -1393,6 +1520,15 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
                 // the whole resblock in one launch: U -> XS (x and the residual never leave the CU in between)
                 AMP_RC(rb_run(rb.c1, rb.c2, U, B, t, slope, XS, mode_last, (float)nk, sj, lens, lm));
                 continue;
+            }
+            if (d.resblock_type == 1 && big && nd <= AMP_AMPB_MAX_STEPS / 2) {
+                const amp_conv *p1[AMP_AMPB_MAX_STEPS / 2], *p2[AMP_AMPB_MAX_STEPS / 2];
+                for (int p = 0; p < nd; ++p) { p1[p] = rb.c1[p].get(); p2[p] = rb.c2[p].get(); }
+                if (ampb_supported(p1, p2, nd, rb.acts.data(), rb.acts.size(), B, t)) {
+                    // the whole AMPBlock in one launch: U -> XS (bigvgan.py:137-146)
+                    AMP_RC(ampb_run(p1, p2, nd, rb.acts.data(), U, B, t, XS, mode_last, (float)nk, sj, lens, lm));
+                    continue;
+                }
             }
             for (int p = 0; p < nd; ++p) {
                 const bool last = p == nd - 1;
@@ -1718,6 +1854,42 @@ int amp_set_resblock_fusion(int mode) {
     if (mode < -1 || mode > 3) { set_error("amp_set_resblock_fusion: mode=%d", mode); return AMP_ERR_INVALID; }
     cfg().rb_fusion = mode < 0 ? 1 : mode;
     return AMP_OK;
+}
+
+int amp_set_ampblock_fusion(int mode) {
+    if (mode < -1 || mode > 3) { set_error("amp_set_ampblock_fusion: mode=%d", mode); return AMP_ERR_INVALID; }
+    cfg().ampb_fusion = mode < 0 ? 1 : mode;
+    return AMP_OK;
+}
+
+int amp_ampblock_forward(const amp_conv* const* c1, const amp_conv* const* c2, int n_pairs, const float* alpha_dev,
+                         const float* beta_dev, int logscale, const float* filt_up_host, const float* filt_down_host,
+                         const float* x_dev, int B, int T, float* y_dev, int mode, float div, void* stream) {
+    if (!c1 || !c2 || !alpha_dev || !filt_up_host || !filt_down_host || !x_dev || !y_dev) { set_error("amp_ampblock_forward: null argument"); return AMP_ERR_INVALID; }
+    if (B <= 0 || T <= 0 || n_pairs < 1 || 2 * n_pairs > AMP_AMPB_MAX_STEPS || mode < 0 || mode > 2) {
+        set_error("amp_ampblock_forward: B=%d T=%d n_pairs=%d mode=%d", B, T, n_pairs, mode);
+        return AMP_ERR_INVALID;
+    }
+    if (x_dev == y_dev) { set_error("amp_ampblock_forward: x and y must not alias (tiles read each other's halo)"); return AMP_ERR_INVALID; }
+    for (int p = 0; p < n_pairs; ++p) if (!c1[p] || !c2[p]) { set_error("amp_ampblock_forward: null conv handle"); return AMP_ERR_INVALID; }
+    const int C = c1[0]->cin, na = 2 * n_pairs;
+    float* scratch[AMP_AMPB_MAX_STEPS] = {};
+    ActParams acts[AMP_AMPB_MAX_STEPS];
+    int rc = AMP_OK;
+    for (int i = 0; i < na && rc == AMP_OK; ++i) {
+        rc = act_params_upload(alpha_dev + (size_t)i * C, beta_dev ? beta_dev + (size_t)i * C : nullptr, C, logscale, filt_up_host, filt_down_host, &scratch[i], &acts[i].a_max);
+        if (rc == AMP_OK) { acts[i].a_dev = scratch[i]; acts[i].invb_dev = scratch[i] + C; acts[i].fu_dev = scratch[i] + 2 * C; acts[i].fd_dev = scratch[i] + 2 * C + 12; acts[i].fu2_dev = scratch[i] + 2 * C + 24; }
+    }
+    if (rc == AMP_OK && !ampb_supported(c1, c2, n_pairs, acts, (size_t)na, B, T)) {
+        set_error("amp_ampblock_forward: block (C=%d k=%d, %d pairs, B=%d T=%d) is not covered by the whole-AMPBlock kernel under the "
+                  "current amp_set_ampblock_fusion mode (run the convs and activations one by one: the same bits)", c1[0]->cin, c1[0]->k, n_pairs, B, T);
+        rc = AMP_ERR_UNSUPPORTED;
+    }
+    if (rc == AMP_OK) rc = ampb_run(c1, c2, n_pairs, acts, x_dev, B, T, y_dev, mode, div, (hipStream_t)stream);
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    for (int i = 0; i < na; ++i) if (scratch[i]) (void)hipFree(scratch[i]);
+    if (rc == AMP_OK && e != hipSuccess) { set_error("amp_ampblock_forward: %s", hipGetErrorString(e)); return AMP_ERR_HIP; }
+    return rc;
 }
 
 int amp_conv_forward_mrf(const amp_conv* c, const float* x_dev, int B, int T, float slope_in, const float* res_dev,

@@ -5,6 +5,11 @@
 //
 // Replaces utils/mel.py:20-170 (torch.stft + sqrt + matmul + log as 5 separate tensor ops) and the
 // conv1d-with-Fourier-basis STFT of utils/stft.py:152-181,259-278 (TacotronSTFT).
+#include <atomic>
+#include <mutex>
+#include <stddef.h>
+#include <string.h>
+
 #include "amp_internal.h"
 
 namespace amp {
@@ -202,6 +207,13 @@ static hipError_t upload_mel_twiddles() {
     for (int j = 0; j < 64; ++j) t.wsp[j] = unit_root(j, 1024);
     return hipMemcpyToSymbol(HIP_SYMBOL(g_mel_tw), &t, sizeof(t), 0, hipMemcpyHostToDevice);
 }
+
+// One-time set-up of the n_fft = 1024 kernel on the CURRENT device (its LDS attribute and the 4.5-KB twiddle table), under a lock:
+// amp_mel_init() does it explicitly; the first launch does it lazily -- but never inside a stream capture, where the blocking copy
+// would invalidate the capture (hipErrorStreamCaptureUnsupported is returned instead and the caller is told to call amp_mel_init).
+static std::mutex g_mel_init_mutex;
+static std::atomic<unsigned long long> g_mel_init_done{0};   // bit per device
+static hipError_t mel1024_device_init(hipStream_t stream_or_null, bool have_stream);
 
 constexpr int MEL_WAVES = 8;       // waves per workgroup
 constexpr int MEL_FPW = 4;         // frames per wave
@@ -465,6 +477,31 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 4) void mel1024_kernel(const float*
     }
 }
 
+static hipError_t mel1024_device_init(hipStream_t stream, bool have_stream) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if ((g_mel_init_done.load(std::memory_order_acquire) >> dev) & 1ull) return hipSuccess;
+    if (have_stream) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+            set_error("amp_mel_forward: the first n_fft = 1024 call on a device uploads its twiddle table with a blocking copy; "
+                      "call amp_mel_init() (or one mel forward) before capturing the stream");
+            return hipErrorStreamCaptureUnsupported;
+        }
+    }
+    std::lock_guard<std::mutex> lock(g_mel_init_mutex);
+    if ((g_mel_init_done.load(std::memory_order_acquire) >> dev) & 1ull) return hipSuccess;
+    const size_t mx = mel1024_lds_floats(MEL_MAXMEL) * sizeof(float);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mel1024_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx);
+    if (e != hipSuccess) return e;
+    e = upload_mel_twiddles();          // pageable copy: returns when the table is on the device
+    if (e != hipSuccess) return e;
+    e = hipDeviceSynchronize();         // ... and is ordered before work on EVERY stream of the device, blocking or not
+    if (e != hipSuccess) return e;
+    g_mel_init_done.fetch_or(1ull << dev, std::memory_order_release);
+    return hipSuccess;
+}
+
 hipError_t launch_mel(const amp_mel_desc& d, const float* wav, const int* lens, int B, int L, int F, const float* window,
                       const float* melbasis, float* mel, float* mag, float* re, float* im, hipStream_t stream) {
     const int pad = d.pad_mode == 0 ? (d.n_fft - d.hop_size) / 2 : d.n_fft / 2;
@@ -473,16 +510,9 @@ hipError_t launch_mel(const amp_mel_desc& d, const float* wav, const int* lens, 
     if (d.n_fft == 1024 && n_mel <= MEL_MAXMEL && (pad & 1) == 0 && (d.hop_size & 1) == 0) {
         // wave-per-frame radix-8 real FFT (every shipped config of the reference)
         const size_t lds = mel1024_lds_floats(n_mel) * sizeof(float);
-        static unsigned long long attr_set = 0;   // per device
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-        if (!((attr_set >> dev) & 1ull)) {
-            const size_t mx = mel1024_lds_floats(MEL_MAXMEL) * sizeof(float);
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mel1024_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx);
+        {
+            const hipError_t e = mel1024_device_init(stream, true);
             if (e != hipSuccess) return e;
-            e = upload_mel_twiddles();      // synchronous, once per device (so: not inside a stream capture)
-            if (e != hipSuccess) return e;
-            attr_set |= 1ull << dev;
         }
         const int fblocks = (F + MEL_FPB - 1) / MEL_FPB;
         hipLaunchKernelGGL(mel1024_kernel, dim3((unsigned)((size_t)B * fblocks)), dim3(64 * MEL_WAVES), lds, stream, wav, lens, L, F,
@@ -726,6 +756,28 @@ using namespace amp;
 
 extern "C" {
 
+// The caller's descriptor, as far as the caller's struct_size says it exists (fields added by later versions of the header
+// read as 0 / NULL for a consumer compiled against an older one).
+static bool mel_desc_in(const amp_mel_desc* in, amp_mel_desc* out, const char* who) {
+    if (!in) { set_error("%s: null descriptor", who); return false; }
+    const size_t sz = in->struct_size;
+    if (sz < offsetof(amp_mel_desc, range_dev) || sz > 4096) {
+        set_error("%s: amp_mel_desc.struct_size = %zu: set it to sizeof(amp_mel_desc) (the library reads nothing beyond it)", who, sz);
+        return false;
+    }
+    memset(out, 0, sizeof(*out));
+    memcpy(out, in, sz < sizeof(*out) ? sz : sizeof(*out));
+    out->struct_size = (uint32_t)sizeof(*out);
+    return true;
+}
+
+int amp_mel_init(void) {
+    if (amp_device_count() <= 0) { set_error("amp_mel_init: no HIP device visible"); return AMP_ERR_HIP; }
+    const hipError_t e = mel1024_device_init(nullptr, false);
+    if (e != hipSuccess) { set_error("amp_mel_init: %s", hipGetErrorString(e)); return AMP_ERR_HIP; }
+    return AMP_OK;
+}
+
 int amp_mel_num_frames(const amp_mel_desc* d, int L) {
     if (!d || d->hop_size <= 0 || d->n_fft <= 0) return 0;
     const int pad = d->pad_mode == 0 ? (d->n_fft - d->hop_size) / 2 : d->n_fft / 2;
@@ -740,9 +792,12 @@ int amp_mel_forward(const amp_mel_desc* d, const float* wav_dev, int B, int L, c
     return amp_mel_forward_ragged(d, wav_dev, nullptr, B, L, window_dev, melbasis_dev, mel_dev, mag_dev, re_dev, im_dev, stream);
 }
 
-int amp_mel_forward_ragged(const amp_mel_desc* d, const float* wav_dev, const int32_t* lens_dev, int B, int L,
+int amp_mel_forward_ragged(const amp_mel_desc* d_in, const float* wav_dev, const int32_t* lens_dev, int B, int L,
                            const float* window_dev, const float* melbasis_dev, float* mel_dev, float* mag_dev,
                            float* re_dev, float* im_dev, void* stream) {
+    amp_mel_desc dn;
+    if (!mel_desc_in(d_in, &dn, "amp_mel_forward_ragged")) return AMP_ERR_INVALID;
+    const amp_mel_desc* d = &dn;
     if (!d || !wav_dev || !window_dev) { set_error("amp_mel_forward: null argument"); return AMP_ERR_INVALID; }
     if (d->n_fft < 64 || d->n_fft > 4096 || (d->n_fft & (d->n_fft - 1)) != 0) {
         set_error("amp_mel_forward: n_fft=%d must be a power of two in [64, 4096]", d->n_fft);
@@ -755,12 +810,16 @@ int amp_mel_forward_ragged(const amp_mel_desc* d, const float* wav_dev, const in
     const int F = amp_mel_num_frames(d, L);
     if (F <= 0) { set_error("amp_mel_forward: no frames for L=%d", L); return AMP_ERR_INVALID; }
     hipError_t e = launch_mel(*d, wav_dev, lens_dev, B, L, F, window_dev, melbasis_dev, mel_dev, mag_dev, re_dev, im_dev, (hipStream_t)stream);
+    if (e == hipErrorStreamCaptureUnsupported) return AMP_ERR_STATE;   // message set by mel1024_device_init
     if (e != hipSuccess) { set_error("amp_mel_forward: %s", hipGetErrorString(e)); return AMP_ERR_HIP; }
     return AMP_OK;
 }
 
-int amp_istft_forward(const amp_mel_desc* d, const float* mag_dev, const float* phase_dev, int B, int F,
+int amp_istft_forward(const amp_mel_desc* d_in, const float* mag_dev, const float* phase_dev, int B, int F,
                       const float* window_dev, const float* wss_dev, float* frames_ws_dev, float* wav_dev, void* stream) {
+    amp_mel_desc dn;
+    if (!mel_desc_in(d_in, &dn, "amp_istft_forward")) return AMP_ERR_INVALID;
+    const amp_mel_desc* d = &dn;
     if (!d || !mag_dev || !phase_dev || !window_dev || !wss_dev || !frames_ws_dev || !wav_dev) { set_error("amp_istft_forward: null argument"); return AMP_ERR_INVALID; }
     if (d->n_fft < 64 || d->n_fft > 4096 || (d->n_fft & (d->n_fft - 1)) != 0) {
         set_error("amp_istft_forward: n_fft=%d must be a power of two in [64, 4096]", d->n_fft);
@@ -772,8 +831,11 @@ int amp_istft_forward(const amp_mel_desc* d, const float* mag_dev, const float* 
     return AMP_OK;
 }
 
-int amp_istft_same(const amp_mel_desc* d, const float* re_dev, const float* im_dev, int B, int F, const float* window_dev,
+int amp_istft_same(const amp_mel_desc* d_in, const float* re_dev, const float* im_dev, int B, int F, const float* window_dev,
                    const float* envelope_dev, float* frames_ws_dev, float* wav_dev, void* stream) {
+    amp_mel_desc dn;
+    if (!mel_desc_in(d_in, &dn, "amp_istft_same")) return AMP_ERR_INVALID;
+    const amp_mel_desc* d = &dn;
     if (!d || !re_dev || !im_dev || !window_dev || !envelope_dev || !frames_ws_dev || !wav_dev) { set_error("amp_istft_same: null argument"); return AMP_ERR_INVALID; }
     if (d->n_fft < 64 || d->n_fft > 4096 || (d->n_fft & (d->n_fft - 1)) != 0 || d->win_size != d->n_fft) {
         set_error("amp_istft_same: n_fft=%d must be a power of two in [64, 4096] and equal win_size=%d", d->n_fft, d->win_size);
@@ -785,10 +847,13 @@ int amp_istft_same(const amp_mel_desc* d, const float* re_dev, const float* im_d
     return AMP_OK;
 }
 
-int amp_mel_backward(const amp_mel_desc* d, const int32_t* lens_dev, int B, int L, const float* window_dev,
+int amp_mel_backward(const amp_mel_desc* d_in, const int32_t* lens_dev, int B, int L, const float* window_dev,
                      const float* melbasis_dev, const float* mel_linear_dev, const float* mag_dev, const float* re_dev,
                      const float* im_dev, const float* grad_logmel_dev, float* spec_ws_dev, float* frames_ws_dev,
                      float* grad_wav_dev, void* stream) {
+    amp_mel_desc dn;
+    if (!mel_desc_in(d_in, &dn, "amp_mel_backward")) return AMP_ERR_INVALID;
+    const amp_mel_desc* d = &dn;
     if (!d || !window_dev || !melbasis_dev || !mel_linear_dev || !mag_dev || !re_dev || !im_dev || !grad_logmel_dev || !spec_ws_dev ||
         !frames_ws_dev || !grad_wav_dev) { set_error("amp_mel_backward: null argument"); return AMP_ERR_INVALID; }
     if (d->n_fft < 64 || d->n_fft > 4096 || (d->n_fft & (d->n_fft - 1)) != 0) {

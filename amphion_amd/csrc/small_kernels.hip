@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void a
             *reinterpret_cast<float4*>(&sl[4 * sl_pos4(2 * lane + 1)]) = make_float4(sv[2].x, sv[2].y, sv[3].x, sv[3].y);
             if (__builtin_expect(big > 1.0e5f, 0)) {
                 // beyond the fast range reduction: redo this lane's eight values one at a time through
-                // snake_sin2 (libm sine above 1e5, the identical operation sequence below it)
+                // snake_sin2 (fp64 range reduction above 1e5, the identical operation sequence below it)
 #pragma nounroll
                 for (int e = 0; e < 8; ++e) sl[sl_pos(8 * lane + e)] = snake_scalar(8 * lane + e);
             }

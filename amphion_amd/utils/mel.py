@@ -170,6 +170,11 @@ def _plan(cfg, device):
         p.bands = mel_bands[p.basis.data_ptr()][1]
         p.descs = {}
         p.n_fft, p.win_size, p.hop_size, p.bins = cfg.n_fft, cfg.win_size, cfg.hop_size, cfg.n_fft // 2 + 1
+        if cfg.n_fft == 1024 and not torch.cuda.is_current_stream_capturing():
+            # the n_fft = 1024 kernel's one-time set-up (a blocking 4.5-KB table upload), here and not at the first launch:
+            # a later call may sit inside a stream capture
+            with torch.cuda.device(device):
+                _lib.check(_lib.lib().amp_mel_init())
         _plans[key] = p
     return p
 

@@ -83,7 +83,11 @@ typedef struct amp_gen_desc {
 
 typedef struct amp_gen amp_gen;
 
-/* Library / device probes.  amp_version: 100 = round 1's surface; 120 adds the fused-WN and conv + activation entry points, 122 amp_set_conv_blk / amp_set_conv_rg_fast / amp_set_pingpong. */
+/* Library / device probes.  amp_version: 100 = round 1's surface; 120 adds the fused-WN and conv + activation entry points, 122
+ * amp_set_conv_blk / amp_set_conv_rg_fast / amp_set_pingpong; 130 (round 3) appended the four range_* fields to amp_mel_desc and
+ * added amp_resblock_forward / amp_set_resblock_fusion / amp_gen_kernel_name; 140 (round 4): amp_mel_desc starts with struct_size
+ * (an ABI break for every earlier consumer of that struct -- re-compile against this header), + amp_mel_init,
+ * amp_ampblock_forward, amp_set_ampblock_fusion. */
 int amp_version(void);
 const char* amp_last_error(void);
 /* Number of HIP devices visible (0 when there is no GPU); never fails. */
@@ -301,6 +305,26 @@ int amp_resblock_forward(const amp_conv* const* c1, const amp_conv* const* c2, i
  * 512-column tiles at C = 32.  Bit-identical results in every mode (tests/test_gpu_resblock.py); env AMP_RB_FUSION. */
 int amp_set_resblock_fusion(int mode);
 
+/* AMPBlock1.forward of BigVGAN (bigvgan.py:137-146) in ONE launch:
+ *     for p < n_pairs:  x = x + c2[p]( a[2p+1]( c1[p]( a[2p](x) ) ) ),   a[i] = Activation1d(Snake | SnakeBeta)
+ * on the whole-AMPBlock kernel (csrc/ampb_f16x3.hip: x read once, y written once, the six anti-aliased activations
+ * (act.py:31-36, resample.py:36-65, filter.py:92-99, snake.py:51-61) evaluated in registers between the convs).  Bit-identical
+ * to running amp_antialias_snake / amp_conv_forward[_mrf] one by one (tests/test_gpu_ampblock.py).
+ * Handles from amp_conv_create under AMP_PRECISION_F16X3: same C and k for all convs, c1[p] dilated, c2[p] dilation 1, 'same'
+ * zero padding, with bias.  alpha_dev / beta_dev: [2 * n_pairs, C] per-channel parameters AS STORED (exp() applied when
+ * logscale; beta_dev NULL -> Snake); filt_up_host / filt_down_host: the 12 filter taps shared by all activations.
+ * mode 0: y = v;  1: y = y + v;  2: y = (y + v) / div  (the MRF accumulation of the generator, bigvgan.py:320-327).
+ * Covered: C in {32, 64}, k in {3, 5, 7, 11}, (k-1)/2 * dilation <= 32, n_pairs <= 3, T % 4 == 0, every |alpha| <= 16, under
+ * the shapes the current amp_set_ampblock_fusion mode admits -- otherwise AMP_ERR_UNSUPPORTED.  y_dev must not alias x_dev.
+ * Op-level convenience: synchronises the stream. */
+int amp_ampblock_forward(const amp_conv* const* c1, const amp_conv* const* c2, int n_pairs, const float* alpha_dev,
+                         const float* beta_dev, int logscale, const float* filt_up_host, const float* filt_down_host,
+                         const float* x_dev, int B, int T, float* y_dev, int mode, float div, void* stream);
+/* 0: BigVGAN generators run every AMPBlock as separate conv / activation launches; 1 (default): the whole-AMPBlock kernel
+ * where it is built and the launch fills the chip; 2: wherever it is built, any grid; 3: as 2 with the four-wave 512-column
+ * tiles at C = 32.  Bit-identical results in every mode; env AMP_AMPB_FUSION.  -1: back to the default. */
+int amp_set_ampblock_fusion(int mode);
+
 void amp_conv_destroy(amp_conv* c);
 
 /* Frame-rate convs (short contraction, small grid: the convs around the VITS decoder) run on a kernel that stages the
@@ -394,6 +418,9 @@ int amp_set_fuse_act(int on);
 
 /* Mel / STFT front end descriptor: cfg.preprocess.{sample_rate,n_fft,win_size,hop_size,n_mel,fmin,fmax}. */
 typedef struct amp_mel_desc {
+    uint32_t struct_size; /* sizeof(amp_mel_desc) AS THE CALLER WAS COMPILED (since amp_version 140): the library reads nothing
+                            beyond it, so fields appended by later versions default to 0 / NULL for older consumers; a value
+                            below the round-2 fields (up to mel_bands_dev) is refused with AMP_ERR_INVALID */
     int32_t n_fft;
     int32_t win_size;
     int32_t hop_size;
@@ -418,6 +445,9 @@ typedef struct amp_mel_desc {
     int32_t range_seq;
 } amp_mel_desc;
 
+/* One-time set-up of the n_fft = 1024 front-end kernel on the CURRENT device (thread-safe, idempotent, blocking): call it
+ * before capturing a stream that contains amp_mel_forward.  Without it the first forward does the same lazily. */
+int amp_mel_init(void);
 /* Number of frames produced for L samples. */
 int amp_mel_num_frames(const amp_mel_desc* d, int L);
 /* Replaces extract_mel_features / mel_spectrogram_torch / extract_linear_features (utils/mel.py:20-170)
@@ -425,8 +455,8 @@ int amp_mel_num_frames(const amp_mel_desc* d, int L);
  * wav_dev [B, L]; window_dev [n_fft] (already centre-padded to n_fft); melbasis_dev [n_mel, n_fft/2+1]
  * (may be NULL when n_mel == 0).  Outputs (any may be NULL): mel_dev [B, n_mel, F] (log-mel),
  * mag_dev [B, n_fft/2+1, F] (magnitude), re_dev/im_dev [B, n_fft/2+1, F].
- * The first n_fft = 1024 call on a device uploads a 4.5-KB twiddle table synchronously (hipMemcpyToSymbol): make that call
- * outside a stream capture. */
+ * The first n_fft = 1024 call on a device sets the kernel up (a 4.5-KB twiddle table, uploaded with a blocking copy under a
+ * lock): inside a stream capture that first call is refused with AMP_ERR_STATE -- call amp_mel_init() (or one forward) first. */
 int amp_mel_forward(const amp_mel_desc* d, const float* wav_dev, int B, int L, const float* window_dev,
                     const float* melbasis_dev, float* mel_dev, float* mag_dev, float* re_dev, float* im_dev,
                     void* stream);

@@ -37,6 +37,7 @@ int main(void) {
     if (amp_conv_create(0, 4, 4, 3, 1, 1, 1, NULL, NULL, &c) != AMP_ERR_INVALID) return 6;
     if (amp_conv_create_gated(64, 5, 1, 2, NULL, NULL, &c) != AMP_ERR_INVALID) return 7;
     if (amp_wn_forward(NULL, NULL, 0, NULL, NULL, 0, NULL, 1, 8, NULL, NULL, NULL) != AMP_ERR_INVALID) return 8;
+    m.struct_size = (uint32_t)sizeof m;
     m.n_fft = 1024; m.win_size = 1024; m.hop_size = 256; m.n_mel = 80; m.pad_mode = 0;
     if (amp_mel_num_frames(&m, 22016) != 86) { printf("frames %d\n", amp_mel_num_frames(&m, 22016)); return 9; }
     printf("abi ok\n");

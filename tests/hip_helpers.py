@@ -138,3 +138,56 @@ def conv_act_forward(w, b, x, alpha, beta, logscale, fu, fd, *, dilation=1, fuse
         return y.cpu()
     finally:
         L.amp_conv_destroy(h)
+
+
+def ampblock_forward(ws1, bs1, ws2, bs2, alphas, betas, logscale, fu, fd, x, *, dilations, fused=True, mode=0, div=1.0, y0=None):
+    """AMPBlock1 (bigvgan.py:137-146) on cuda:0 from per-pair weights and per-activation parameters (``alphas`` / ``betas``
+    [2 * n, C]; ``betas`` None -> Snake).  fused=True -> ``amp_ampblock_forward`` (ONE launch, csrc/ampb_f16x3.hip);
+    fused=False -> the launches it replaces: ``amp_antialias_snake`` -> ``amp_conv_forward`` -> ``amp_antialias_snake`` ->
+    ``amp_conv_forward`` (with the residual; the last conv through ``amp_conv_forward_mrf`` with the MRF ``mode``, bigvgan.py:320-327).
+    ``y0``: the running MRF sum for modes 1 / 2.  CPU tensors in and out."""
+    L = _lib.lib()
+    C, _, k = ws1[0].shape
+    n = len(dilations)
+    h1, h2 = [], []
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    try:
+        for ws, bs, hs, ds in ((ws1, bs1, h1, dilations), (ws2, bs2, h2, [1] * n)):
+            for w, b, d in zip(ws, bs, ds):
+                h = ctypes.c_void_p()
+                w, b = w.contiguous().float(), b.contiguous().float()
+                _lib.check(L.amp_conv_create(0, C, C, k, 1, d, (k * d - d) // 2, p(w), p(b), ctypes.byref(h)))
+                hs.append(h)
+        xd = x.contiguous().float().cuda()
+        B, _, T = xd.shape
+        st = _lib.current_stream_ptr(xd.device)
+        ad = alphas.contiguous().float().cuda()
+        bd = betas.contiguous().float().cuda() if betas is not None else None
+        fu, fd = fu.contiguous().float(), fd.contiguous().float()
+        y = y0.contiguous().float().cuda().clone() if y0 is not None else torch.full_like(xd, float("nan"))
+        if fused:
+            a1, a2 = (ctypes.c_void_p * n)(*[h.value for h in h1]), (ctypes.c_void_p * n)(*[h.value for h in h2])
+            _lib.check(L.amp_ampblock_forward(a1, a2, n, p(ad), p(bd), int(logscale), p(fu), p(fd), p(xd), B, T, p(y), mode, div, st))
+        else:
+            act = torch.empty_like(xd)
+            xt = torch.empty_like(xd)
+            cur = xd
+            for i in range(n):
+                for j, h in ((0, h1[i]), (1, h2[i])):
+                    s = 2 * i + j
+                    src = cur if j == 0 else xt
+                    _lib.check(L.amp_antialias_snake(p(src), B, C, T, p(ad[s]), p(bd[s]) if bd is not None else None, int(logscale),
+                                                     p(fu), p(fd), p(act), st))
+                    if j == 0:
+                        _lib.check(L.amp_conv_forward(h, p(act), B, T, 1.0, None, 1.0, p(xt), st))
+                    elif i + 1 < n:
+                        nxt = torch.empty_like(xd)
+                        _lib.check(L.amp_conv_forward(h, p(act), B, T, 1.0, p(cur), 1.0, p(nxt), st))
+                        cur = nxt
+                    else:
+                        _lib.check(L.amp_conv_forward_mrf(h, p(act), B, T, 1.0, p(cur), p(y), mode, div, st))
+        torch.cuda.synchronize()
+        return y.cpu()
+    finally:
+        for h in h1 + h2:
+            L.amp_conv_destroy(h)
