@@ -63,15 +63,27 @@ union FragQ {
 #define AMP_PT(c) (((c) >> 5) + 2 * (((c) >> 2) & 1))
 #define AMP_PR(c) (4 * (((c) >> 3) & 3) + ((c) & 3))
 
+// v_permlane32_swap: lanes 32-63 of a swap with lanes 0-31 of b.  Issued through inline asm on scalar copies, for two reasons seen on
+// hipcc 7.2: (i) __builtin_bit_cast applied directly to an element of an ext_vector_type lvalue reads element 0 and rewrites the whole
+// vector; (ii) with the builtin on sub-registers of the 512-bit accumulator tuples the round trip C -> P -> C came back permuted
+// (first hardware run: a lane's b = 1 column groups held its b = 0 groups), while the same builtin on plain scalars is correct
+// (tests/experiments/ampb_primitives.hip).  The s_nop covers the "VALU write -> v_permlane read" hazard (2 wait states).
+__device__ __forceinline__ void lane_half_swap(float a, float b, float& na, float& nb) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    na = a;
+    nb = b;
+}
+
 // C layout <-> P layout (an involution): lanes 32-63 of v[t][r] swap with lanes 0-31 of v[t + 2][r]
 __device__ __forceinline__ void swap_layout(f32x16 (&v)[4]) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const auto s = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v[t][r]), __builtin_bit_cast(unsigned, v[t + 2][r]), false, false);
-            v[t][r] = __builtin_bit_cast(float, s[0]);
-            v[t + 2][r] = __builtin_bit_cast(float, s[1]);
+            float na, nb;
+            lane_half_swap(v[t][r], v[t + 2][r], na, nb);
+            v[t][r] = na;
+            v[t + 2][r] = nb;
         }
 }
 
@@ -158,10 +170,15 @@ __device__ __forceinline__ void act_run(f32x16 (&v)[4], const float (&hl)[5], co
         // "rewrites" the next group's first inputs together with this group's outputs is a true data dependence: group g + 1 cannot
         // start before group g's outputs exist.
         if (g >= 1 && g < 17) {
-            asm volatile("" : "+v"(v[AMP_PT((4 * g + 4) & 63)][AMP_PR((4 * g + 4) & 63)]), "+v"(v[AMP_PT((4 * g + 5) & 63)][AMP_PR((4 * g + 5) & 63)]),
-                              "+v"(v[AMP_PT((4 * g + 6) & 63)][AMP_PR((4 * g + 6) & 63)]), "+v"(v[AMP_PT((4 * g + 7) & 63)][AMP_PR((4 * g + 7) & 63)]),
-                              "+v"(v[AMP_PT((4 * g - 5) & 63)][AMP_PR((4 * g - 5) & 63)]), "+v"(v[AMP_PT((4 * g - 4) & 63)][AMP_PR((4 * g - 4) & 63)]),
-                              "+v"(v[AMP_PT((4 * g - 3) & 63)][AMP_PR((4 * g - 3) & 63)]), "+v"(v[AMP_PT((4 * g - 2) & 63)][AMP_PR((4 * g - 2) & 63)]));
+            float t0 = v[AMP_PT((4 * g + 4) & 63)][AMP_PR((4 * g + 4) & 63)], t1 = v[AMP_PT((4 * g + 5) & 63)][AMP_PR((4 * g + 5) & 63)];
+            float t2 = v[AMP_PT((4 * g + 6) & 63)][AMP_PR((4 * g + 6) & 63)], t3 = v[AMP_PT((4 * g + 7) & 63)][AMP_PR((4 * g + 7) & 63)];
+            float o0 = v[AMP_PT((4 * g - 5) & 63)][AMP_PR((4 * g - 5) & 63)], o1 = v[AMP_PT((4 * g - 4) & 63)][AMP_PR((4 * g - 4) & 63)];
+            float o2 = v[AMP_PT((4 * g - 3) & 63)][AMP_PR((4 * g - 3) & 63)], o3 = v[AMP_PT((4 * g - 2) & 63)][AMP_PR((4 * g - 2) & 63)];
+            asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3));
+            v[AMP_PT((4 * g + 4) & 63)][AMP_PR((4 * g + 4) & 63)] = t0; v[AMP_PT((4 * g + 5) & 63)][AMP_PR((4 * g + 5) & 63)] = t1;
+            v[AMP_PT((4 * g + 6) & 63)][AMP_PR((4 * g + 6) & 63)] = t2; v[AMP_PT((4 * g + 7) & 63)][AMP_PR((4 * g + 7) & 63)] = t3;
+            v[AMP_PT((4 * g - 5) & 63)][AMP_PR((4 * g - 5) & 63)] = o0; v[AMP_PT((4 * g - 4) & 63)][AMP_PR((4 * g - 4) & 63)] = o1;
+            v[AMP_PT((4 * g - 3) & 63)][AMP_PR((4 * g - 3) & 63)] = o2; v[AMP_PT((4 * g - 2) & 63)][AMP_PR((4 * g - 2) & 63)] = o3;
         }
     }
 }
@@ -297,12 +314,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void ampb_f16x3_kernel(const AmpbA
             const float* nb = h ? xch + ((wr * 2 + 0) * 32 + m) * 5 : xch + ((wl * 2 + 1) * 32 + m) * 5;
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
-                const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, acc[AMP_PT(i)][AMP_PR(i)]),
-                                                                 __builtin_bit_cast(unsigned, acc[AMP_PT(59 + i)][AMP_PR(59 + i)]), false, false);
-                // sw[0] in lanes h = 1: the last five of lane (m, 0); sw[1] in lanes h = 0: the first five of lane (m, 1)
+                float from_lo, from_hi;
+                lane_half_swap(acc[AMP_PT(i)][AMP_PR(i)], acc[AMP_PT(59 + i)][AMP_PR(59 + i)], from_lo, from_hi);
+                // from_lo in lanes h = 1: the last five of lane (m, 0); from_hi in lanes h = 0: the first five of lane (m, 1)
                 const float other = nb[i];
-                hl[i] = h ? __builtin_bit_cast(float, sw[0]) : other;
-                hr[i] = h ? other : __builtin_bit_cast(float, sw[1]);
+                hl[i] = h ? from_lo : other;
+                hr[i] = h ? other : from_hi;
             }
         }
         // wave-uniform filter taps (scalar loads -> SGPR operands); the up taps arrive doubled (UpSample1d's gain, resample.py:41:
