@@ -7,73 +7,45 @@
 
 namespace amp {
 
-// sin(x)^2 for Snake (snake.py:56-61).  The activation evaluates two sines per output sample and was
-// sin-bound with the full-range libm sinf (Payne-Hanek branch + ~40 instructions): a 3-term Cody-Waite
-// reduction by pi (exact k * PI_A for |k| < 2^16) and the odd Taylor polynomial through r^13 on
-// [-pi/2, pi/2] costs 13 FMAs and stays within 1.1e-7 of the exact sine for |x| <= 1e5 (libm: 0.7e-7);
-// the sign lost by reducing modulo pi does not matter under the square.  Larger arguments are reduced in
-// fp64 (snake_reduce_slow: a dozen instructions, so that the whole-AMPBlock kernel can carry the rare path
-// inline) and then take the same polynomial: every kernel of the library evaluates exactly this function.
-__device__ __forceinline__ float snake_reduce_slow(float x) {
-    const double xd = (double)x;
-    const double k = __builtin_rint(xd * 0.31830988618379067154);
-    double r = __builtin_fma(-k, 3.14159265358979311600, xd);     // pi rounded to fp64 ...
-    r = __builtin_fma(-k, 1.22464679914735317723e-16, r);         // ... and what that rounding dropped
-    const float rf = (float)r;
-    // |x| beyond ~1e15 has no phase left in fp64 either: 0 for finite arguments, NaN for inf / NaN (as sin does)
-    return __builtin_fabsf(rf) <= 1.6f ? rf : (x - x);
-}
+// sin(x)^2 for Snake (snake.py:56-61), x = alpha * u already rounded to fp32 as the reference rounds it.
+// Round 4: the hardware sine behind an exact range reduction.  v_sin_f32 takes revolutions and is accurate to ~2e-7 on a reduced
+// argument; what made it useless in round 2's probe was the fp32 rounding of x / 2pi.  With 1 / 2pi split into hi + lo:
+//     k = rint(x * hi);   f = fma(x, hi, -k)  (the exact product minus k: one rounding, |f| <= 0.5);   f = fma(x, lo, f)
+// f is the phase in revolutions to ~1e-8 for every finite x up to ~1e8 (beyond, and for inf / NaN, the result is a bounded
+// garbage value / NaN, as in the reference), and sin(x)^2 = v_sin(f)^2 stays within 3.3e-7 of the exact value over all of that
+// range (tests/experiments/vsin_snake.hip; the reduction by pi + Taylor polynomial it replaces: 1.1e-7 up to |x| = 1e5 and an fp64
+// fallback beyond).  5 ordinary instructions + 1 quarter-rate transcendental instead of 14, no large-argument branch: the evaluation
+// is 1.5x faster, and the activation -- VALU-bound everywhere it runs -- about 15 %.  Every kernel of the library evaluates exactly
+// this function, so they agree bit for bit.
+constexpr float kInv2PiHi = 0.15915493667125702f;      // fp32(1 / 2pi)
+constexpr float kInv2PiLo = 6.4206382432985265e-09f;   // fp32(1 / 2pi - kInv2PiHi)
 
 __device__ __forceinline__ float snake_sin2(float x) {
-    const float k = rintf(x * 0.31830988618379067f);
-    float r = fmaf(-k, 3.140625f, x);
-    r = fmaf(-k, 9.67502593994140625e-4f, r);
-    r = fmaf(-k, 1.509957990978376432e-07f, r);
-    if (__builtin_expect(fabsf(x) > 1.0e5f, 0)) r = snake_reduce_slow(x);
-    const float r2 = r * r;
-    float p = 1.0f / 6227020800.0f;
-    p = fmaf(p, r2, -1.0f / 39916800.0f);
-    p = fmaf(p, r2, 1.0f / 362880.0f);
-    p = fmaf(p, r2, -1.0f / 5040.0f);
-    p = fmaf(p, r2, 1.0f / 120.0f);
-    p = fmaf(p, r2, -1.0f / 6.0f);
-    const float sn = fmaf(r * r2, p, r);
-    return sn * sn;
+    const float k = rintf(x * kInv2PiHi);
+    float f = fmaf(x, kInv2PiHi, -k);
+    f = fmaf(x, kInv2PiLo, f);
+    const float s = __builtin_amdgcn_sinf(f);
+    return s * s;
 }
 
-// Two fp32 lanes per instruction (v_pk_fma_f32 / v_pk_mul_f32: the 157 TFLOP/s vector rate needs them).  Every
-// half goes through exactly the scalar operation sequence, so packed and scalar paths agree bit for bit.
+// Two fp32 lanes per instruction where the ISA has them (v_pk_fma_f32 / v_pk_mul_f32).  Every half goes through exactly the scalar
+// operation sequence, so packed and scalar paths agree bit for bit.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 pk_splat(float v) { return (f32x2){v, v}; }
 
-// sin(x)^2 of snake_sin2's fast path on four pairs (x = a*u already formed by the caller).  Written step by step
-// across the four independent chains so that dependent packed ops are never back to back.
+// snake_sin2 on four pairs (x = a*u already formed by the caller), step by step across the four independent chains.
 __device__ __forceinline__ void snake_sin2_pk4(const f32x2 (&x)[4], f32x2 (&out)[4]) {
-    f32x2 k[4], r[4], r2[4], p[4];
+    f32x2 k[4], f[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) k[q] = __builtin_elementwise_rint(x[q] * 0.31830988618379067f);
+    for (int q = 0; q < 4; ++q) k[q] = __builtin_elementwise_rint(x[q] * kInv2PiHi);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) r[q] = pk_fma(-k[q], pk_splat(3.140625f), x[q]);
+    for (int q = 0; q < 4; ++q) f[q] = pk_fma(x[q], pk_splat(kInv2PiHi), -k[q]);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) r[q] = pk_fma(-k[q], pk_splat(9.67502593994140625e-4f), r[q]);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) r[q] = pk_fma(-k[q], pk_splat(1.509957990978376432e-07f), r[q]);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) r2[q] = r[q] * r[q];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) p[q] = pk_fma(pk_splat(1.0f / 6227020800.0f), r2[q], pk_splat(-1.0f / 39916800.0f));
-#pragma unroll
-    for (int q = 0; q < 4; ++q) p[q] = pk_fma(p[q], r2[q], pk_splat(1.0f / 362880.0f));
-#pragma unroll
-    for (int q = 0; q < 4; ++q) p[q] = pk_fma(p[q], r2[q], pk_splat(-1.0f / 5040.0f));
-#pragma unroll
-    for (int q = 0; q < 4; ++q) p[q] = pk_fma(p[q], r2[q], pk_splat(1.0f / 120.0f));
-#pragma unroll
-    for (int q = 0; q < 4; ++q) p[q] = pk_fma(p[q], r2[q], pk_splat(-1.0f / 6.0f));
+    for (int q = 0; q < 4; ++q) f[q] = pk_fma(x[q], pk_splat(kInv2PiLo), f[q]);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const f32x2 sn = pk_fma(r[q] * r2[q], p[q], r[q]);
+        const f32x2 sn = {__builtin_amdgcn_sinf(f[q].x), __builtin_amdgcn_sinf(f[q].y)};
         out[q] = sn * sn;
     }
 }

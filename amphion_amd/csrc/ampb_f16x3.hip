@@ -14,9 +14,11 @@
 // same LDS tile and the same packed weights (the A and B operand layouts of v_mfma_f32_32x32x16_f16 are mirror images), the
 // same products summed in the same order, so the same bits -- and gets "lane = channel, registers = time":
 //
-//   C layout   acc[t][r] of lane (m = lane & 31, h = lane >> 5): channel 32 * wm + m, wave column 32 t + 8 (r >> 2) + 4 h + (r & 3)
-//   P layout   after 32 v_permlane32_swap (acc[t][r] <-> acc[t + 2][r], t < 2): lane (m, h) owns the 64 CONSECUTIVE columns
-//              64 h + c of its channel, c = 32 t + 8 i + 4 b + j in register acc[t + 2 b][4 i + j].
+//   A rows     row i = 8 a + 4 b + j of the MFMA tile t reads tile column 64 b + 16 t + 4 a + j (a lane picks its own LDS address,
+//              so the row -> column map is free; this one keeps ds_read_b128's four 16-lane groups on 16 distinct bank quads)
+//   P layout   hence acc[t][r] of lane (m = lane & 31, h = lane >> 5) = channel 32 * wm + m at wave column 64 h + 16 t + r: a lane
+//              owns 64 CONSECUTIVE columns of its channel, in register order.  (The first version computed the plain C layout and
+//              exchanged half-waves with 64 v_permlane32_swap per conv; permuting the rows costs nothing.)
 //
 // In the P layout Activation1d is register arithmetic: act1d_kernel's operation sequence (act1d_math.h) on a run of 64 columns,
 // in place, with a sliding window of Snake pairs; only the 5 columns either side of a run come from elsewhere -- the other half
@@ -60,8 +62,8 @@ union FragQ {
 #define AMP_PIN_VMEM() __builtin_amdgcn_sched_barrier(0x386)
 
 // P layout: run column c (0 .. 63) of a lane lives in v[AMP_PT(c)][AMP_PR(c)]
-#define AMP_PT(c) (((c) >> 5) + 2 * (((c) >> 2) & 1))
-#define AMP_PR(c) (4 * (((c) >> 3) & 3) + ((c) & 3))
+#define AMP_PT(c) ((c) >> 4)
+#define AMP_PR(c) ((c) & 15)
 
 // v_permlane32_swap: lanes 32-63 of a swap with lanes 0-31 of b.  Issued through inline asm on scalar copies, for two reasons seen on
 // hipcc 7.2: (i) __builtin_bit_cast applied directly to an element of an ext_vector_type lvalue reads element 0 and rewrites the whole
@@ -72,19 +74,6 @@ __device__ __forceinline__ void lane_half_swap(float a, float b, float& na, floa
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     na = a;
     nb = b;
-}
-
-// C layout <-> P layout (an involution): lanes 32-63 of v[t][r] swap with lanes 0-31 of v[t + 2][r]
-__device__ __forceinline__ void swap_layout(f32x16 (&v)[4]) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float na, nb;
-            lane_half_swap(v[t][r], v[t + 2][r], na, nb);
-            v[t][r] = na;
-            v[t + 2][r] = nb;
-        }
 }
 
 template <int CTRL>
@@ -139,30 +128,39 @@ __device__ __forceinline__ void act_run(f32x16 (&v)[4], const float (&hl)[5], co
 #pragma unroll
     for (int g = 0; g < 18; ++g) {
         f32x2 uv[4], xa[4], sv[4];
+        // the four chains step by step (dependent packed FMAs back to back cost a wait state each)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int Q = 4 * g + q;
-            f32x2 u = pk_splat(0.f);
+        for (int q = 0; q < 4; ++q) uv[q] = pk_splat(0.f);
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const int c = Q - k;
+        for (int k = 0; k < 6; ++k) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = 4 * g + q - k;
                 const float xv = c < 0 ? hl[c + 5 < 0 ? 0 : c + 5] : (c > 63 ? hr[c - 64 > 4 ? 4 : c - 64] : v[AMP_PT(c & 63)][AMP_PR(c & 63)]);
-                u = pk_fma(pk_splat(xv), (f32x2){fu2[2 * k], fu2[2 * k + 1]}, u);
+                uv[q] = pk_fma(pk_splat(xv), (f32x2){fu2[2 * k], fu2[2 * k + 1]}, uv[q]);
             }
-            uv[q] = u;
-            xa[q] = u * a;
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xa[q] = uv[q] * a;
         snake_sin2_pk4(xa, sv);
 #pragma unroll
         for (int q = 0; q < 4; ++q) P[4 * g + q] = pk_fma(pk_splat(invb), sv[q], uv[q]);
+        {
+            f32x2 oa[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int t = 4 * g - 5 + e;
-            if (t >= 0 && t < 64) {
-                f32x2 acc = pk_splat(0.f);
+            for (int e = 0; e < 4; ++e) oa[e] = pk_splat(0.f);
 #pragma unroll
-                for (int m = 0; m < 6; ++m) acc = pk_fma((f32x2){fd[2 * m], fd[2 * m + 1]}, P[(t + m) < 72 ? (t + m) : 71], acc);
-                v[AMP_PT(t & 63)][AMP_PR(t & 63)] = acc.x + acc.y;
+            for (int m = 0; m < 6; ++m) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int t = 4 * g - 5 + e;
+                    if (t >= 0 && t < 64) oa[e] = pk_fma((f32x2){fd[2 * m], fd[2 * m + 1]}, P[(t + m) < 72 ? (t + m) : 71], oa[e]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int t = 4 * g - 5 + e;
+                if (t >= 0 && t < 64) v[AMP_PT(t & 63)][AMP_PR(t & 63)] = oa[e].x + oa[e].y;
             }
         }
         // One group at a time.  The 18 groups are independent until their outputs, and instruction selection linearises the block
@@ -280,7 +278,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void ampb_f16x3_kernel(const AmpbA
     };
 
     f32x16 xv[4];                             // x (then x + pair_0(x), ...): the residual, P layout
-    f32x16 acc[4];                            // accumulators (C layout) / the activation's operand and result (P layout)
+    f32x16 acc[4];                            // accumulators / the activation's operand and result (P layout)
     load_rows(a.x, qw, xv);
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = xv[t];
@@ -433,7 +431,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void ampb_f16x3_kernel(const AmpbA
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[t][r] = bv * sc;
             } else {
-                // (bias + residual [+ running MRF sum]) * scale, conv_f16x3.hip's accumulator start; formed in the P layout
+                // (bias + residual [+ running MRF sum]) * scale, conv_f16x3.hip's accumulator start
 #pragma unroll
                 for (int t = 0; t < 4; ++t) acc[t] = xv[t] + bv;
                 if (last && a.mode != 0) {
@@ -444,11 +442,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void ampb_f16x3_kernel(const AmpbA
                 }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) acc[t] *= sc;
-                swap_layout(acc);
             }
             const int d = a.dil[s];
             const uint4* wa = static_cast<const uint4*>(a.wp[s]) + (size_t)wm * MBS + lane;
-            const int rd = h * WL + G + 128 * wn + m - H2 * d;
+            // A row m = 8 a + 4 b + j of tile t <- tile column 64 b + 16 t + 4 a + j (see the header): output register r of tile t is then
+            // run column 16 t + r of this lane
+            const int rd = h * WL + G + 128 * wn + 64 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3) - H2 * d;
 #pragma unroll 1
             for (int c = 0; c < NCH; ++c) {
                 const uint4* wcur = wa + (size_t)c * (KT * 128);
@@ -463,8 +462,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void ampb_f16x3_kernel(const AmpbA
                         FragQ xh[2], xl[2];
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
-                            xh[t].u = bg[32 * (th * 2 + t)];
-                            xl[t].u = bg[2 * WL + 32 * (th * 2 + t)];
+                            xh[t].u = bg[16 * (th * 2 + t)];
+                            xl[t].u = bg[2 * WL + 16 * (th * 2 + t)];
                         }
 #pragma unroll
                         for (int t = 0; t < 2; ++t)
@@ -485,7 +484,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void ampb_f16x3_kernel(const AmpbA
                     AMP_PIN_VMEM();
                 }
             }
-            // un-scale (conv_f16x3.hip's epilogue), back to the P layout
+            // un-scale (conv_f16x3.hip's epilogue)
             const float isc = a.isc[s];
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[t] *= isc;
@@ -496,7 +495,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void ampb_f16x3_kernel(const AmpbA
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[t][r] = acc[t][r] / dv;
             }
-            swap_layout(acc);
             if (odd) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) xv[t] = acc[t];

@@ -339,7 +339,6 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
             const float4 w2 = *reinterpret_cast<const float4*>(yw + 8);
             const float xw[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
             f32x2 uv[4], xa[4], sv[4];
-            float big = 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int top = q + 8;
@@ -348,24 +347,10 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
                 for (int k = 0; k < 6; ++k) u = pk_fma(pk_splat(xw[top - k]), (f32x2){fu2[2 * k], fu2[2 * k + 1]}, u);
                 uv[q] = u;
                 xa[q] = u * aa;
-                big = fmaxf(big, fmaxf(fabsf(xa[q].x), fabsf(xa[q].y)));
             }
             snake_sin2_pk4(xa, sv);
 #pragma unroll
             for (int q = 0; q < 4; ++q) sv[q] = pk_fma(pk_splat(invb), sv[q], uv[q]);
-            if (__builtin_expect(big > 1.0e5f, 0)) {
-                // beyond the fast range reduction: the eight values one at a time through snake_sin2 (libm sine above
-                // 1e5, the identical operation sequence below it), as act1d_kernel does
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int top = ((e + 10) >> 1) + 3, par = e & 1;
-                    float u = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) u = fmaf(xw[top - k], fu2[par + 2 * k], u);
-                    const float s1 = fmaf(invb, snake_sin2(u * aa), u);
-                    if (par) sv[e >> 1].y = s1; else sv[e >> 1].x = s1;
-                }
-            }
             *reinterpret_cast<float4*>(&srow[4 * sl_pos4(2 * cg)]) = make_float4(sv[0].x, sv[0].y, sv[1].x, sv[1].y);
             *reinterpret_cast<float4*>(&srow[4 * sl_pos4(2 * cg + 1)]) = make_float4(sv[2].x, sv[2].y, sv[3].x, sv[3].y);
             __syncthreads();

@@ -899,7 +899,6 @@ struct ActParams {  // one Activation1d
     float* fu_dev = nullptr;    // 12 taps
     float* fd_dev = nullptr;
     float* fu2_dev = nullptr;   // 2 * the up taps (UpSample1d's gain folded in, resample.py:41): what ampb_f16x3.hip reads into SGPRs
-    float a_max = 0.f;          // max_c |alpha_c| (host copy: ampb_supported)
 };
 
 struct ResBlock {
@@ -913,12 +912,20 @@ struct ResBlock {
 // bit-identical to the 6 conv + 6 act1d launches.  amp_set_ampblock_fusion / AMP_AMPB_FUSION: 0 off, 1 (default) the policy
 // below, 2 every shape the kernel is built for (any grid), 3 = 2 with the four-wave 512-column tiles at C = 32.
 static int ampb_fusion_mode() { return cfg().ampb_fusion; }
-static int ampb_form(int C, int /*k*/) {
+static int ampb_form(int C, int k) {
     const int m = ampb_fusion_mode();
     if (m == 0) return -1;
     if (m == 3) return C == 32 ? 0 : 1;
     if (m == 2) return 1;
-    if (C == 32 || C == 64) return 1;
+    // policy: measured INSIDE the config-3 forward (BigVGAN-base, B = 32), one box, modes alternating (tools/ampb_inforward.py,
+    // profiles/r4_i_ampb_inforward.txt; ms per AMPBlock, 6 conv + 6 act1d launches -> this kernel):
+    //   C = 32  k = 3 1.67 -> 1.07, k = 7 1.83 -> 1.42 with the four-wave 512-column tiles (two workgroups per CU: one's activations run
+    //           under the other's MFMAs; eight-wave 1024-column tiles: 1.20 / 1.46); k = 11 2.14 -> 1.81 with the EIGHT-wave tiles (18 %
+    //           recomputed halo instead of 36 %; four-wave: 1.91)
+    //   C = 64  (eight waves, 512 columns, one workgroup per CU: every wave in the same phase, so MFMA and VALU time add up)
+    //           k = 3 1.69 -> 1.57; k = 7 2.10 -> 2.22 and k = 11 2.51 -> 3.07 lose and stay on separate launches
+    if (C == 32) return k >= 11 ? 1 : 0;
+    if (C == 64) return k <= 3 ? 1 : -1;
     return -1;
 }
 constexpr long long kAmpbMinWorkgroups = 256;
@@ -930,15 +937,10 @@ static int ampb_halo(const amp_conv* const* c1, int np) {
     return (rh + 3) & ~3;
 }
 
-// Snake's fast range reduction (act1d_math.h) holds for |alpha * u| <= 1e5, where the stand-alone kernels switch to the fp64 reduction;
-// this kernel carries only the fast path (18 inlined branches to the slow one cost 200 spilled registers).  With alpha <= 16 an
-// argument beyond 1e5 needs |u| > 6250, i.e. activations that leave the f16x3 operand range (4094) on the very next staging and trip
-// the range guard, which repeats the forward on the exact-fp32 path.  Larger alphas keep the unfused launches.
-constexpr float kAmpbMaxAlpha = 16.f;
 static bool ampb_supported(const amp_conv* const* c1, const amp_conv* const* c2, int np, const ActParams* acts, size_t nacts, int B, int T) {
     if (np < 1 || 2 * np > AMP_AMPB_MAX_STEPS || nacts != (size_t)(2 * np)) return false;
     for (size_t i = 0; i < nacts; ++i)
-        if (!(acts[i].a_max <= kAmpbMaxAlpha) || !acts[i].fu2_dev) return false;
+        if (!acts[i].fu2_dev) return false;
     if ((T & 3) != 0) return false;                               // rows are moved as aligned float4
     int max_dil = 1;
     for (int p = 0; p < np; ++p) {
@@ -1056,7 +1058,7 @@ static std::string ups_key(const amp_gen* g, int i) {
 // Op-level convenience (tests): derive a = alpha (exp'ed when logscale) and 1 / (beta + 1e-9) on the host and upload them
 // with the two 12-tap filters: scratch = [a (C) | invb (C) | up taps (12) | down taps (12) | 2 * up taps (12)].  The caller frees `*out`.
 static int act_params_upload(const float* alpha_dev, const float* beta_dev, int C, int logscale, const float* filt_up_host,
-                             const float* filt_down_host, float** out, float* a_max = nullptr) {
+                             const float* filt_down_host, float** out) {
     std::vector<float> al(C), be(C), a(C), ib(C);
     AMP_HIP(hipMemcpy(al.data(), alpha_dev, C * sizeof(float), hipMemcpyDeviceToHost));
     if (beta_dev) AMP_HIP(hipMemcpy(be.data(), beta_dev, C * sizeof(float), hipMemcpyDeviceToHost));
@@ -1065,7 +1067,6 @@ static int act_params_upload(const float* alpha_dev, const float* beta_dev, int 
         if (logscale) { av = expf(av); bv = expf(bv); }
         a[i] = av;
         ib[i] = 1.0f / (bv + 0.000000001f);
-        if (a_max) *a_max = fmaxf(*a_max, fabsf(av));
     }
     float* scratch = nullptr;
     AMP_HIP(hipMalloc((void**)&scratch, (2 * (size_t)C + 36) * sizeof(float)));
@@ -1249,7 +1250,6 @@ static int build_act(amp_gen* g, const std::string& p, int c, ActParams* out) {
         if (g->d.snake_logscale) { al = expf(al); be = expf(be); }  // snake.py:57-58,116-118
         a[i] = al;
         ib[i] = 1.0f / (be + 0.000000001f);                          // snake.py:59,119
-        out->a_max = fmaxf(out->a_max, fabsf(al));
     }
     int rc;
     if ((rc = upload(g, a.data(), c, &out->a_dev)) != AMP_OK) return rc;
@@ -1877,7 +1877,7 @@ int amp_ampblock_forward(const amp_conv* const* c1, const amp_conv* const* c2, i
     ActParams acts[AMP_AMPB_MAX_STEPS];
     int rc = AMP_OK;
     for (int i = 0; i < na && rc == AMP_OK; ++i) {
-        rc = act_params_upload(alpha_dev + (size_t)i * C, beta_dev ? beta_dev + (size_t)i * C : nullptr, C, logscale, filt_up_host, filt_down_host, &scratch[i], &acts[i].a_max);
+        rc = act_params_upload(alpha_dev + (size_t)i * C, beta_dev ? beta_dev + (size_t)i * C : nullptr, C, logscale, filt_up_host, filt_down_host, &scratch[i]);
         if (rc == AMP_OK) { acts[i].a_dev = scratch[i]; acts[i].invb_dev = scratch[i] + C; acts[i].fu_dev = scratch[i] + 2 * C; acts[i].fd_dev = scratch[i] + 2 * C + 12; acts[i].fu2_dev = scratch[i] + 2 * C + 24; }
     }
     if (rc == AMP_OK && !ampb_supported(c1, c2, n_pairs, acts, (size_t)na, B, T)) {

@@ -266,7 +266,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void a
             const float4 w2 = *reinterpret_cast<const float4*>(&xl[xb + 8]);
             const float xw[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
             f32x2 uv[4], xa[4], sv[4];
-            float big = 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int top = q + 8;                        // ((2q + 10) >> 1) + 3
@@ -275,19 +274,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void a
                 for (int k = 0; k < 6; ++k) u = pk_fma(pk_splat(xw[top - k]), (f32x2){fu2[2 * k], fu2[2 * k + 1]}, u);
                 uv[q] = u;
                 xa[q] = u * a;
-                big = fmaxf(big, fmaxf(fabsf(xa[q].x), fabsf(xa[q].y)));
             }
             snake_sin2_pk4(xa, sv);
 #pragma unroll
             for (int q = 0; q < 4; ++q) sv[q] = pk_fma(pk_splat(invb), sv[q], uv[q]);
             *reinterpret_cast<float4*>(&sl[4 * sl_pos4(2 * lane)]) = make_float4(sv[0].x, sv[0].y, sv[1].x, sv[1].y);
             *reinterpret_cast<float4*>(&sl[4 * sl_pos4(2 * lane + 1)]) = make_float4(sv[2].x, sv[2].y, sv[3].x, sv[3].y);
-            if (__builtin_expect(big > 1.0e5f, 0)) {
-                // beyond the fast range reduction: redo this lane's eight values one at a time through
-                // snake_sin2 (fp64 range reduction above 1e5, the identical operation sequence below it)
-#pragma nounroll
-                for (int e = 0; e < 8; ++e) sl[sl_pos(8 * lane + e)] = snake_scalar(8 * lane + e);
-            }
             // the 10 values past the 512 (the down filter's right halo): one lane each
             if (lane >= 64 - 10) {
                 const int i = 2 * A1_WT + (lane - (64 - 10));

@@ -314,7 +314,7 @@ int amp_set_resblock_fusion(int mode);
  * zero padding, with bias.  alpha_dev / beta_dev: [2 * n_pairs, C] per-channel parameters AS STORED (exp() applied when
  * logscale; beta_dev NULL -> Snake); filt_up_host / filt_down_host: the 12 filter taps shared by all activations.
  * mode 0: y = v;  1: y = y + v;  2: y = (y + v) / div  (the MRF accumulation of the generator, bigvgan.py:320-327).
- * Covered: C in {32, 64}, k in {3, 5, 7, 11}, (k-1)/2 * dilation <= 32, n_pairs <= 3, T % 4 == 0, every |alpha| <= 16, under
+ * Covered: C in {32, 64}, k in {3, 5, 7, 11}, (k-1)/2 * dilation <= 32, n_pairs <= 3, T % 4 == 0, under
  * the shapes the current amp_set_ampblock_fusion mode admits -- otherwise AMP_ERR_UNSUPPORTED.  y_dev must not alias x_dev.
  * Op-level convenience: synchronises the stream. */
 int amp_ampblock_forward(const amp_conv* const* c1, const amp_conv* const* c2, int n_pairs, const float* alpha_dev,

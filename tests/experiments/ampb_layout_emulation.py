@@ -1,5 +1,5 @@
-"""CPU emulation of the data movement of csrc/ampb_f16x3.hip (one workgroup): C layout -> P layout (v_permlane32_swap), the halo
-exchange (swap + LDS slots), the 8 x 8 DPP lane transposes and the operand-tile addresses, and the conv's fragment reads -- every
+"""CPU emulation of the data movement of csrc/ampb_f16x3.hip (one workgroup): the permuted A rows that make the MFMA result land in
+the P layout, the halo exchange (v_permlane32_swap + LDS slots), the 8 x 8 DPP lane transposes and the operand-tile addresses, and the conv's fragment reads -- every
 index formula of the kernel restated over numpy "registers" [wave][lane][...] and checked against the tensor coordinates it is meant
 to hold.  The hardware semantics it assumes (permlane32_swap, DPP row_shl/shr/quad_perm, the MFMA operand mirror) are the ones
 tests/experiments/ampb_primitives.hip checks on the GPU.      python tests/experiments/ampb_layout_emulation.py"""
@@ -15,10 +15,15 @@ def f(ch, col):            # the tensor value at (channel, tile column): unique 
     return ch * 10000.0 + col
 
 
-PT = lambda c: (c >> 5) + 2 * ((c >> 2) & 1)
-PR = lambda c: 4 * ((c >> 3) & 3) + (c & 3)
+PT = lambda c: c >> 4
+PR = lambda c: c & 15
 
-# --- conv output in the C layout (transposed product): lane (m, h) of wave (wm, wn), acc[t][r]
+
+def arow_col(i, t):          # A row i of MFMA tile t reads wave column ...
+    return 64 * ((i >> 2) & 1) + 16 * t + 4 * (i >> 3) + (i & 3)
+
+
+# --- conv output (transposed product): lane (m, h), acc[t][r] = MFMA row 8 (r >> 2) + 4 h + (r & 3), i.e. the column that row read
 acc = np.zeros((NW, 64, 4, 16))
 for w in range(NW):
     wm, wn = divmod(w, WN)
@@ -26,7 +31,7 @@ for w in range(NW):
         m, h = lane & 31, lane >> 5
         for t in range(4):
             for r in range(16):
-                acc[w, lane, t, r] = f(32 * wm + m, 128 * wn + 32 * t + 8 * (r >> 2) + 4 * h + (r & 3))
+                acc[w, lane, t, r] = f(32 * wm + m, 128 * wn + arow_col(8 * (r >> 2) + 4 * h + (r & 3), t))
 
 
 def permlane32_swap(a, b):  # a, b: [64]; lanes 32-63 of a swap with lanes 0-31 of b
@@ -35,11 +40,7 @@ def permlane32_swap(a, b):  # a, b: [64]; lanes 32-63 of a swap with lanes 0-31 
     return a2, b2
 
 
-# --- swap_layout
-for w in range(NW):
-    for t in range(2):
-        for r in range(16):
-            acc[w, :, t, r], acc[w, :, t + 2, r] = permlane32_swap(acc[w, :, t, r], acc[w, :, t + 2, r])
+# --- the result is the P layout
 for w in range(NW):
     wm, wn = divmod(w, WN)
     for lane in range(64):
@@ -137,17 +138,21 @@ for w in range(NW):
     wm, wn = divmod(w, WN)
     for lane in range(64):
         m, h = lane & 31, lane >> 5
-        rd = h * WL + G + 128 * wn + m - H2 * d
+        rd = h * WL + G + 128 * wn + 64 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3) - H2 * d
         for c in range(NCH):
             for g in (0, 5, 10):
                 for t in range(4):
-                    col = 128 * wn + 32 * t + m + (g - H2) * d
-                    got = smem[c * CHS + rd + g * d + 32 * t]
+                    col = 128 * wn + arow_col(m, t) + (g - H2) * d
+                    got = smem[c * CHS + rd + g * d + 16 * t]
                     if 0 <= col < W:
                         assert all(got[e] == f(16 * c + 8 * h + e, col) for e in range(8)), (w, lane, c, g, t)
                     else:
                         assert all(got[e] == -1.0 for e in range(8))           # guard columns (zero in the kernel)
 print("fragment reads ok")
+# ds_read_b128 is served in four 16-lane groups; each must touch 16 distinct 16-B slots (mod 16: 64 banks)
+for grp in ([0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]):
+    assert len({arow_col(i, 0) % 16 for i in grp}) == 16
+print("fragment reads conflict-free")
 # --- the edge patch address: channel ch, tile column col -> f16 index
 for ch in (0, 7, 8, 15, 16, 40, 63):
     for col in (0, 3, 100):

@@ -42,8 +42,8 @@ def test_activation1d_vs_oracle(B, C, T):
 
 
 def test_activation1d_large_arguments():
-    # |alpha * u| > 1e5 leaves the fast range reduction (snake_sin2 falls back to libm's sine).  fp32 sin of such
-    # arguments is ill-conditioned (one ulp of u moves the phase by ~0.02 rad), so the check is the bound
+    # |alpha * u| > 1e5 (rounds 1-3: beyond the polynomial's range reduction, a libm fallback; round 4: the same hardware-sine path as
+    # every other argument).  fp32 sin of such arguments is ill-conditioned (one ulp of u moves the phase by ~0.02 rad), so the check is the bound
     # |y - down(up(x))| <= max 1/beta, finiteness, and agreement with the oracle where alpha is small.
     from hip_helpers import act1d_forward
 
