@@ -95,13 +95,15 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairArgs a) {
         okc[t] = (col < NT) && (q < T);
         qc[t] = q < T ? q : T - 1;
     }
-    const float* xres = a.x + (size_t)item * C * T + (size_t)(32 * wm + 4 * hi) * T;
+    // this lane's rows: channels 32 * wm + 16 * hi + r (permuted A rows, round 4 -- see rb_f16x3.hip's header: a lane's accumulators
+    // are one 16-channel chunk, the seam two conflict-free ds_write_b128 per plane; the same dot products, the same bits)
+    const float* xres = a.x + (size_t)item * C * T + (size_t)(32 * wm + 16 * hi) * T;
     f32x16 rv[NI];
     if (RES_EARLY) {
 #pragma unroll
         for (int t = 0; t < NI; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) rv[t][r] = xres[(size_t)((r & 3) + 8 * (r >> 2)) * T + qc[t]];
+            for (int r = 0; r < 16; ++r) rv[t][r] = xres[(size_t)r * T + qc[t]];
     }
 
     // ---------------- phase 1: conv1 ----------------
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairArgs a) {
         const float s1 = a.sc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float bv = a.bias1[32 * wm + (r & 3) + 8 * (r >> 2) + 4 * hi] * s1;
+            const float bv = a.bias1[32 * wm + 16 * hi + r] * s1;
 #pragma unroll
             for (int t = 0; t < NI; ++t) acc[t][r] = bv;
         }
@@ -152,8 +154,9 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairArgs a) {
 
     // A fragments [mb][chunk][tap][plane][lane] x uint4, one register set, reloaded one chunk ahead
     // (conv_f16x3.hip); the reload during conv1's LAST chunk fetches conv2's first chunk.
-    const uint4* wa1 = static_cast<const uint4*>(a.wp1) + (size_t)wm * NCH * (KT * 128) + lane;
-    const uint4* wa2 = static_cast<const uint4*>(a.wp2) + (size_t)wm * NCH * (KT * 128) + lane;
+    const int wlane = (lane & 32) | (16 * ((lane >> 2) & 1) + 4 * ((lane >> 3) & 3) + (lane & 3));   // A row 8a + 4b + j <- weight row 16b + 4a + j
+    const uint4* wa1 = static_cast<const uint4*>(a.wp1) + (size_t)wm * NCH * (KT * 128) + wlane;
+    const uint4* wa2 = static_cast<const uint4*>(a.wp2) + (size_t)wm * NCH * (KT * 128) + wlane;
     Frag a_h[KT], a_l[KT];
 
     const int colw = wn * (32 * NI) + l31;    // this lane's column inside the tile (n-tile 0)
@@ -205,20 +208,20 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairArgs a) {
     {
         const float i1 = a.isc1;
         const float slope = a.slope;
-        uint2* xt2 = reinterpret_cast<uint2*>(xt4);
 #pragma unroll
         for (int t = 0; t < NI; ++t) {
             const int col = colw + 32 * t;                   // xt column (tile-local)
             const int q = q0 - H2 + col;                     // its global column
             const bool qok = (q >= 0) && (q < Tv);           // conv2 zero-pads xt outside the utterance
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                struct { uint2 u; } fh, fl;
-                seam4_f16(acc[t][4 * j + 0], acc[t][4 * j + 1], acc[t][4 * j + 2], acc[t][4 * j + 3], i1, slope, qok, range_max, fh.u, fl.u);
-                // channels 32*wm + 8*j + 4*hi + i  ->  chunk 2*wm + (j >> 1), octet j & 1, half hi
-                const int o4 = (2 * wm + (j >> 1)) * XTCH + (j & 1) * XT + col;
-                xt2[(o4 << 1) + hi] = fh.u;
-                xt2[((o4 + 2 * XT) << 1) + hi] = fl.u;
+            for (int o = 0; o < 2; ++o) {
+                struct { uint2 u; } fh0, fl0, fh1, fl1;
+                seam4_f16(acc[t][8 * o + 0], acc[t][8 * o + 1], acc[t][8 * o + 2], acc[t][8 * o + 3], i1, slope, qok, range_max, fh0.u, fl0.u);
+                seam4_f16(acc[t][8 * o + 4], acc[t][8 * o + 5], acc[t][8 * o + 6], acc[t][8 * o + 7], i1, slope, qok, range_max, fh1.u, fl1.u);
+                // channels 32*wm + 16*hi + 8*o + i  ->  chunk 2*wm + hi, octet o: a whole 16-B unit
+                const int o4 = (2 * wm + hi) * XTCH + o * XT + col;
+                xt4[o4] = make_uint4(fh0.u.x, fh0.u.y, fh1.u.x, fh1.u.y);
+                xt4[o4 + 2 * XT] = make_uint4(fl0.u.x, fl0.u.y, fl1.u.x, fl1.u.y);
             }
         }
     }
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairArgs a) {
         const float s2 = a.sc2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float bv = a.bias2[32 * wm + (r & 3) + 8 * (r >> 2) + 4 * hi] * s2;
+            const float bv = a.bias2[32 * wm + 16 * hi + r] * s2;
 #pragma unroll
             for (int t = 0; t < NI; ++t) acc[t][r] = bv;
         }
@@ -269,12 +272,12 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairArgs a) {
     {
         const float i2 = a.isc2;
         const int mode = a.mode;
-        float* yr = a.y + (size_t)item * C * T + (size_t)(32 * wm + 4 * hi) * T;
+        float* yr = a.y + (size_t)item * C * T + (size_t)(32 * wm + 16 * hi) * T;
         if (!RES_EARLY) {
 #pragma unroll
             for (int t = 0; t < NI; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) rv[t][r] = xres[(size_t)((r & 3) + 8 * (r >> 2)) * T + qc[t]];
+                for (int r = 0; r < 16; ++r) rv[t][r] = xres[(size_t)r * T + qc[t]];
         }
 #pragma unroll
         for (int t = 0; t < NI; ++t) acc[t] = acc[t] * i2 + rv[t];
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairArgs a) {
 #pragma unroll
             for (int t = 0; t < NI; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) rv[t][r] = yr[(size_t)((r & 3) + 8 * (r >> 2)) * T + qc[t]];
+                for (int r = 0; r < 16; ++r) rv[t][r] = yr[(size_t)r * T + qc[t]];
 #pragma unroll
             for (int t = 0; t < NI; ++t) acc[t] += rv[t];
             if (mode == 2) {
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void pair_f16x3_kernel(const PairArgs a) {
         for (int t = 0; t < NI; ++t)
             if (okc[t]) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) yr[(size_t)((r & 3) + 8 * (r >> 2)) * T + qc[t]] = acc[t][r];
+                for (int r = 0; r < 16; ++r) yr[(size_t)r * T + qc[t]] = acc[t][r];
             }
     }
     if (a.range_flag && __any(range_max > 65504.f) && lane == 0) atomicOr(a.range_flag, 1u);

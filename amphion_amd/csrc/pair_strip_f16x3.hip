@@ -103,8 +103,12 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
     // next to the staging loads of the same cache lines (pair_f16x3.hip); C >= 128 re-reads in the epilogue.
     constexpr bool RES_EARLY = WM * MI < 4;
     const int colw = wn * (32 * NI) + l31;    // this lane's column inside the step (n-tile 0)
-    const float* xres = a.x + (size_t)item * C * T + (size_t)(32 * MI * wm + 4 * hi) * T;
-    float* yr = a.y + (size_t)item * C * T + (size_t)(32 * MI * wm + 4 * hi) * T;
+    // this lane's rows of row block mi: channels 32 * (MI * wm + mi) + 16 * hi + r (PERMUTED A rows, round 4: A row (lane & 31) =
+    // 8 a + 4 b + j fetches the packed fragment of weight row 16 b + 4 a + j, so a lane's sixteen accumulators are one 16-channel
+    // chunk = two whole octets and the seam is two conflict-free ds_write_b128 per plane instead of four ds_write_b64 at a 16-B lane
+    // stride -- rb_f16x3.hip's header has the measurement; the same dot products in other rows of the tile, the same bits)
+    const float* xres = a.x + (size_t)item * C * T + (size_t)(32 * MI * wm + 16 * hi) * T;
+    float* yr = a.y + (size_t)item * C * T + (size_t)(32 * MI * wm + 16 * hi) * T;
 
     // Step-local, opaque copies of T and the row bases (set at the top of every step): with the plain values hipcc
     // hoists every row offset r * T and the 48 residual / output addresses out of the step loop and holds them
@@ -156,8 +160,9 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
     // A fragments [mb][chunk][tap][plane][lane] x uint4, one register set, reloaded one chunk ahead; the reload
     // during conv1's last chunk fetches conv2's first chunk, the one during conv2's last chunk the next step's.
     constexpr size_t MBS = (size_t)NCH * (KT * 128);   // uint4 per 32-row block of packed A fragments
-    const uint4* wa1 = static_cast<const uint4*>(a.wp1) + (size_t)(MI * wm) * MBS + lane;
-    const uint4* wa2 = static_cast<const uint4*>(a.wp2) + (size_t)(MI * wm) * MBS + lane;
+    const int wlane = (lane & 32) | (16 * ((lane >> 2) & 1) + 4 * ((lane >> 3) & 3) + (lane & 3));   // the permuted fragment (above)
+    const uint4* wa1 = static_cast<const uint4*>(a.wp1) + (size_t)(MI * wm) * MBS + wlane;
+    const uint4* wa2 = static_cast<const uint4*>(a.wp2) + (size_t)(MI * wm) * MBS + wlane;
     constexpr int NA = RING > 0 ? RING : KT;          // A-fragment register sets per row block
     FragS a_h[MI][NA], a_l[MI][NA];
     // after tap g of the chunk at `wcur`: the register set of tap g is re-loaded with the tap it serves next -- the same tap of the
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
 #pragma unroll
                 for (int t = 0; t < NI; ++t)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) rv[mi][t][r] = xres_s[(size_t)(32 * mi + (r & 3) + 8 * (r >> 2)) * Ts + qc[t]];
+                    for (int r = 0; r < 16; ++r) rv[mi][t][r] = xres_s[(size_t)(32 * mi + r) * Ts + qc[t]];
         }
 
         // ---------------- conv1 ----------------
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float bv = bias1[32 * (MI * wm + mi) + (r & 3) + 8 * (r >> 2) + 4 * hi] * s1;
+                    const float bv = bias1[32 * (MI * wm + mi) + 16 * hi + r] * s1;
 #pragma unroll
                     for (int t = 0; t < NI; ++t) acc[mi][t][r] = bv;
                 }
@@ -276,20 +281,19 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
 
         // ---------------- seam: carry the halo, xt = lrelu(conv1) -> LDS, split-f16 B layout ----------------
         {
-            uint2* xt2 = reinterpret_cast<uint2*>(xt4);
             // position of xt column `col` of this step = HB + col.  The lane that wrote column col >= N1 - HB in the
             // previous step moves it from HB + col to HB + col - N1 before overwriting it (own data, in order).
             if (s > 0 && wn == WN - 1) {
                 const int col = colw + 32 * (NI - 1);
                 if (col >= N1 - HB) {
 #pragma unroll
-                    for (int jm = 0; jm < 4 * MI; ++jm) {
-                        const int mi = jm >> 2, j = jm & 3;
-                        const int o4 = (2 * (MI * wm + mi) + (j >> 1)) * XTCH + (j & 1) * XT + HB + col;
-                        const uint2 vh = xt2[(o4 << 1) + hi];
-                        const uint2 vl = xt2[((o4 + 2 * XT) << 1) + hi];
-                        xt2[((o4 - N1) << 1) + hi] = vh;
-                        xt2[((o4 - N1 + 2 * XT) << 1) + hi] = vl;
+                    for (int jm = 0; jm < 2 * MI; ++jm) {
+                        const int mi = jm >> 1, o = jm & 1;
+                        const int o4 = (2 * (MI * wm + mi) + hi) * XTCH + o * XT + HB + col;
+                        const uint4 vh = xt4[o4];
+                        const uint4 vl = xt4[o4 + 2 * XT];
+                        xt4[o4 - N1] = vh;
+                        xt4[o4 - N1 + 2 * XT] = vl;
                     }
                 }
             }
@@ -301,14 +305,15 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
                 const int q = X + col;                           // its global column
                 const bool qok = (q >= 0) && (q < Tv);           // conv2 zero-pads xt outside the utterance
 #pragma unroll
-                for (int jm = 0; jm < 4 * MI; ++jm) {
-                    const int mi = jm >> 2, j = jm & 3;
-                    struct { uint2 u; } fh, fl;
-                    seam4_f16(acc[mi][t][4 * j + 0], acc[mi][t][4 * j + 1], acc[mi][t][4 * j + 2], acc[mi][t][4 * j + 3], i1, slope, qok, range_max, fh.u, fl.u);
-                    // channels 32*(MI*wm + mi) + 8*j + 4*hi + i  ->  chunk 2*(MI*wm + mi) + (j >> 1), octet j & 1, half hi
-                    const int o4 = (2 * (MI * wm + mi) + (j >> 1)) * XTCH + (j & 1) * XT + HB + col;
-                    xt2[(o4 << 1) + hi] = fh.u;
-                    xt2[((o4 + 2 * XT) << 1) + hi] = fl.u;
+                for (int jm = 0; jm < 2 * MI; ++jm) {
+                    const int mi = jm >> 1, o = jm & 1;
+                    struct { uint2 u; } fh0, fl0, fh1, fl1;
+                    seam4_f16(acc[mi][t][8 * o + 0], acc[mi][t][8 * o + 1], acc[mi][t][8 * o + 2], acc[mi][t][8 * o + 3], i1, slope, qok, range_max, fh0.u, fl0.u);
+                    seam4_f16(acc[mi][t][8 * o + 4], acc[mi][t][8 * o + 5], acc[mi][t][8 * o + 6], acc[mi][t][8 * o + 7], i1, slope, qok, range_max, fh1.u, fl1.u);
+                    // channels 32*(MI*wm + mi) + 16*hi + 8*o + i  ->  chunk 2*(MI*wm + mi) + hi, octet o: a whole 16-B unit
+                    const int o4 = (2 * (MI * wm + mi) + hi) * XTCH + o * XT + HB + col;
+                    xt4[o4] = make_uint4(fh0.u.x, fh0.u.y, fh1.u.x, fh1.u.y);
+                    xt4[o4 + 2 * XT] = make_uint4(fl0.u.x, fl0.u.y, fl1.u.x, fl1.u.y);
                 }
             }
         }
@@ -318,7 +323,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float bv = bias2[32 * (MI * wm + mi) + (r & 3) + 8 * (r >> 2) + 4 * hi] * s2;
+                    const float bv = bias2[32 * (MI * wm + mi) + 16 * hi + r] * s2;
 #pragma unroll
                     for (int t = 0; t < NI; ++t) acc[mi][t][r] = bv;
                 }
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
 #pragma unroll
                     for (int t = 0; t < NI; ++t)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) rv[mi][t][r] = xres_s[(size_t)(32 * mi + (r & 3) + 8 * (r >> 2)) * Ts + qc[t]];
+                        for (int r = 0; r < 16; ++r) rv[mi][t][r] = xres_s[(size_t)(32 * mi + r) * Ts + qc[t]];
                 }
 #pragma unroll
                 for (int t = 0; t < NI; ++t) acc[mi][t] = acc[mi][t] * i2 + rv[mi][t];
@@ -385,7 +390,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
 #pragma unroll
                     for (int t = 0; t < NI; ++t)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) rv[mi][t][r] = yr_s[(size_t)(32 * mi + (r & 3) + 8 * (r >> 2)) * Ts + qc[t]];
+                        for (int r = 0; r < 16; ++r) rv[mi][t][r] = yr_s[(size_t)(32 * mi + r) * Ts + qc[t]];
 #pragma unroll
                     for (int t = 0; t < NI; ++t) acc[mi][t] += rv[mi][t];
                     if (mode == 2) {
@@ -399,7 +404,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
                 for (int t = 0; t < NI; ++t)
                     if (okc[t]) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) yr_s[(size_t)(32 * mi + (r & 3) + 8 * (r >> 2)) * Ts + qc[t]] = acc[mi][t][r];
+                        for (int r = 0; r < 16; ++r) yr_s[(size_t)(32 * mi + r) * Ts + qc[t]] = acc[mi][t][r];
                     }
             }
         }

@@ -26,6 +26,14 @@
 // add and divide) is that of pair_f16x3.hip / conv_f16x3.hip, so the result is bit-identical to three fused pairs for
 // every tiling (tests/test_gpu_resblock.py).
 //
+// Round 4: PERMUTED A ROWS.  In the MFMA C layout a lane holds rows 8 a + 4 hi + j (a, j < 4) of its column: four 4-channel
+// groups 8 apart, so the seam wrote 8-B halves of a 16-B octet at a 16-B lane stride -- SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS
+// 61-90 % at C = 32 (profiles/r3_sq_counters_in_forward.txt).  Which weight row an A-fragment lane fetches is only an address:
+// lane (l & 31) = 8 a + 4 b + j now fetches the packed fragment of row 16 b + 4 a + j, and the lane's sixteen accumulators are the
+// sixteen CONSECUTIVE channels 32 wm + 16 hi + r of its column = one 16-channel chunk = two whole octets: the seam is two
+// conflict-free ds_write_b128 per plane instead of four ds_write_b64, with no instruction added anywhere (every output element is
+// the same dot product, computed in another row of the tile: same bits).
+//
 // Compiled once per tap count:  -DAMP_KT=<3|5|7|11>.
 #include "amp_internal.h"
 
@@ -99,20 +107,23 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void rb_f16x3_kernel(const RbArgs 
         qok[t] = (q >= 0) && (q < Tv);
         qcl[t] = q < 0 ? 0 : (q < T ? q : T - 1);
     }
-    const float* xr = a.x + (size_t)item * C * T + (size_t)(32 * wm + 4 * hi) * T;
+    // this lane's rows: channels 32 * wm + 16 * hi + r (permuted A rows, see the header)
+    const float* xr = a.x + (size_t)item * C * T + (size_t)(32 * wm + 16 * hi) * T;
     f32x16 rv[NI];                            // x (then x + pair_0(x), ...) of this lane's rows / columns: the residual
 #pragma unroll
     for (int t = 0; t < NI; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) rv[t][r] = xr[(size_t)((r & 3) + 8 * (r >> 2)) * T + qcl[t]];
+        for (int r = 0; r < 16; ++r) rv[t][r] = xr[(size_t)r * T + qcl[t]];
 
     // A fragments [mb][chunk][tap][plane][lane] x uint4 (conv_build): one register set, re-loaded one chunk ahead; the reload
     // during a conv's last chunk fetches the next conv's first chunk
     constexpr size_t MBS = (size_t)NCH * (KT * 128);
     constexpr int NA = RING > 0 ? RING : KT;  // A-fragment register sets
     FragR a_h[NA], a_l[NA];
+    // the packed fragment this lane fetches: A row (lane & 31) = 8 a + 4 b + j holds weight row 16 b + 4 a + j
+    const int wlane = (lane & 32) | (16 * ((lane >> 2) & 1) + 4 * ((lane >> 3) & 3) + (lane & 3));
     {
-        const uint4* w0 = static_cast<const uint4*>(a.wp1[0]) + (size_t)wm * MBS + lane;
+        const uint4* w0 = static_cast<const uint4*>(a.wp1[0]) + (size_t)wm * MBS + wlane;
 #pragma unroll
         for (int g = 0; g < NA; ++g) {
             a_h[g].u = w0[g * 128];
@@ -122,7 +133,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void rb_f16x3_kernel(const RbArgs 
     AMP_PIN_VMEM();
 
     float range_max = 0.f;       // largest |staged operand| (x16 applied): beyond 65504 it left the f16 range (a.range_flag)
-    uint2* const lds2 = reinterpret_cast<uint2*>(smem4);
     const float kpos = 16.f, kneg = 16.f * a.slope;
     // x (registers) -> lrelu, the conv's zero padding, x16, hi / lo -> the LDS tile; what stage_store of pair_f16x3.hip does
     auto stage_x = [&]() __attribute__((always_inline)) {
@@ -130,15 +140,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void rb_f16x3_kernel(const RbArgs 
         for (int t = 0; t < NI; ++t) {
             const int col = RB_G + colw + 32 * t;
             const bool ok = qok[t];
+            // channels 32 * wm + 16 * hi + r  ->  chunk 2 * wm + hi, octet r >> 3: two whole 16-B units per plane
+            const int o4 = (2 * wm + hi) * CHS + col;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                struct { uint2 u; } fh, fl;
-                stage4_f16(ok ? rv[t][4 * j + 0] : 0.f, ok ? rv[t][4 * j + 1] : 0.f, ok ? rv[t][4 * j + 2] : 0.f,
-                           ok ? rv[t][4 * j + 3] : 0.f, kpos, kneg, range_max, fh.u, fl.u);
-                // channels 32*wm + 8*j + 4*hi + i  ->  chunk 2*wm + (j >> 1), octet j & 1, half hi
-                const int o4 = (2 * wm + (j >> 1)) * CHS + (j & 1) * WL + col;
-                lds2[(o4 << 1) + hi] = fh.u;
-                lds2[((o4 + 2 * WL) << 1) + hi] = fl.u;
+            for (int o = 0; o < 2; ++o) {
+                struct { uint2 u; } fh0, fl0, fh1, fl1;
+                stage4_f16(ok ? rv[t][8 * o + 0] : 0.f, ok ? rv[t][8 * o + 1] : 0.f, ok ? rv[t][8 * o + 2] : 0.f,
+                           ok ? rv[t][8 * o + 3] : 0.f, kpos, kneg, range_max, fh0.u, fl0.u);
+                stage4_f16(ok ? rv[t][8 * o + 4] : 0.f, ok ? rv[t][8 * o + 5] : 0.f, ok ? rv[t][8 * o + 6] : 0.f,
+                           ok ? rv[t][8 * o + 7] : 0.f, kpos, kneg, range_max, fh1.u, fl1.u);
+                smem4[o4 + o * WL] = make_uint4(fh0.u.x, fh0.u.y, fh1.u.x, fh1.u.y);
+                smem4[o4 + o * WL + 2 * WL] = make_uint4(fl0.u.x, fl0.u.y, fl1.u.x, fl1.u.y);
             }
         }
     };
@@ -148,12 +160,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void rb_f16x3_kernel(const RbArgs 
     auto conv = [&](const void* wp, const float* bias, float sc, int d, const void* wp_next) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float bv = bias[32 * wm + (r & 3) + 8 * (r >> 2) + 4 * hi] * sc;
+            const float bv = bias[32 * wm + 16 * hi + r] * sc;
 #pragma unroll
             for (int t = 0; t < NI; ++t) acc[t][r] = bv;
         }
-        const uint4* wa = static_cast<const uint4*>(wp) + (size_t)wm * MBS + lane;
-        const uint4* wn0 = static_cast<const uint4*>(wp_next) + (size_t)wm * MBS + lane;
+        const uint4* wa = static_cast<const uint4*>(wp) + (size_t)wm * MBS + wlane;
+        const uint4* wn0 = static_cast<const uint4*>(wp_next) + (size_t)wm * MBS + wlane;
         const int rd = hi * WL + RB_G + colw - H2 * d;
 #pragma unroll 1
         for (int c = 0; c < NCH; ++c) {
@@ -213,14 +225,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void rb_f16x3_kernel(const RbArgs 
                 const float slope = a.slope;
 #pragma unroll
                 for (int t = 0; t < NI; ++t) {
-                    const int col = RB_G + colw + 32 * t;
+                    const int o4 = (2 * wm + hi) * CHS + RB_G + colw + 32 * t;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        struct { uint2 u; } fh, fl;
-                        seam4_f16(acc[t][4 * j + 0], acc[t][4 * j + 1], acc[t][4 * j + 2], acc[t][4 * j + 3], i1, slope, qok[t], range_max, fh.u, fl.u);
-                        const int o4 = (2 * wm + (j >> 1)) * CHS + (j & 1) * WL + col;
-                        lds2[(o4 << 1) + hi] = fh.u;
-                        lds2[((o4 + 2 * WL) << 1) + hi] = fl.u;
+                    for (int o = 0; o < 2; ++o) {
+                        struct { uint2 u; } fh0, fl0, fh1, fl1;
+                        seam4_f16(acc[t][8 * o + 0], acc[t][8 * o + 1], acc[t][8 * o + 2], acc[t][8 * o + 3], i1, slope, qok[t], range_max, fh0.u, fl0.u);
+                        seam4_f16(acc[t][8 * o + 4], acc[t][8 * o + 5], acc[t][8 * o + 6], acc[t][8 * o + 7], i1, slope, qok[t], range_max, fh1.u, fl1.u);
+                        smem4[o4 + o * WL] = make_uint4(fh0.u.x, fh0.u.y, fh1.u.x, fh1.u.y);
+                        smem4[o4 + o * WL + 2 * WL] = make_uint4(fl0.u.x, fl0.u.y, fl1.u.x, fl1.u.y);
                     }
                 }
             }
@@ -245,12 +257,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void rb_f16x3_kernel(const RbArgs 
     // ---------------- epilogue: MRF accumulate, store the NT output columns of the tile ----------------
     {
         const int mode = a.mode;
-        float* yr = a.y + (size_t)item * C * T + (size_t)(32 * wm + 4 * hi) * T;
+        float* yr = a.y + (size_t)item * C * T + (size_t)(32 * wm + 16 * hi) * T;
         if (mode != 0) {   // workgroup-uniform
 #pragma unroll
             for (int t = 0; t < NI; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][r] = yr[(size_t)((r & 3) + 8 * (r >> 2)) * T + qcl[t]];
+                for (int r = 0; r < 16; ++r) acc[t][r] = yr[(size_t)r * T + qcl[t]];
 #pragma unroll
             for (int t = 0; t < NI; ++t) rv[t] += acc[t];
             if (mode == 2) {
@@ -266,7 +278,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void rb_f16x3_kernel(const RbArgs 
             const int q = q0 + col;
             if (col >= RH && col < W - RH && q < T) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) yr[(size_t)((r & 3) + 8 * (r >> 2)) * T + qcl[t]] = rv[t][r];
+                for (int r = 0; r < 16; ++r) yr[(size_t)r * T + qcl[t]] = rv[t][r];
             }
         }
     }
