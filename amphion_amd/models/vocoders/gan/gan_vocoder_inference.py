@@ -6,6 +6,9 @@ arithmetic, but runs each padded batch through the generator ONCE instead of one
 ``ragged=True`` it instead vocodes every utterance as if alone, in length-sorted true batches
 (``forward_ragged``: the kernels pad every layer at each utterance's own end).
 """
+import threading
+import weakref
+
 import torch
 
 from amphion_amd import _lib
@@ -25,20 +28,26 @@ def _reference_range(model, run, device):
     return out
 
 
+_staging = weakref.WeakKeyDictionary()      # model -> grow-only pinned host buffer
+_staging_lock = threading.Lock()
+
+
 def _crops_to_host(model, out, lengths):
     """``[out[i, :lengths[i]] for i]`` as host tensors.  ``out`` [B, L] (device) goes to the host in ONE DMA into a pinned
     staging buffer kept on the model (grow-only) and the kept samples are cut out of it -- instead of ``out.cpu()``: a fresh
     pageable [B, L] tensor per call (26 MB for 64 utterances: mmap + first-touch page faults + a bounce-buffered copy, 3-4 ms
     against 0.5 ms for the pinned DMA) of which the padding is then thrown away."""
     n = out.numel()
-    buf = getattr(model, "_amp_host_staging", None)
-    if buf is None or buf.numel() < n or buf.dtype != out.dtype:
-        buf = torch.empty(n, dtype=out.dtype, pin_memory=True)
-        model._amp_host_staging = buf
-    host = buf[:n].view(out.shape)
-    host.copy_(out, non_blocking=True)
-    torch.cuda.current_stream(out.device).synchronize()
-    return [host[i, : int(l)].clone() for i, l in enumerate(lengths)]
+    # (the buffer lives in a weak-keyed side table, not on the module: it must not travel with torch.save(model) / deepcopy, and two
+    #  threads serving one model take turns on it)
+    with _staging_lock:
+        buf = _staging.get(model)
+        if buf is None or buf.numel() < n or buf.dtype != out.dtype:
+            buf = _staging[model] = torch.empty(n, dtype=out.dtype, pin_memory=True)
+        host = buf[:n].view(out.shape)
+        host.copy_(out, non_blocking=True)
+        torch.cuda.current_stream(out.device).synchronize()
+        return [host[i, : int(l)].clone() for i, l in enumerate(lengths)]
 
 
 def vocoder_inference(cfg, model, mels, f0s=None, device=None, fast_inference=False):

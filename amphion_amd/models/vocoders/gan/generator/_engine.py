@@ -107,6 +107,21 @@ def _destroy_handle(ptr):
         pass
 
 
+class _InferenceOnly(torch.autograd.Function):
+    """Identity on the generator's output whose backward raises: see ``HipGenerator._amp_forward``."""
+
+    @staticmethod
+    def forward(ctx, out, witness):
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, grad):
+        raise RuntimeError("amphion_amd generators are inference-only (no backward through the HIP kernels): a gradient was asked for "
+                           "THROUGH the generator -- a training step, or an input that requires grad.  Call under torch.no_grad() / "
+                           ".eval() for inference; build the reference class (module._reference_<Name>, kept by "
+                           "amphion_amd.integration) for training")
+
+
 class HipGenerator(nn.Module):
     """Base of HiFiGAN / HiFiGAN_vits / BigVGAN: owns the ``amp_gen`` handle and the workspace."""
 
@@ -242,20 +257,18 @@ class HipGenerator(nn.Module):
         return h
 
     def _amp_forward(self, x, g=None, lengths=None, workspace=None):
-        # Inference only: the HIP kernels have no backward.  A gradient asked for THROUGH the generator cannot be honoured,
-        # and neither can a training step: a module in training mode, with autograd on and trainable parameters, is what a
-        # GAN trainer calls (the registry / class patch of amphion_amd.integration reaches gan_vocoder_trainer.py and the
-        # VITS trainers too) -- an output without grad_fn would let loss_g.backward() succeed through the discriminator
-        # only and the generator would silently never train.  Fail instead.
+        # Inference only: the HIP kernels have no backward.  The forward itself runs whenever the reference's would -- a module left in
+        # its default training mode and called without torch.no_grad() is an ordinary inference call (round 3 refused it) --
+        # but where autograd would have recorded a graph through the reference generator (an input that requires grad; training mode
+        # with trainable parameters: what a GAN trainer does through the registry / class patch of amphion_amd.integration) the output
+        # carries a grad_fn that RAISES when a backward pass reaches it: loss_g.backward() fails loudly instead of succeeding through
+        # the discriminator only with a generator that silently never trains.
+        guard = None
         if torch.is_grad_enabled() and isinstance(x, torch.Tensor):
             if x.requires_grad:
-                raise RuntimeError("amphion_amd generators are inference-only (no backward through the HIP kernels): "
-                                   "detach the input or call under torch.no_grad()")
-            if self.training and any(p.requires_grad for p in self.parameters()):
-                raise RuntimeError("amphion_amd generators are inference-only: called in training mode with autograd on and "
-                                   "trainable parameters, the output would carry no gradient and the generator would never "
-                                   "train; call .eval() / torch.no_grad() for inference, or build the reference class "
-                                   "(module._reference_<Name>, kept by amphion_amd.integration) for training")
+                guard = x
+            elif self.training:
+                guard = next((p for p in self.parameters() if p.requires_grad), None)
         x = _lib.require_device_tensor(x, "generator input")
         if x.dim() != 3:
             raise ValueError(f"expected [B, C, T] input, got {tuple(x.shape)}")
@@ -296,7 +309,7 @@ class HipGenerator(nn.Module):
             _lib.check(L.amp_gen_forward_ragged(h, ctypes.c_void_p(x.data_ptr()), cond_ptr, lens_ptr, B, T,
                                                 ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
                                                 ws.numel(), _lib.current_stream_ptr(dev)))
-        return out
+        return out if guard is None else _InferenceOnly.apply(out, guard)
 
     def check_range(self):
         """Synchronise and raise ``AmpError`` (``status == _lib.AMP_ERR_RANGE``) if a forward since the last check

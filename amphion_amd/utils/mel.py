@@ -90,6 +90,9 @@ def _window(cfg, device):
 # the slot to pinned memory behind itself; a LATER call (or flush_range_warnings()) prints what has landed.  Per device: a ring of
 # slots, each re-initialised by the kernel of the call before it -- no extra launch, no host synchronisation, no allocation per call
 # (round 2: torch.aminmax + stack + a fresh pinned tensor + copy + event = as much host time as the mel kernel takes on the GPU).
+# One ring per (device, STREAM): "kernel k resets the slot of kernel k + 1" is an ordering argument that only holds along one stream.
+# A call that fails after taking its slot re-initialises both slots itself (_range_abort); inside a stream capture the notice is
+# skipped altogether (the ring's bookkeeping is host state a replay would not repeat, and a full ring would have to synchronise).
 _RANGE_SLOTS = 64
 _INIT = (int(np.float32(-1.0).view(np.int32)), int(np.float32(1.0).view(np.int32)), 0, 0)
 _range_rings = {}
@@ -104,6 +107,15 @@ class _RangeRing:
         self.seq = 0                       # calls issued
         self.done = 0                      # calls whose slot has been looked at
         self.stream_dev = device
+
+    def abort(self, seq):
+        """call `seq` took its slot and then raised before (or instead of) launching: nobody reset the next slot, and its own may
+        hold a partial fold -- re-initialise both on the current stream and stop waiting for its copy"""
+        init = torch.tensor(_INIT, dtype=torch.int32)
+        for k in (seq, seq + 1):
+            self.dev[k % _RANGE_SLOTS].copy_(init, non_blocking=False)
+        row = self.host_np[seq % _RANGE_SLOTS]
+        row[0], row[1], row[2] = _INIT[0], _INIT[1], seq & 0x7FFFFFFF      # "landed, nothing seen"
 
     def next(self):
         """(range_dev, range_host, range_reset_dev, seq) for the next call."""
@@ -133,12 +145,25 @@ class _RangeRing:
                 print("max value is ", mx)
 
 
+def _ring_key(device):
+    return (device, torch.cuda.current_stream(device).cuda_stream)
+
+
 def _range_slot(device):
-    ring = _range_rings.get(device)
+    if torch.cuda.is_current_stream_capturing():
+        return None, None, None, 0                  # no notice from inside a capture (see above)
+    key = _ring_key(device)
+    ring = _range_rings.get(key)
     if ring is None:
-        ring = _range_rings[device] = _RangeRing(device)
+        ring = _range_rings[key] = _RangeRing(device)
     ring.flush(block=False)
     return ring.next()
+
+
+def _range_abort(device, seq):
+    ring = _range_rings.get(_ring_key(device))
+    if ring is not None and seq:
+        ring.abort(seq)
 
 
 def _range_warning(y):
@@ -189,8 +214,10 @@ def _run(y, cfg, *, n_mel, pad_mode, mag_eps, log_clip, want=("mel",), basis=Non
     bands = mel_bands.get(basis.data_ptr()) if basis is not None else None       # (basis kept alive, bands) of a cached basis
     d = _lib.amp_mel_desc(cfg.n_fft, cfg.win_size, cfg.hop_size, n_mel, pad_mode, mag_eps, log_clip,
                           bands[1].data_ptr() if bands is not None and bands[0] is basis else None)
+    seq_taken = 0
     if report_range:
         d.range_dev, d.range_host, d.range_reset_dev, d.range_seq = _range_slot(y.device)
+        seq_taken = d.range_seq
     L = _lib.lib()
     F = L.amp_mel_num_frames(ctypes.byref(d), Lh)
     bins = cfg.n_fft // 2 + 1
@@ -210,9 +237,13 @@ def _run(y, cfg, *, n_mel, pad_mode, mag_eps, log_clip, want=("mel",), basis=Non
         for t in outs.values():
             t.zero_()                      # frames beyond an utterance's own count are not written by the kernel
     with torch.cuda.device(dev):
-        _lib.check(L.amp_mel_forward_ragged(ctypes.byref(d), ptr(y), ptr(lens), B, Lh, ptr(window), ptr(basis),
-                                            ptr(outs.get("mel")), ptr(outs.get("mag")), ptr(outs.get("re")),
-                                            ptr(outs.get("im")), _lib.current_stream_ptr(dev)))
+        try:
+            _lib.check(L.amp_mel_forward_ragged(ctypes.byref(d), ptr(y), ptr(lens), B, Lh, ptr(window), ptr(basis),
+                                                ptr(outs.get("mel")), ptr(outs.get("mag")), ptr(outs.get("re")),
+                                                ptr(outs.get("im")), _lib.current_stream_ptr(dev)))
+        except Exception:
+            _range_abort(dev, seq_taken)           # the slot this call took never got its kernel
+            raise
     return outs
 
 
@@ -264,8 +295,12 @@ def _logmel_fast(y, cfg, mag_eps):
         y = y.contiguous().float()
     out = torch.empty((B, cfg.n_mel, F), device=dev)
     with torch.cuda.device(dev):
-        _lib.check(_lib.lib().amp_mel_forward_ragged(ctypes.byref(d), y.data_ptr(), None, B, Lh, p.window.data_ptr(), p.basis.data_ptr(),
-                                                     out.data_ptr(), None, None, None, _lib.current_stream_ptr(dev)))
+        try:
+            _lib.check(_lib.lib().amp_mel_forward_ragged(ctypes.byref(d), y.data_ptr(), None, B, Lh, p.window.data_ptr(), p.basis.data_ptr(),
+                                                         out.data_ptr(), None, None, None, _lib.current_stream_ptr(dev)))
+        except Exception:
+            _range_abort(dev, d.range_seq)
+            raise
     return out
 
 

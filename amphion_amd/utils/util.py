@@ -33,6 +33,9 @@ class few_host_threads:
     def __init__(self, n=4):
         self.n = max(1, min(n, _cpu_budget() // 4 or 1))
 
+    # torch.set_num_threads is omp_set_num_threads: the nthreads ICV of the CALLING thread, not process-wide state -- another thread's
+    # setting is neither changed nor observed by this scope (tests/test_host_logic.py checks that), so enter / exit only have to save
+    # and restore the caller's own value, nesting included.
     def __enter__(self):
         self.prev = torch.get_num_threads()
         if self.prev > self.n:

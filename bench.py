@@ -141,6 +141,43 @@ def library_baseline(sd, hp, device, reps=3):
                       f"({first:.1f} s: MIOpen solver search)", "torch": torch.__version__}
 
 
+def strict_fp32(device, steps=5):
+    """The same workload with the conv contractions in exact fp32 (v_mfma_f32_32x32x2_f32, amp_set_precision(AMP_PRECISION_F32)):
+    the no-emulation number, in the driver's own line.  Its peak is the fp32 MFMA peak (157.3 TFLOP/s)."""
+    from amphion_amd import _lib
+    from amphion_amd.utils.synthetic import synthetic_mel
+
+    _lib.set_precision("f32")
+    try:
+        model, _, hp = build_model(device)
+        mel = synthetic_mel(B_PER_GPU, N_MEL, T_FRAMES, seed=0).to(device)
+        with torch.no_grad():
+            for _ in range(2):
+                model(mel)
+            torch.cuda.synchronize()
+            model.set_profiling(steps)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                model(mel)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+        dom = sum(model.last_timing_ms(100 + 16 * 1 + 2, b) for b in range(steps)) / steps / 6.0     # six unfused k = 11 convs at C = 128
+        names = sorted({n for b in range(steps) for n in model.kernel_names(100 + 16 * 1 + 2, b)})
+        model.set_profiling(0)
+        n = B_PER_GPU * T_FRAMES * model.hop_factor
+        C1, T1 = hp["upsample_initial_channel"] // 4, T_FRAMES * hp["upsample_rates"][0] * hp["upsample_rates"][1]
+        dom_tf = 2.0 * C1 * C1 * 11 * B_PER_GPU * T1 / (dom * 1e-3) / 1e12
+        ms = el / steps * 1e3
+        return {"ms_per_step": ms, "steps": steps, "samples_per_s": n / ms * 1e3, "x_realtime": n / ms * 1e3 / SAMPLE_RATE,
+                "whole_forward_tflops": FLOP_PER_SAMPLE_ALL * n / (ms * 1e-3) / 1e12,
+                "frac_of_fp32_peak": FLOP_PER_SAMPLE_ALL * n / (ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+                "dominant_conv": {"kernel": " | ".join(names), "launch_us": dom * 1e3, "tflops": dom_tf, "frac_of_fp32_peak": dom_tf / PEAK_FP32_TFLOPS},
+                "dtype": "f32 operands, f32 MFMA, f32 accumulate (no split-f16 emulation)"}
+    finally:
+        _lib.set_precision("f16x3")
+        torch.cuda.empty_cache()
+
+
 def conv_flop_per_frame(convs):
     """sum of 2 * Cin * Cout * k * (outputs per mel frame) over (cin, cout, k, outputs_per_frame) tuples"""
     return sum(2.0 * ci * co * k * m for ci, co, k, m in convs)
@@ -170,8 +207,9 @@ def other_configs(reps=5):
                   "frac_of_hbm_peak": (act_bytes + conv_bytes) / r["ms_per_step"] / 1e6 / PEAK_HBM_GBS,
                   "roofline_floor_ms": {"convs_at_f16x3_mfma_peak": flop / (PEAK_F16_TFLOPS / 3.0) / 1e9,
                                         "activations_at_hbm_peak": act_bytes / PEAK_HBM_GBS / 1e6},
-                  "note": "73 act1d launches are ~1/3 of the step (8.9 ms at 3-3.6 TB/s, profiles/r2_uv_act1d.txt); the convs run "
-                          "unfused around them (an AMPBlock has an activation between its two convs)"})
+                  "launches_per_forward": bc.c3_launch_counts(),
+                  "note": "round 4: the AMPBlocks of the C = 32 stage (and k = 3 at C = 64) run as ONE launch each (csrc/ampb_f16x3.hip); the "
+                          "C >= 128 stages keep separate conv / act1d launches"})
         out["c3_bigvgan"] = r
         torch.cuda.empty_cache()
         # C5 VITS decode path B=16: enc_q (513 -> 192, WN 16 x k5) + flow both ways (4 couplings x WN 4 x k5, twice) + decoder
@@ -192,10 +230,50 @@ def other_configs(reps=5):
         r = bc.mel(max(reps, 10))[0]
         r.update({"algorithmic_bytes": 64 * 65536 * 4 + 64 * 80 * 256 * 4, "frac_of_hbm_peak": r["algorithmic_GBps"] / PEAK_HBM_GBS})
         out["mel_front_end"] = r
-        out["latency"] = [x for x in bc.lat(reps) if "hipGraph" not in x["config"]]
+        out["mel_front_end_large"] = bc.mel_large(reps)[0]     # 1 024 x 65 536 samples: the dataset-extraction regime
+        torch.cuda.empty_cache()
+        out["c1_clips"] = bc.c1(reps)[0]                        # BASELINE configs[0]: the 16 real clips end to end, batch_size = 1
+        out["latency"] = bc.lat(reps)                           # eager and hipGraph replay (what the drop-in entry points use for repeats)
         out["list_api"] = bc.lst(reps)          # synthesis_audios on 64 utterances of 60..400 frames, host to host
         torch.cuda.empty_cache()
     return out
+
+
+def multi_gpu_diagnostics(model, mel, total_items, device, per_rank_ms, reps=5):
+    """N > 1 only, after the timed region (collective calls: every rank runs this).  What a first 8-GPU run needs to be read:
+    per-rank step times, the generator alone (no gather), the fp32 gather alone (nothing to overlap with) and the same gather with
+    16-bit PCM rows (amp_wav_to_pcm16 on the device first: half the bytes on every xGMI link)."""
+    from amphion_amd.distributed import gather_audio
+    from amphion_amd.utils.io import wav_to_pcm16
+
+    def timed_ms(fn):
+        dist.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        t = torch.tensor([e0.elapsed_time(e1) / reps], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    with torch.no_grad():
+        wav = model(mel).squeeze(1)
+        pcm = wav_to_pcm16(wav)
+        compute_ms = timed_ms(lambda: model(mel))
+        gather_ms = timed_ms(lambda: gather_audio(wav, total_items, dst=0))
+        gather_pcm_ms = timed_ms(lambda: gather_audio(pcm, total_items, dst=0))
+        pcm_convert_ms = timed_ms(lambda: wav_to_pcm16(wav))
+    step_ms = max(per_rank_ms)
+    nbytes = wav.numel() * 4
+    return {"per_rank_ms": [round(v, 3) for v in per_rank_ms], "per_rank_ms_min": min(per_rank_ms), "per_rank_ms_max": step_ms,
+            "compute_only_ms": compute_ms, "gather_ms": gather_ms, "gather_ms_overlapped": max(0.0, step_ms - compute_ms),
+            "gather_ms_pcm16": gather_pcm_ms, "pcm16_convert_ms": pcm_convert_ms,
+            "gather_bytes_per_rank": nbytes, "gather_GBps_per_link": nbytes / gather_ms / 1e6,
+            "gather_note": "gather_ms: the fp32 gather alone, stream idle otherwise (max over ranks); gather_ms_overlapped: what it adds to a step "
+                           "when issued asynchronously behind the next batch's forward (step - compute_only); gather_ms_pcm16: int16 rows"}
 
 
 def free_port():
@@ -302,10 +380,14 @@ def main():
         out = step()
     fence()
     elapsed = time.perf_counter() - t0
+    multi = None
     if world > 1:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = tmax.item()
+        mine = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
+        elapsed = max(float(t.item()) for t in every)
+        multi = multi_gpu_diagnostics(model, mel, total_items, device, per_rank_ms)
     fwd_ms, mrf_ms, stage_ms, dom_ms = [], [], [], []
     for back in range(args.steps):
         fwd_ms.append(model.last_timing_ms(0, back))
@@ -405,16 +487,21 @@ def main():
             },
             "roofline": roofline,
             "parity_note": "this exact shape is under tests/test_gpu_full_size.py (-m gpu): items 0 / 31 / 63 of the batch equal "
-                           "that item vocoded alone bit for bit, a batch equals its halves, the CPU oracle agrees on items 0 and 63 "
+                           "that item vocoded alone bit for bit, a batch equals its halves, the CPU oracle agrees on items 0, 21, 42 and 63 "
                            "within 1e-4 (measured 3e-6); the oracle is not run on all 64 items (30 s per batch on the host)",
         }
         if gather_check:
             result["gather_check"] = gather_check
+        if multi:
+            result.update(multi)
         if not args.no_cpu_baseline and world == 1:
             del out
             # the side legs must never cost the headline line: a failure is reported in place of the figure
-            for key, leg in (("other_configs", other_configs), ("library_baseline", lambda: library_baseline(sd, hp, device)),
-                             ("cpu_baseline", lambda: cpu_baseline(sd, hp))):
+            legs = [("other_configs", other_configs), ("library_baseline", lambda: library_baseline(sd, hp, device)),
+                    ("cpu_baseline", lambda: cpu_baseline(sd, hp))]
+            if args.precision == "f16x3":
+                legs.insert(0, ("strict_fp32", lambda: strict_fp32(device)))
+            for key, leg in legs:
                 try:
                     result[key] = leg()
                 except Exception as e:  # noqa: BLE001

@@ -295,7 +295,8 @@ int amp_pair_forward(const amp_conv* c1, const amp_conv* c2, const float* x_dev,
 /* ResBlock1.forward (hifigan.py:93-100) in ONE launch:  for p < n_pairs:  x = x + c2[p](lrelu(c1[p](lrelu(x)))), on the
  * whole-resblock kernel (csrc/rb_f16x3.hip: x read once, y written once, the residual carried in registers).  Handles from
  * amp_conv_create as for amp_pair_forward (same C and k for all pairs, c1[p] dilated, c2[p] dilation 1, 'same' padding);
- * covered: C in {32, 64}, k in {3, 5, 7}, n_pairs <= 3, f16x3 arithmetic, under the shapes the current
+ * covered: C in {32, 64} with k in {3, 5, 7, 11}, C = 128 with k in {3, 5}, (k-1)/2 * dilation within the tile's guard columns (32;
+ * 16 at C = 128), n_pairs <= 3, f16x3 arithmetic, under the shapes the current
  * amp_set_resblock_fusion mode admits -- otherwise AMP_ERR_UNSUPPORTED (run amp_pair_forward n_pairs times: the same bits).
  * y_dev must not alias x_dev. */
 int amp_resblock_forward(const amp_conv* const* c1, const amp_conv* const* c2, int n_pairs, const float* x_dev, int B, int T,
@@ -329,7 +330,7 @@ void amp_conv_destroy(amp_conv* c);
 
 /* Frame-rate convs (short contraction, small grid: the convs around the VITS decoder) run on a kernel that stages the
  * whole K extent of its input tile at once (csrc/conv_small_f16x3.hip; same bits as the pipelined kernel).  0 keeps
- * them on the pipelined kernel -- an A/B and cross-check switch, also AMP_SMALL_CONV=0 in the environment. */
+ * them on the pipelined kernel -- an A/B and cross-check switch (no environment form since round 3). */
 int amp_set_small_conv(int on);
 
 /* Transposed convs and k = 3 / 7 / 11 convs whose GEMM rows are a multiple of 256 (ConvTranspose1d: Cout * stride) run, on grids
@@ -341,11 +342,11 @@ int amp_set_conv_blk(int mode);
 
 /* Convs with several row groups (more GEMM rows than one workgroup holds) launch with the row group as the fastest grid
  * index: the row groups of one x tile run back to back on one XCD and share its L2 copy of x (same bits; 1 = default).
- * 0 = the 2-D grid with the row group in blockIdx.y, -1 = back to AMP_CONV_RG_FAST / the default -- an A/B switch. */
+ * 0 = the 2-D grid with the row group in blockIdx.y, -1 = back to the default (on) -- an A/B switch. */
 int amp_set_conv_rg_fast(int on);
 
 /* Ping-pong tile order: every other conv / fused-pair launch walks its tiles in descending order, starting on the part of its
- * input that the previous launch wrote last (same bits).  -1 = back to AMP_PINGPONG / the default -- an A/B switch. */
+ * input that the previous launch wrote last (same bits).  -1 = back to the default (on) -- an A/B switch. */
 int amp_set_pingpong(int on);
 
 /* ---- WN (modules/flow/modules.py:74-151), fused: two launches per layer ---- */
@@ -411,7 +412,7 @@ int amp_antialias_snake(const float* x_dev, int B, int C, int T, const float* al
  * padding and a bias, k in {3, 5, 7, 11}, cout a multiple of 32, and a launch of at least 384 full-width tiles; anything
  * else returns AMP_ERR_UNSUPPORTED (run the two ops).  Parameters as in amp_antialias_snake (op-level convenience:
  * synchronises).  Measured slower than the two launches on MI355X, so amp_gen_forward uses it only after
- * amp_set_fuse_act(1) / AMP_FUSE_ACT=1 (A/B and cross-check switch). */
+ * amp_set_fuse_act(1) (A/B and cross-check switch; round 4's whole-AMPBlock kernel, amp_ampblock_forward, is the form that pays). */
 int amp_conv_act_forward(const amp_conv* c, const float* x_dev, int B, int T, const float* alpha_dev, const float* beta_dev,
                          int logscale, const float* filt_up_host, const float* filt_down_host, float* y_dev, void* stream);
 int amp_set_fuse_act(int on);

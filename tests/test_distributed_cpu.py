@@ -100,3 +100,27 @@ def test_two_rank_shard_and_gather(n_items):
     ranks = q.get(timeout=10)
     s0 = shard_bounds(n_items, 2, 0)
     assert ranks == [0.0] * (s0[1] - s0[0]) + [1.0] * (n_items - (s0[1] - s0[0]))
+
+
+def test_eight_rank_ragged_tail_b509():
+    """BASELINE configs[3]'s world size with a batch that does not divide: B = 509 over 8 ranks (five shards of 64, three of 63) --
+    sharded forward + gather equals the single-process result bit for bit, and the PCM rows arrive in rank order."""
+    n_items, world = 509, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_items, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    assert q.get(timeout=20) is True
+    ranks = q.get(timeout=20)
+    want = []
+    for r in range(world):
+        s, e = shard_bounds(n_items, world, r)
+        want += [float(r)] * (e - s)
+    assert ranks == want
+    sizes = [shard_bounds(n_items, world, r)[1] - shard_bounds(n_items, world, r)[0] for r in range(world)]
+    assert sizes == [64] * 5 + [63] * 3

@@ -272,9 +272,10 @@ def test_load_audio_torch_and_save_feature(tmp_path):
 
 
 def test_generator_is_inference_only():
-    # no backward through the HIP kernels: an input that asks for a gradient is refused, and so is a training step (training
-    # mode + autograd + trainable parameters: what a GAN trainer does through the integration patch -- the generator would
-    # silently never train); a CPU tensor is refused either way (no fallback)
+    # no backward through the HIP kernels.  The forward runs whenever the reference's would (a CPU tensor is refused either way: no
+    # fallback); what fails is a BACKWARD through the generator -- the output of a call autograd would have recorded (input requires
+    # grad; training mode + trainable parameters: a GAN trainer through the integration patch) carries a grad_fn that raises
+    # (tests/test_gpu_generator.py::test_backward_through_the_generator_raises runs that on the GPU)
     import warnings
     from types import SimpleNamespace as NS
 
@@ -286,10 +287,16 @@ def test_generator_is_inference_only():
     hp = dict(resblock="1", upsample_rates=[2, 2], upsample_kernel_sizes=[4, 4], upsample_initial_channel=32,
               resblock_kernel_sizes=[3], resblock_dilation_sizes=[[1, 3, 5]])
     m = HiFiGAN(NS(preprocess=NS(n_mel=8), model=NS(hifigan=NS(**hp))))
-    with pytest.raises(RuntimeError, match="inference-only"):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.zeros(1, 8, 4, requires_grad=True))
-    with pytest.raises(RuntimeError, match="training mode"):
-        m(torch.zeros(1, 8, 4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 8, 4))                             # default training mode, autograd on: an ordinary (CPU: refused) call
+    from amphion_amd.models.vocoders.gan.generator._engine import _InferenceOnly
+    w = torch.ones(3, requires_grad=True)
+    y = _InferenceOnly.apply(torch.zeros(2, 3), w)
+    assert y.requires_grad
+    with pytest.raises(RuntimeError, match="inference-only"):
+        y.sum().backward()
     with warnings.catch_warnings():
         warnings.simplefilter("error")                      # under no_grad, frozen, or in eval: nothing to say
         with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU fallback"):
@@ -324,7 +331,10 @@ def test_bench_relaunch_command_and_cli_guards():
 def test_few_host_threads_scope_and_cpu_budget():
     """The list / batch entry points cap torch's intra-op threads while they pad and crop on the host (a 128-thread OpenMP pool
     under a 16-CPU cgroup quota got the whole process throttled: profiles/r3_o_list_api_cgroup_throttle.txt) and restore the
-    setting afterwards, also when the body raises."""
+    setting afterwards, also when the body raises or scopes nest.  The setting is the calling thread's own (omp_set_num_threads):
+    a scope open in one thread is not visible in another (code health 12)."""
+    import threading
+
     import torch
 
     from amphion_amd.utils.util import _cpu_budget, few_host_threads
@@ -334,7 +344,16 @@ def test_few_host_threads_scope_and_cpu_budget():
     with few_host_threads(4) as scope:
         assert torch.get_num_threads() <= max(1, min(4, before))
         assert 1 <= scope.n <= 4
+        inner_seen = torch.get_num_threads()
+        with few_host_threads(2):
+            assert torch.get_num_threads() <= inner_seen
+        assert torch.get_num_threads() == inner_seen
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(torch.get_num_threads()))
+        t.start()
+        t.join(10)
     assert torch.get_num_threads() == before
+    assert seen and seen[0] >= inner_seen                 # the other thread kept its own (default) pool size
     try:
         with few_host_threads(2):
             raise KeyError("boom")

@@ -1,9 +1,10 @@
 #!/usr/bin/env python
 """Throughput of the other BASELINE.json configs on one MI355X (reported in DESIGN.md; bench.py stays the
 configs[1] headline):  c3 BigVGAN-base 24 kHz B=32,  c5 VITS enc_q -> flow -> flow^-1 -> dec B=16,  mel = the
-front end at B=64 x 65 536 samples,  list = the list API on ragged utterances,  lat = single-utterance latency.
+front end at B=64 x 65 536 samples (mel_large: 1 024 x 65 536),  list = the list API on ragged utterances,  lat = single-utterance
+latency,  c1 = the 16 real clips of configs[0] end to end.
 
-    python tools/bench_configs.py [--reps 5] [--only c3|c5|mel|pcm|list|lat]
+    python tools/bench_configs.py [--reps 5] [--only c1|c3|c5|vits|mel|mel_large|pcm|list|lat]
 Product path only (amphion_amd modules + seeded random-init weights); one JSON line per config."""
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -42,6 +43,21 @@ def c3(reps):
     ms = timed(lambda: m(mel), reps)
     n = 32 * 256 * 256
     return [{"config": "C3 BigVGAN-base 24 kHz, B=32 x 100 mel x 256 frames", "ms_per_step": ms, "samples_per_s": n / ms * 1e3, "x_realtime": n / ms * 1e3 / 24000}]
+
+
+def c3_launch_counts():
+    """kernel launches of ONE C3 forward by family, from the handle's own launch log (amp_gen_kernel_name over every resblock)"""
+    from amphion_amd.models.vocoders.gan.generator.bigvgan import BigVGAN
+    hp = dict(V1, activation="snakebeta", snake_logscale=True)
+    m = randomize_(BigVGAN(NS(preprocess=NS(n_mel=100, hop_size=256), model=NS(bigvgan=NS(**hp)))), 1234, g_gain=0.75).to(DEV).eval()
+    mel = torch.randn(32, 100, 256, generator=torch.Generator().manual_seed(0)).to(DEV)
+    m.set_profiling(1)
+    m(mel); torch.cuda.synchronize()
+    fused = sum(1 for i in range(4) for j in range(3) if any("ampb_f16x3" in n for n in m.kernel_names(100 + 16 * i + j, 0)))
+    m.set_profiling(0)
+    unfused = 12 - fused
+    return {"whole_ampblock_launches": fused, "act1d_launches": 6 * unfused + 1, "conv_launches_in_ampblocks": 6 * unfused,
+            "act1d_launches_round3": 73}
 
 
 def c5(reps):
@@ -95,6 +111,55 @@ def mel(reps):
     byts = 64 * 65536 * 4 + 64 * 80 * 256 * 4
     return [{"config": "mel front end (reflect pad + STFT 1024/256 + mel 80 + log), B=64 x 65536 samples", "ms_per_step": ms,
              "samples_per_s": 64 * 65536 / ms * 1e3, "algorithmic_GBps": byts / ms / 1e6}]
+
+
+def mel_large(reps):
+    """The front end in the regime feature extraction runs it in (processors/acoustic_extractor.py:376-449: a dataset's worth of audio):
+    1 024 x 65 536 samples = 268 MB in, 84 MB out -- 16 rounds of 512 workgroups instead of the one round of `mel`, so the figure is the
+    kernel's sustained rate, not its start-up."""
+    from amphion_amd.utils.mel import mel_spectrogram_torch
+    pp = NS(sample_rate=22050, n_fft=1024, win_size=1024, hop_size=256, n_mel=80, fmin=0, fmax=8000)
+    B = 1024
+    wav = (torch.rand(B, 65536, generator=torch.Generator().manual_seed(1)) * 2 - 1).to(DEV)
+    ms = timed(lambda: mel_spectrogram_torch(wav, pp), reps)
+    byts = B * 65536 * 4 + B * 80 * 256 * 4
+    return [{"config": f"mel front end at dataset scale, B={B} x 65536 samples ({byts / 1e6:.0f} MB algorithmic)", "ms_per_step": ms,
+             "samples_per_s": B * 65536 / ms * 1e3, "x_realtime": B * 65536 / ms * 1e3 / 22050, "algorithmic_bytes": byts,
+             "algorithmic_GBps": byts / ms / 1e6, "frac_of_hbm_peak": byts / ms / 1e6 / 8000.0, "ns_per_frame": ms * 1e6 / (B * 256),
+             "bound": "VALU (about 800 vector instructions per 1024-point frame, DESIGN.md §3.5), not HBM"}]
+
+
+def c1(reps):
+    """BASELINE.json configs[0] on the GPU: the 16 real clips (3.0-12.9 s, 103.6 s of 22.05 kHz audio; int16 PCM kept as a test
+    fixture, tests/golden/golden_c1.npz) through wav -> mel front end -> HiFi-GAN V1 -> crop -> 16-bit PCM, ONE utterance per forward
+    (inference.batch_size = 1, as bins/vocoder/inference.py runs it), host memory to host memory; median of `reps` passes."""
+    import statistics as st
+    import numpy as np
+    from amphion_amd.utils import mel as M
+    from amphion_amd.utils.io import wav_to_pcm16
+    G = np.load(os.path.join(ROOT, "tests", "golden", "golden_c1.npz"))
+    clips = [torch.from_numpy(G[f"pcm_{i}"].astype(np.float32) / 32768.0).pin_memory() for i in range(16)]
+    cfg, m = hifigan()
+    pp = NS(sample_rate=22050, n_fft=1024, win_size=1024, hop_size=256, n_mel=80, fmin=0, fmax=8000)
+
+    def one_pass():
+        outs = []
+        for w in clips:
+            wd = w.to(DEV, non_blocking=True).unsqueeze(0)
+            mel = M.extract_mel_features(wd, pp)                  # [n_mel, F]
+            wav = m(mel.unsqueeze(0))                             # [1, 1, F * hop]
+            outs.append(wav_to_pcm16(wav[0, :, : mel.shape[-1] * 256]).cpu())
+        return outs
+
+    one_pass(); torch.cuda.synchronize()
+    wall = []
+    for _ in range(max(3, reps)):
+        t0 = time.perf_counter(); outs = one_pass(); torch.cuda.synchronize(); wall.append((time.perf_counter() - t0) * 1e3)
+    secs = sum(int(c.numel()) for c in clips) / 22050.0
+    med = st.median(wall)
+    return [{"config": "C1: 16 LJSpeech-style clips, wav -> mel -> HiFi-GAN V1 -> PCM16, batch_size = 1, host to host", "ms_total": med,
+             "ms_all": [round(w, 1) for w in wall], "audio_s": secs, "x_realtime": secs / (med * 1e-3), "ms_per_clip": med / 16,
+             "samples_out": int(sum(o.numel() for o in outs))}]
 
 
 def pcm(reps):
@@ -157,9 +222,9 @@ def lat(reps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--only", default="", choices=["", "c3", "c5", "vits", "mel", "pcm", "list", "lat"])
+    ap.add_argument("--only", default="", choices=["", "c1", "c3", "c5", "vits", "mel", "mel_large", "pcm", "list", "lat"])
     a = ap.parse_args()
-    runs = {"c3": c3, "c5": c5, "vits": vits, "mel": mel, "pcm": pcm, "list": lst, "lat": lat}
+    runs = {"c1": c1, "c3": c3, "c5": c5, "vits": vits, "mel": mel, "mel_large": mel_large, "pcm": pcm, "list": lst, "lat": lat}
     with torch.no_grad():
         for name, fn in runs.items():
             if a.only in ("", name):
