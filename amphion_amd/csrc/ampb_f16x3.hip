@@ -263,23 +263,26 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void ampb_f16x3_kernel(const AmpbA
 
     // a tensor row in the P layout: 16 aligned float4 per lane (T % 4 == 0, q0 % 4 == 0: a group lies inside [0, T) or outside)
     const size_t rowoff = ((size_t)item * C + ch) * T;
-    auto load_rows = [&](const float* base, const int qrun, f32x16 (&dst)[4]) __attribute__((always_inline)) {
+    // `lim`: columns from there on read as zero.  x: the utterance's own length -- beyond it a ragged row holds whatever the workspace
+    // held (possibly NaN), and although those columns are zeroed again when the operand tile is written (a factor 0), NaN * 0 would
+    // not be; the running MRF sum: the row length (its columns only ever meet the same columns of the output)
+    auto load_rows = [&](const float* base, const int qrun, const int lim, f32x16 (&dst)[4]) __attribute__((always_inline)) {
         const float* row = base + rowoff;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int qg = qrun + 4 * i;
-            const bool inb = qg >= 0 && qg < T;
+            const bool inb = qg >= 0 && qg < T;                  // whole float4 inside the row or outside (T, q0 multiples of 4)
             const float4 f = *reinterpret_cast<const float4*>(row + (inb ? qg : 0));
-            dst[AMP_PT(4 * i)][AMP_PR(4 * i) + 0] = inb ? f.x : 0.f;
-            dst[AMP_PT(4 * i)][AMP_PR(4 * i) + 1] = inb ? f.y : 0.f;
-            dst[AMP_PT(4 * i)][AMP_PR(4 * i) + 2] = inb ? f.z : 0.f;
-            dst[AMP_PT(4 * i)][AMP_PR(4 * i) + 3] = inb ? f.w : 0.f;
+            dst[AMP_PT(4 * i)][AMP_PR(4 * i) + 0] = (inb && qg + 0 < lim) ? f.x : 0.f;
+            dst[AMP_PT(4 * i)][AMP_PR(4 * i) + 1] = (inb && qg + 1 < lim) ? f.y : 0.f;
+            dst[AMP_PT(4 * i)][AMP_PR(4 * i) + 2] = (inb && qg + 2 < lim) ? f.z : 0.f;
+            dst[AMP_PT(4 * i)][AMP_PR(4 * i) + 3] = (inb && qg + 3 < lim) ? f.w : 0.f;
         }
     };
 
     f32x16 xv[4];                             // x (then x + pair_0(x), ...): the residual, P layout
     f32x16 acc[4];                            // accumulators / the activation's operand and result (P layout)
-    load_rows(a.x, qw, xv);
+    load_rows(a.x, qw, Tv, xv);
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = xv[t];
 
@@ -436,7 +439,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void ampb_f16x3_kernel(const AmpbA
                 for (int t = 0; t < 4; ++t) acc[t] = xv[t] + bv;
                 if (last && a.mode != 0) {
                     f32x16 yv[4];
-                    load_rows(a.y, opaque(qw), yv);
+                    load_rows(a.y, opaque(qw), T, yv);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) acc[t] += yv[t];
                 }

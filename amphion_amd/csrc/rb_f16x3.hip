@@ -139,7 +139,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void rb_f16x3_kernel(const RbArgs 
 #pragma unroll
         for (int t = 0; t < NI; ++t) {
             const int col = RB_G + colw + 32 * t;
-            const bool ok = qok[t];
+            const bool ok = qok[t];        // (a select, not a zero factor: beyond a ragged utterance's end the rows hold whatever the
+                                           //  workspace held -- possibly NaN -- and NaN * 0 would reach the valid columns through the taps)
             // channels 32 * wm + 16 * hi + r  ->  chunk 2 * wm + hi, octet r >> 3: two whole 16-B units per plane
             const int o4 = (2 * wm + hi) * CHS + col;
 #pragma unroll

@@ -212,3 +212,41 @@ def test_bigvgan_full_size_policy_equals_separate_launches(fusion):
     with torch.no_grad():
         y0 = m(mel)
     assert torch.equal(y1, y0)
+
+
+@pytest.mark.parametrize("arch", ["bigvgan", "hifigan"])
+def test_ragged_forward_ignores_what_lies_beyond_an_utterance(fusion, arch):
+    """Beyond a ragged utterance's end the scratch tensors hold whatever the workspace held -- here NaN, on purpose.  Every layer takes
+    its input as zero / replicated there, so the valid samples must not change (a zero FACTOR instead of a select would let NaN * 0
+    through the conv taps)."""
+    if arch == "bigvgan":
+        hp = vo.bigvgan_base_hp()
+        m = _bigvgan(hp, 100, synth.synth_state_dict(synth.bigvgan_param_shapes(100, hp), 1234, g_gain=0.75))
+        n_mel = 100
+    else:
+        from amphion_amd.models.vocoders.gan.generator.hifigan import HiFiGAN
+
+        hp = vo.hifigan_v1_hp()
+        m = HiFiGAN(NS(preprocess=NS(n_mel=80, hop_size=256), model=NS(hifigan=NS(**hp))))
+        m.load_state_dict(synth.synth_state_dict(synth.hifigan_param_shapes(80, hp), 1234))
+        m = m.cuda().eval()
+        n_mel = 80
+    fusion(2)
+    from amphion_amd import _lib
+    _lib.check(_lib.lib().amp_set_resblock_fusion(2))
+    try:
+        gen = torch.Generator().manual_seed(11)
+        lens = torch.tensor([120, 37, 88, 120, 3, 64], dtype=torch.int32)
+        mel = torch.randn(6, n_mel, 120, generator=gen)
+        for i, l in enumerate(lens):
+            mel[i, :, l:] = 0
+        with torch.no_grad():
+            y0 = m.forward_ragged(mel.cuda(), lens.cuda()).cpu()
+            ws = m._amp_ws
+            ws[: ws.numel() // 4 * 4].view(torch.float32).fill_(float("nan"))
+            y1 = m.forward_ragged(mel.cuda(), lens.cuda()).cpu()
+    finally:
+        _lib.check(_lib.lib().amp_set_resblock_fusion(-1))
+    for i, l in enumerate(lens):
+        assert torch.isfinite(y1[i, :, : l * 256]).all(), i
+        assert torch.equal(y1[i, :, : l * 256], y0[i, :, : l * 256]), i
