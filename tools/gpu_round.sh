@@ -19,6 +19,9 @@ export TMPDIR=/tmp
 REPO=$PWD
 python -c "import torch; print(torch.cuda.get_device_name(0))" > $OUT/device.txt 2>&1
 PROF="rocprofv3 --output-format csv --kernel-trace"
+# PROFCMD=<command>: what the prof / pmc steps profile (default: the config-2 bench line; e.g. "python $PWD/tools/bench_configs.py --only c3")
+PROFCMD=${PROFCMD:-"python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline"}
+PMCCMD=${PROFCMD_PMC:-${PROFCMD/--steps 5 --warmup 2/--steps 2 --warmup 1}}
 for STEP in $STEPS; do
   echo "== $STEP"
   case $STEP in
@@ -28,10 +31,10 @@ for STEP in $STEPS; do
     bench)
       ( timeout 600 python bench.py --steps 10 --warmup 3 2> $OUT/bench.err | tail -1 ) > $OUT/bench.json; cut -c1-1500 $OUT/bench.json ;;
     prof)
-      ( cd /tmp && timeout 600 $PROF --stats -d $REPO/$OUT/prof -o kt -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $REPO/$OUT/prof_bench.json 2> $REPO/$OUT/prof.err ) ;;
+      ( cd /tmp && timeout 600 $PROF --stats -d $REPO/$OUT/prof -o kt -- $PROFCMD > $REPO/$OUT/prof_bench.json 2> $REPO/$OUT/prof.err ) ;;
     pmc)
-      ( cd /tmp && timeout 600 $PROF --pmc FETCH_SIZE -d $REPO/$OUT/pmc_fetch -o pf -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $REPO/$OUT/pmc_fetch.err )
-      ( cd /tmp && timeout 600 $PROF --pmc WRITE_SIZE -d $REPO/$OUT/pmc_write -o pw -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $REPO/$OUT/pmc_write.err ) ;;
+      ( cd /tmp && timeout 600 $PROF --pmc FETCH_SIZE -d $REPO/$OUT/pmc_fetch -o pf -- $PMCCMD > /dev/null 2> $REPO/$OUT/pmc_fetch.err )
+      ( cd /tmp && timeout 600 $PROF --pmc WRITE_SIZE -d $REPO/$OUT/pmc_write -o pw -- $PMCCMD > /dev/null 2> $REPO/$OUT/pmc_write.err ) ;;
     sq)
       SQCMD=${SQCMD:-"python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline"}     # SQCMD=<other command>: counters of another workload
       ( cd /tmp
