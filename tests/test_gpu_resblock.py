@@ -65,7 +65,7 @@ CASES = [
     (128, 3, (1, 3, 5), 2, 700),      # C = 128: 256-column tiles, 16 guard columns
     (128, 5, (1, 3, 5), 1, 300),
     # large launches (thousands of tiles, every wave of the chip busy; these shapes also exercised the strip-walking variant of
-    # the kernel that was measured slower and not kept, tests/experiments/rb_strip_f16x3.hip.txt)
+    # the kernel that was measured slower and not kept, profiles/negative_kernels/rb_strip_f16x3.hip.txt)
     (32, 3, (1, 3, 5), 600, 2100),
     (32, 7, (1, 3, 5), 40, 5000),
     (32, 11, (1, 3, 5), 70, 4000),

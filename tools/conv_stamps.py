@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Phase timeline of conv_f16x3_kernel from in-kernel clock stamps (experiment build: copy tests/experiments/conv_f16x3_stamps.hip.txt over csrc/conv_f16x3.hip, then
+"""Phase timeline of conv_f16x3_kernel from in-kernel clock stamps (experiment build: copy profiles/negative_kernels/conv_f16x3_stamps.hip.txt over csrc/conv_f16x3.hip, then
 AMP_BUILD_TAG=ct AMP_BUILD_FLAGS=-DCONV_TIMING python -m amphion_amd.build; run with AMP_LIB_PATH pointing at the ct library)."""
 import ctypes
 import os

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Phase timeline of mel1024_kernel from in-kernel clock stamps.  Experiment builds only: the MEL_STAMP macros and the
-amp_debug_mel_stamps export are in tests/experiments/mel1024_prefetch.hip.txt (copy it over csrc/mel.hip, then
+amp_debug_mel_stamps export are in profiles/negative_kernels/mel1024_prefetch.hip.txt (copy it over csrc/mel.hip, then
 AMP_BUILD_TAG=tm AMP_BUILD_FLAGS=-DMEL_TIMING python -m amphion_amd.build, and run with AMP_LIB_PATH pointing at the tm library)."""
 import ctypes
 import os
