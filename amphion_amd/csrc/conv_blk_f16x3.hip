@@ -32,18 +32,26 @@ union FragB {
 
 #define AMP_PIN_VMEM() __builtin_amdgcn_sched_barrier(0x386)
 
-// 4 waves along M (WN = 1), MI = 2 row blocks per wave: 256 rows x NT = 32 * NI columns per workgroup.
+// 4 / WN waves along M, WN along the columns, MI = 2 row blocks per wave: 256 / WN rows x WN * 32 * NI columns per workgroup.
+// WN = 1: 256-row groups (the C = 256 stage, the transposed convs' polyphase rows); round 4: WN = 2 for convs with 128 rows -- BigVGAN's
+// AMPBlock convs at C = 128 cannot be paired (an activation sits between them) and ran on conv_f16x3.hip's 32-row wave tiles.  Measured
+// inside the C3 forward (profiles/r4_t_narrow_blocked_conv.txt): k = 7 / 11 resblocks 2.98 / 3.77 -> 2.91 / 3.72 ms, k = 3 1.86 -> 1.92 (the
+// policy keeps k = 3 on the pipelined kernel); a WN = 4 form for 64-row convs (576 staged columns: 11 spilled registers) was +5 % / +-0 at
+// k = 7 / 11 and is not built.
 // RING = 0: one A-fragment register set per staging round (CM * KT taps), every entry re-loaded for the next round right after
 // its use.  RING = D > 0 (long tap loops, CM = 1): a ring of D taps -- two row blocks' whole-chunk sets (16 * KT registers)
 // plus 128 accumulators do not fit two waves per SIMD at KT = 7 / 11.  Tap g lives in slot g % D and the slot is re-loaded right
 // after tap g with the next tap that will use it: g + D of this chunk, or -- from the last D taps -- tap (g % D) of the NEXT
 // chunk, whose first D taps restart at slot 0.  Loads run 2-4 taps (3 000-6 000 matrix-pipe cycles) ahead of their use.
-template <int KT, int NI, int HALO, int CM, int RING = 0>
+template <int KT, int NI, int HALO, int CM, int RING = 0, int WN = 1>
 __global__ __launch_bounds__(256, 2) void conv_blk_kernel(const ConvArgs a) {
     constexpr int MI = 2;
     static_assert(RING == 0 || (CM == 1 && RING <= KT), "the A ring serves one chunk per round");
-    constexpr int NT = 32 * NI;                // output columns per workgroup
-    constexpr int S = NT + HALO;               // staged columns
+    static_assert(WN == 1 || WN == 2, "4 waves: 4 x 1 or 2 x 2");
+    constexpr int WMW = 4 / WN;                // waves along M
+    constexpr int NT = 32 * NI;                // output columns per WAVE
+    constexpr int NTW = NT * WN;               // ... per workgroup
+    constexpr int S = NTW + HALO;              // staged columns
     constexpr int NST = (4 * S) / 256;         // staging items (column x channel quad) per thread and chunk
     constexpr int BUF = 4 * S;                 // uint4 per chunk: [plane hi|lo][octet h][S]
     constexpr int VT = CM * KT;                // taps per staging round
@@ -61,17 +69,18 @@ __global__ __launch_bounds__(256, 2) void conv_blk_kernel(const ConvArgs a) {
     if (a.row_groups > 0) { rg = bx % a.row_groups; bx /= a.row_groups; }   // row group fastest, see ConvArgs
     const int item = bx / a.tiles_per_item;
     const int tile = bx - item * a.tiles_per_item;
-    const int q0 = tile * NT;
+    const int q0 = tile * NTW;
+    const int wm = wave / WN, wnc = (wave % WN) * NT;     // this wave's row-block pair and first column inside the workgroup's tile
     if (a.lens) {   // ragged batch: tiles beyond the utterance's valid length, see conv_f16x3.hip
         const long long lv = (long long)a.lens[item] * a.len_mul;
         const long long first_out = (long long)q0 * a.up - a.up_pad;
         if ((a.up > 1 || a.Tout == a.Tin) && first_out >= lv * a.up) return;
     }
-    const int mb0 = (rg * 4 + wave) * MI;   // first 32-row block of this wave (host: M % 256 == 0)
+    const int mb0 = (rg * WMW + wm) * MI;   // first 32-row block of this wave (host: M % (256 / WN) == 0)
 
     const int up = a.up;
-    const int qw = q0 + l31;
-    const bool fast = (up == 1) && (q0 + NT <= a.Tq);
+    const int qw = q0 + wnc + l31;
+    const bool fast = (up == 1) && (q0 + NTW <= a.Tq);
     const int lane_off = (4 * hi) * a.Tout + qw;
     const float asc = a.acc_scale;
     f32x16 acc[MI][NI];
@@ -202,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void conv_blk_kernel(const ConvArgs a) {
     constexpr int NA = RING > 0 ? RING : VT;             // A-fragment register sets held per row block
     FragB a_h[MI][NA], a_l[MI][NA];
 
-    const int rd0 = hi * S + l31 + a.halo_left + a.off0;
+    const int rd0 = hi * S + wnc + l31 + a.halo_left + a.off0;
     const int dstep = a.dstep;
 
     stage_load(0);
@@ -234,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void conv_blk_kernel(const ConvArgs a) {
                 const uint4* bg = base + cc * BUF + g * dstep;
                 // BH = 2 (ring form): the tap's B fragments in two halves of NI / 2 column tiles -- 16 registers instead of 32
                 // (what lets a ring of 4 taps fit); every accumulator still sees hh, hl, lh of this tap in that order
-                constexpr int BH = (RING > 3 && NI % 2 == 0) ? 2 : 1;
+                constexpr int BH = ((RING > 3 || WN > 1) && NI % 2 == 0) ? 2 : 1;   // (WN > 1: the wider staging holds 8-24 more registers)
                 constexpr int NB = NI / BH;
 #pragma unroll
                 for (int th = 0; th < BH; ++th) {
@@ -367,23 +376,24 @@ __global__ __launch_bounds__(256, 2) void conv_blk_kernel(const ConvArgs a) {
     }
 }
 
-template <int KT, int NI, int HALO, int CM, int RING = 0>
+template <int KT, int NI, int HALO, int CM, int RING = 0, int WN = 1>
 static hipError_t launch_blk_one(const ConvArgs& a, hipStream_t stream) {
-    constexpr int S = 32 * NI + HALO;
+    constexpr int S = 32 * NI * WN + HALO;
     const size_t lds = (size_t)2 * CM * 4 * S * sizeof(uint4);
     static unsigned long long attr_set = 0;   // per device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!((attr_set >> dev) & 1ull) && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_blk_kernel<KT, NI, HALO, CM, RING>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_blk_kernel<KT, NI, HALO, CM, RING, WN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set |= 1ull << dev;
     }
-    dim3 grid((unsigned)(a.B * a.tiles_per_item), (unsigned)(a.M / 256));
+    dim3 grid((unsigned)(a.B * a.tiles_per_item), (unsigned)(a.M / (256 / WN)));
     if (a.row_groups > 0) grid = dim3((unsigned)(a.B * a.tiles_per_item * a.row_groups), 1u);
-    note_kernel("conv_blk_kernel", KT, NI, HALO, CM, RING);
-    hipLaunchKernelGGL((conv_blk_kernel<KT, NI, HALO, CM, RING>), grid, dim3(256), lds, stream, a);
+    if (WN == 1) note_kernel("conv_blk_kernel", KT, NI, HALO, CM, RING);
+    else note_kernel("conv_blk_kernel", KT, NI, HALO, CM, RING, WN);
+    hipLaunchKernelGGL((conv_blk_kernel<KT, NI, HALO, CM, RING, WN>), grid, dim3(256), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -406,18 +416,25 @@ int AMP_CAT(conv_blk_nt_kt, AMP_KT)(int cm, int halo_total) {
     return (cm == 1 && halo_total <= 64) ? 128 : 0;
 }
 
-// cm = chunks per staging round; the caller guarantees M % 256 == 0, nchunks % cm == 0, tanh_out == 0 and tiles of
-// conv_blk_nt_kt*(cm, halo) columns
-hipError_t AMP_CAT(launch_conv_blk_kt, AMP_KT)(int cm, const ConvArgs& a, hipStream_t stream) {
+// cm = chunks per staging round, wn = waves along the columns (1 | 2: 256- | 128-row groups); the caller guarantees
+// M % (256 / wn) == 0, nchunks % cm == 0, tanh_out == 0 and tiles of wn * conv_blk_nt_kt*(cm, halo) columns
+hipError_t AMP_CAT(launch_conv_blk_kt, AMP_KT)(int cm, int wn, const ConvArgs& a, hipStream_t stream) {
     constexpr int KT = AMP_KT;
     if constexpr (KT == 2) {
+        if (wn != 1) return hipErrorInvalidValue;
         if (cm == 2) return launch_blk_one<KT, 3, 32, 2>(a, stream);
         return launch_blk_one<KT, 3, 32, 1>(a, stream);
     } else if constexpr (KT == 3) {
         if (cm != 1) return hipErrorInvalidValue;
+        if (wn == 2) return launch_blk_one<KT, 4, 64, 1, 0, 2>(a, stream);
+        if (wn != 1) return hipErrorInvalidValue;
         return launch_blk_one<KT, 4, 64, 1>(a, stream);
     } else {
         if (cm != 1) return hipErrorInvalidValue;
+        // (two waves along the columns stage 320 columns per chunk -- 8 more staging registers than the 192 of the 256-row form: a
+        //  ring of 3 taps keeps the kernel free of scratch)
+        if (wn == 2) return launch_blk_one<KT, 4, 64, 1, 3, 2>(a, stream);
+        if (wn != 1) return hipErrorInvalidValue;
         return launch_blk_one<KT, 4, 64, 1, AMP_BLK_RING>(a, stream);
     }
 }

@@ -331,6 +331,7 @@ struct Config {
     int conv_rg_fast = 1;
     int pingpong = 1;
     int fuse_act = 0;
+    int narrow_blk = 1;        // row-blocked conv kernel for 128- / 64-row convs (amp_set_conv_blk_narrow)
     Config() {
         auto num = [](const char* name, int lo, int hi, int dflt) {
             const char* e = getenv(name);
@@ -442,11 +443,12 @@ int conv_blk_nt_kt2(int, int);
 int conv_blk_nt_kt3(int, int);
 int conv_blk_nt_kt7(int, int);
 int conv_blk_nt_kt11(int, int);
-hipError_t launch_conv_blk_kt2(int, const ConvArgs&, hipStream_t);
-hipError_t launch_conv_blk_kt3(int, const ConvArgs&, hipStream_t);
-hipError_t launch_conv_blk_kt7(int, const ConvArgs&, hipStream_t);
-hipError_t launch_conv_blk_kt11(int, const ConvArgs&, hipStream_t);
+hipError_t launch_conv_blk_kt2(int, int, const ConvArgs&, hipStream_t);
+hipError_t launch_conv_blk_kt3(int, int, const ConvArgs&, hipStream_t);
+hipError_t launch_conv_blk_kt7(int, int, const ConvArgs&, hipStream_t);
+hipError_t launch_conv_blk_kt11(int, int, const ConvArgs&, hipStream_t);
 static int conv_blk_mode() { return cfg().conv_blk; }
+static int narrow_blk_mode() { return cfg().narrow_blk; }
 // Convs with more than one row group (M > 32 * WM rows: the C = 256 stage, the transposed convs' polyphase rows) launch a
 // 1-D grid with the row group as the fastest index, so that the row groups of one x tile run back to back on one XCD and x
 // comes from HBM once (ConvArgs::row_groups).  amp_set_conv_rg_fast(0): the 2-D grid (row group =
@@ -673,20 +675,26 @@ static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope
         // k = 7 / 11 (long contractions: the pipelined kernel is efficient per tile) only gain from the whole-K kernel's
         // narrower tiles while the chip is badly under-filled: one 3-s utterance 1.16 -> 1.06 ms, a 10-s one 2.28 -> 2.30
         const long long wgs_half = (long long)B * ((a.Tq + 63) / 64) * ((c->M + plan.Mgroup() - 1) / plan.Mgroup());
-        int blk_cm = 0, blk_nt = 0;
+        int blk_cm = 0, blk_nt = 0, blk_wn = 1;
         const bool blk_kt = c->KT == 2 || c->KT == 3 || (conv_blk_mode() == 3 && (c->KT == 7 || c->KT == 11));   // mode 3: + the A-ring form for k = 7 / 11
-        if (conv_blk_mode() > 0 && plan.NI == 4 && plan.WM == 4 && blk_kt && c->M % 256 == 0 && !c->tanh_out) {
+        // row groups of 256 (four waves along M), or -- round 4, Conv1d only -- 128 rows with two waves along the columns: the AMPBlock
+        // convs of BigVGAN's C = 128 stage (unpaired: an activation sits between them), k = 7 / 11 under the policy (mode 1), any k in mode 2
+        if (c->M % 256 == 0) blk_wn = 1;
+        else if (c->M % 128 == 0 && c->KT != 2 && (narrow_blk_mode() >= 2 || (narrow_blk_mode() == 1 && c->KT >= 7))) blk_wn = 2;
+        else blk_wn = 0;
+        if (conv_blk_mode() > 0 && plan.NI == 4 && blk_wn > 0 && blk_kt && !c->tanh_out && !c->pad_reflect) {
             int cm = (conv_blk_mode() >= 2 && c->KT == 2 && c->nchunks % 2 == 0) ? 2 : 1;
             const int halo = c->halo_left + c->halo_right;
-            const int nt = c->KT == 2 ? conv_blk_nt_kt2(cm, halo) : c->KT == 3 ? conv_blk_nt_kt3(cm, halo) : c->KT == 7 ? conv_blk_nt_kt7(cm, halo) : conv_blk_nt_kt11(cm, halo);
-            if (nt > 0 && (long long)B * ((a.Tq + nt - 1) / nt) * (c->M / 256) >= kConvBlkMinWorkgroups) { blk_cm = cm; blk_nt = nt; }
+            const int nt = blk_wn * (c->KT == 2 ? conv_blk_nt_kt2(cm, halo) : c->KT == 3 ? conv_blk_nt_kt3(cm, halo) : c->KT == 7 ? conv_blk_nt_kt7(cm, halo) : conv_blk_nt_kt11(cm, halo));
+            if (nt > 0 && (long long)B * ((a.Tq + nt - 1) / nt) * (c->M / (256 / blk_wn)) >= kConvBlkMinWorkgroups) { blk_cm = cm; blk_nt = nt; }
         }
         if (blk_cm > 0) {
+            const int rows = 256 / blk_wn;
             a.tiles_per_item = (a.Tq + blk_nt - 1) / blk_nt;
             a.wd = blk_nt + c->halo_left + c->halo_right;
-            a.row_groups = (conv_rg_fast() && c->M / 256 > 1 && conv_weight_bytes(c) <= kConvRgFastMaxWeightBytes) ? c->M / 256 : 0;
-            AMP_HIP(c->KT == 2 ? launch_conv_blk_kt2(blk_cm, a, stream) : c->KT == 3 ? launch_conv_blk_kt3(blk_cm, a, stream) :
-                    c->KT == 7 ? launch_conv_blk_kt7(blk_cm, a, stream) : launch_conv_blk_kt11(blk_cm, a, stream));
+            a.row_groups = (conv_rg_fast() && c->M / rows > 1 && conv_weight_bytes(c) <= kConvRgFastMaxWeightBytes) ? c->M / rows : 0;
+            AMP_HIP(c->KT == 2 ? launch_conv_blk_kt2(blk_cm, blk_wn, a, stream) : c->KT == 3 ? launch_conv_blk_kt3(blk_cm, blk_wn, a, stream) :
+                    c->KT == 7 ? launch_conv_blk_kt7(blk_cm, blk_wn, a, stream) : launch_conv_blk_kt11(blk_cm, blk_wn, a, stream));
         } else if (plan.NI == 2 && small_conv_covers(c) && (c->KT <= 5 || wgs_half <= 128)) {
             // a small grid of a short contraction: the whole-K kernel (128 x 32 or 128 x 64 tiles, same bits)
             const int ni = small_conv_ni(c);
@@ -1694,6 +1702,12 @@ int amp_set_pingpong(int on) {
 
 int amp_set_conv_rg_fast(int on) {
     cfg().conv_rg_fast = on < 0 ? kConvRgFastDefault : (on ? 1 : 0);   // -1: back to the default
+    return AMP_OK;
+}
+
+int amp_set_conv_blk_narrow(int on) {
+    if (on < -1 || on > 2) { set_error("amp_set_conv_blk_narrow: %d (0 off, 1 policy: 128-row convs with k >= 7, 2 every 128-row conv, -1 default)", on); return AMP_ERR_INVALID; }
+    cfg().narrow_blk = on < 0 ? 1 : on;
     return AMP_OK;
 }
 

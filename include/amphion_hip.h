@@ -339,6 +339,10 @@ int amp_set_small_conv(int on);
  * round, 2 = two where available, 3 = 2 + k = 7 / 11 on the A-fragment-ring form (default), -1 = back to AMP_CONV_BLK /
  * the default -- an A/B and cross-check switch. */
 int amp_set_conv_blk(int mode);
+/* Conv1d with 128 output rows (BigVGAN's unpaired AMPBlock convs at C = 128) on the row-blocked kernel, two waves along the columns: 1
+ * (default) the measured policy (k = 7 / 11), 2 every tap count the kernel is built for, 0 all on the pipelined kernel.  Same bits in every
+ * mode (an A/B and cross-check switch); -1: default. */
+int amp_set_conv_blk_narrow(int on);
 
 /* Convs with several row groups (more GEMM rows than one workgroup holds) launch with the row group as the fastest grid
  * index: the row groups of one x tile run back to back on one XCD and share its L2 copy of x (same bits; 1 = default).

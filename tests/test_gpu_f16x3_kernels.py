@@ -160,6 +160,50 @@ def test_row_group_order_is_bitwise_neutral(tr, cin, cout, k, s, d, B, T):
     assert (outs[1] - ref).abs().max().item() <= 2e-5
 
 
+NARROW_CASES = [
+    # cin, cout, k, dilation, B, T      (128 output rows: two waves along the columns, 256-column workgroup tiles; 64 rows: pipelined)
+    (128, 128, 3, 1, 8, 8200),
+    (128, 128, 3, 5, 8, 8200),
+    (128, 128, 7, 3, 8, 8200),
+    (128, 128, 11, 5, 8, 8200),
+    (128, 128, 11, 1, 6, 8193),        # unaligned rows, ragged last tile
+    (100, 128, 7, 1, 8, 8200),         # Cin not a multiple of 16
+    (64, 64, 3, 1, 8, 16500),
+    (64, 64, 7, 5, 8, 16500),
+    (64, 64, 11, 3, 8, 16500),
+    (16, 64, 11, 1, 8, 16500),         # ONE chunk
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,d,B,T", NARROW_CASES)
+def test_narrow_blocked_conv_bitwise(cin, cout, k, d, B, T):
+    """Round 4: the row-blocked kernel with two waves along the columns for 128-row convs (BigVGAN's unpaired AMPBlock convs):
+    amp_set_conv_blk_narrow 0 (pipelined kernel) / 1 (policy: k >= 7) / 2 (every tap count) give the same bits, incl. residual and
+    leaky-ReLU on load / store."""
+    from amphion_amd import _lib
+    from hip_helpers import conv_forward
+
+    w = _rand(cout, cin, k, seed=1, scale=(cin * k) ** -0.5)
+    b = _rand(cout, seed=2, scale=0.1)
+    x = _rand(B, cin, T, seed=3)
+    res = _rand(B, cout, T, seed=4)
+    pad = (k * d - d) // 2
+    L = _lib.lib()
+    outs = {}
+    try:
+        for mode in (0, 1, 2):
+            _lib.check(L.amp_set_conv_blk_narrow(mode))
+            outs[mode] = [conv_forward(w, b, x, dilation=d, padding=pad), conv_forward(w, b, x, dilation=d, padding=pad, res=res),
+                          conv_forward(w, None, x, dilation=d, padding=pad, slope_in=0.1, slope_out=0.2)]
+    finally:
+        _lib.check(L.amp_set_conv_blk_narrow(-1))
+    for mode in (1, 2):
+        for a, c in zip(outs[mode], outs[0]):
+            assert torch.isfinite(a).all() and torch.equal(a, c), f"narrow mode {mode} differs from the pipelined kernel"
+    ref = F.conv1d(x, w, b, dilation=d, padding=pad)
+    assert (outs[2][0] - ref).abs().max().item() <= 2e-5
+
+
 def test_blocked_conv_switch_rejects_bad_mode():
     from amphion_amd import _lib
 

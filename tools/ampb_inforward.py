@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--modes", type=int, nargs="+", default=[0, 1, 2, 3])
+    ap.add_argument("--narrow", type=int, nargs="+", default=None, help="instead of the fusion modes: amp_set_conv_blk_narrow values to alternate (fusion = policy)")
     a = ap.parse_args()
     from amphion_amd.models.vocoders.gan.generator.bigvgan import BigVGAN
     m = randomize_(BigVGAN(NS(preprocess=NS(n_mel=100, hop_size=256), model=NS(bigvgan=NS(**V1)))), 1234, g_gain=0.75).cuda().eval()
@@ -32,8 +33,11 @@ def main():
         torch.cuda.synchronize()
         res = {}
         for rnd in range(a.rounds):
-            for mode in a.modes:
-                _lib.check(L.amp_set_ampblock_fusion(mode))
+            for mode in (a.narrow if a.narrow is not None else a.modes):
+                if a.narrow is not None:
+                    _lib.check(L.amp_set_conv_blk_narrow(mode))
+                else:
+                    _lib.check(L.amp_set_ampblock_fusion(mode))
                 for _ in range(3):
                     m(mel)
                 m.set_profiling(a.steps)
@@ -49,6 +53,7 @@ def main():
                         r["names"][(i, j)] = " | ".join(m.kernel_names(w, 0))
                 m.set_profiling(0)
     _lib.check(L.amp_set_ampblock_fusion(-1))
+    _lib.check(L.amp_set_conv_blk_narrow(-1))
     print("mode," + ",".join(f"fwd_round{r}" for r in range(a.rounds)))
     for mode, r in res.items():
         print(f"{mode}," + ",".join(f"{v:.3f}" for v in r["fwd"]))
