@@ -48,6 +48,10 @@
 #ifndef AMP_KT
 #error "compile with -DAMP_KT=<taps>"
 #endif
+#ifndef AMP_AMPB_SCATTER
+#define AMP_AMPB_SCATTER 1     // 0: the register-transpose form of the tile write (same bits; kept for the A/B, profiles/r4_u_*)
+#endif
+#include <type_traits>
 
 namespace amp {
 
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void ampb_f16x3_kernel(const AmpbA
     static_assert(RING == 0 || RING < KT, "a ring shorter than one chunk");
     constexpr int NTHR = 64 * WM * WN;
     constexpr int W = 128 * WN;               // columns per tile (every op is evaluated on all of them)
-    constexpr int WL = W + 2 * G;             // LDS row length
+    constexpr int WL = W + 2 * G + 1;         // LDS row length: guards either side + 1 pad column (WL = 1 mod 8: see the scatter below)
     constexpr int H2 = (KT - 1) / 2;
     constexpr int NCH = 2 * WM;               // 16-channel chunks (C = 32 * WM)
     constexpr int CHS = 4 * WL;               // uint4 per chunk [plane][octet][WL]
@@ -374,7 +378,38 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void ampb_f16x3_kernel(const AmpbA
         }
         AMP_PIN_VMEM();
 
-        // ---------------- lane = channel -> lane = column, x16, hi / lo, the conv's zero padding -> the operand tile ----------------
+        // ---------------- x16, hi / lo, the conv's zero padding -> the operand tile ----------------
+#if AMP_AMPB_SCATTER
+        // A lane holds ONE channel of 64 columns; the tile wants 8 channels of one column per 16-B unit.  The transposition is left to
+        // the LDS: every value goes to its own 2-byte slot (ds_write_b16 / _d16_hi of the packed conversions, 128 per step).  The kernel is
+        // VALU-bound with the LDS pipe ~10 % busy, and the register transposes of the first version (below) were 384 of its ~2 500 vector
+        // instructions per step.  Rows of WL * 16 B with WL = 1 (mod 8): the four octets of a half-wave (two per chunk, chunks 4 WL apart) land on disjoint banks.
+        {
+            _Float16* const dst = reinterpret_cast<_Float16*>(smem4 + (2 * wm + (o4 >> 1)) * CHS + (o4 & 1) * WL + G + 128 * wn + 64 * h) + e8;
+            auto scatter = [&](auto masked) __attribute__((always_inline)) {
+                const int qws = opaque(qw);
+#pragma unroll
+                for (int c = 0; c < 64; c += 4) {
+                    float k[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) k[j] = (!decltype(masked)::value || (qws + c + j >= 0 && qws + c + j < Tv)) ? 16.f : 0.f;
+                    const amp_f32x2 v01 = {acc[AMP_PT(c)][AMP_PR(c)] * k[0], acc[AMP_PT(c + 1)][AMP_PR(c + 1)] * k[1]};
+                    const amp_f32x2 v23 = {acc[AMP_PT(c + 2)][AMP_PR(c + 2)] * k[2], acc[AMP_PT(c + 3)][AMP_PR(c + 3)] * k[3]};
+                    range_max = __builtin_fmaxf(range_max, __builtin_fmaxf(__builtin_fabsf(v01.x), __builtin_fabsf(v01.y)));
+                    range_max = __builtin_fmaxf(range_max, __builtin_fmaxf(__builtin_fabsf(v23.x), __builtin_fabsf(v23.y)));
+                    uint2 hh, ll;
+                    split4_f16(v01, v23, hh, ll);
+                    const amp_f16x2 h01 = __builtin_bit_cast(amp_f16x2, hh.x), h23 = __builtin_bit_cast(amp_f16x2, hh.y);
+                    const amp_f16x2 l01 = __builtin_bit_cast(amp_f16x2, ll.x), l23 = __builtin_bit_cast(amp_f16x2, ll.y);
+                    dst[8 * (c + 0)] = h01.x; dst[8 * (c + 1)] = h01.y; dst[8 * (c + 2)] = h23.x; dst[8 * (c + 3)] = h23.y;
+                    dst[8 * (c + 0 + 2 * WL)] = l01.x; dst[8 * (c + 1 + 2 * WL)] = l01.y; dst[8 * (c + 2 + 2 * WL)] = l23.x; dst[8 * (c + 3 + 2 * WL)] = l23.y;
+                }
+            };
+            if (edge) scatter(std::true_type{});      // (workgroup-uniform: the selects only where an utterance ends)
+            else scatter(std::false_type{});
+        }
+#else
+        // the first version: lane = channel -> lane = column by 8 x 8 DPP transposes, one ds_write_b128 per column and plane
         {
             const int qws = opaque(qw);           // (not hoisted: eight loop-invariant k16 pairs cost 16 registers for the whole kernel)
             const int colb = G + 128 * wn + 64 * h + e8;
@@ -400,6 +435,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void ampb_f16x3_kernel(const AmpbA
                 dst[8 * b + 2 * WL] = make_uint4(la.x, la.y, lb.x, lb.y);
             }
         }
+#endif
         if (edge) {
             __syncthreads();                      // the patched columns belong to other lanes' writes
             if (wn == 0 && (h ? has_hi : has_lo)) {
@@ -524,7 +560,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void ampb_f16x3_kernel(const AmpbA
 template <int KT, int WM, int WN, int RING, int G>
 static hipError_t launch_ampb_one(const AmpbArgs& a, hipStream_t stream) {
     constexpr int W = 128 * WN;
-    const size_t lds = (size_t)2 * WM * 4 * (W + 2 * G) * sizeof(uint4) + (size_t)WM * WN * 320 * sizeof(float) + (size_t)32 * WM * 10 * sizeof(float);
+    const size_t lds = (size_t)2 * WM * 4 * (W + 2 * G + 1) * sizeof(uint4) + (size_t)WM * WN * 320 * sizeof(float) + (size_t)32 * WM * 10 * sizeof(float);
     static unsigned long long attr_set = 0;   // per device: the attribute belongs to that device's copy of the function
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;

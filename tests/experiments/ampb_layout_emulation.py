@@ -6,8 +6,8 @@ tests/experiments/ampb_primitives.hip checks on the GPU.      python tests/exper
 import numpy as np
 
 WM, WN, G = 2, 4, 32
-W, WL = 128 * WN, 128 * WN + 2 * G
-NCH, CHS = 2 * WM, 4 * (128 * WN + 2 * G)
+W, WL = 128 * WN, 128 * WN + 2 * G + 1          # + 1 pad column: WL = 1 (mod 8), see the bank check of the scatter below
+NCH, CHS = 2 * WM, 4 * WL
 NW = WM * WN
 
 
@@ -130,7 +130,25 @@ for c in range(NCH):
             for e in range(8):
                 assert smem[c * CHS + oct_ * WL + G + col, e] == f(16 * c + 8 * oct_ + e, col), (c, oct_, col, e)
                 assert smem[c * CHS + 2 * WL + oct_ * WL + G + col, e] == -f(16 * c + 8 * oct_ + e, col)
-print("operand tile ok")
+print("operand tile ok (register transposes: AMP_AMPB_SCATTER = 0)")
+
+# --- the default form: every lane scatters its own 64 columns as 2-byte stores (ds_write_b16), no lane transposes
+smem2 = np.full((NCH * CHS, 8), -1.0)
+worst = 0
+for w in range(NW):
+    wm, wn = divmod(w, WN)
+    for c in range(64):
+        banks = {}
+        for lane in range(64):
+            h, e8, o4 = lane >> 5, lane & 7, (lane >> 3) & 3
+            unit = (2 * wm + (o4 >> 1)) * CHS + (o4 & 1) * WL + G + 128 * wn + 64 * h + c
+            smem2[unit, e8] = acc[w, lane, PT(c), PR(c)]
+            smem2[unit + 2 * WL, e8] = -acc[w, lane, PT(c), PR(c)]
+            byte = unit * 16 + 2 * e8
+            banks.setdefault((h, (byte // 4) % 32), set()).add(byte // 4)     # per half-wave: distinct dwords on one bank
+        worst = max(worst, max(len(v) for v in banks.values()))
+assert np.array_equal(smem2, smem)
+print(f"operand tile ok (LDS scatter); distinct dwords per bank and half-wave: {worst} (1 = conflict-free; two lanes share each dword)")
 
 # --- the conv's fragment reads (A operand of the transposed product: row = time = lane & 31, k-block = lane >> 5)
 H2, d = 5, 5
