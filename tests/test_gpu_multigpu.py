@@ -26,3 +26,36 @@ def test_bench_two_ranks_rccl_gather_is_bitwise():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["scaling"] == "weak"
     assert "bitwise" in d["gather_check"]
+
+
+def test_multi_gpu_diagnostics_on_a_one_rank_group():
+    """The N > 1 diagnostics of the bench line (per-rank ms, generator alone, fp32 / PCM16 gather alone) cannot meet a second GPU on
+    these boxes; a one-rank RCCL group at least runs every collective and every key of the code path on the hardware, so that a first
+    8-GPU run does not die of a typo."""
+    import importlib.util
+    import socket
+
+    import torch.distributed as dist
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=device)
+    try:
+        from amphion_amd.utils.synthetic import synthetic_mel
+
+        model, _, _ = bench.build_model(device)
+        mel = synthetic_mel(4, bench.N_MEL, 32, seed=0).to(device)
+        d = bench.multi_gpu_diagnostics(model, mel, 4, device, [1.5], reps=2)
+    finally:
+        dist.destroy_process_group()
+    for k in ("per_rank_ms", "compute_only_ms", "gather_ms", "gather_ms_overlapped", "gather_ms_pcm16", "pcm16_convert_ms", "gather_GBps_per_link"):
+        assert k in d, k
+    assert d["per_rank_ms"] == [1.5] and d["compute_only_ms"] > 0 and d["gather_ms"] > 0 and d["gather_ms_pcm16"] > 0
+    json.dumps(d)
