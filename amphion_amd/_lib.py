@@ -101,11 +101,16 @@ _SIGNATURES = {
     "amp_conv_out_len": (c_int, [c_void_p, c_int]),
     "amp_conv_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_float, c_void_p, c_void_p]),
     "amp_conv_forward_strided": (c_int, [c_void_p, c_void_p, ctypes.c_longlong, c_int, c_int, c_float, c_void_p, c_float, c_void_p, c_void_p]),
+    "amp_conv_forward_ragged": (c_int, [c_void_p, c_void_p, ctypes.c_longlong, c_int, c_int, c_void_p, c_float, c_void_p, c_float, c_void_p, c_void_p]),
     "amp_conv_forward_mrf": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_float, c_void_p]),
     "amp_apnet_polar": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "amp_istft_same": (c_int, [POINTER(amp_mel_desc), c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "amp_layer_norm_c": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
     "amp_add_channel_bias": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "amp_layer_norm_c_ragged": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
+    "amp_dwconv_layer_norm_c": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
+    "amp_rel_attention_strided": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "amp_set_rel_attention_tiled": (c_int, [c_int]),
     "amp_rel_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "amp_dwconv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "amp_spline_flow": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -113,6 +118,7 @@ _SIGNATURES = {
     "amp_embed_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "amp_durations": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "amp_expand_path": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "amp_expand_path_strided": (c_int, [c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "amp_gauss_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_void_p, c_void_p]),
     "amp_snake": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "amp_fir_upsample": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
@@ -229,6 +235,12 @@ def require_device_tensor(t, name="tensor"):
 
 
 def current_stream_ptr(device):
+    """the raw hipStream_t of torch's current stream on ``device`` (the private accessor torch's own compiled-graph runtime uses:
+    no Stream object per launch -- the text side of VITS is ~250 launches, all host-bound)"""
     import torch
 
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if raw is not None:
+        idx = device.index if isinstance(device, torch.device) else torch.device(device).index
+        return c_void_p(raw(torch.cuda.current_device() if idx is None else idx))
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)

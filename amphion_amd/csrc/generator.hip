@@ -1094,8 +1094,10 @@ extern "C" {
 
 // 100: round 1; 120: + amp_conv_create_gated / amp_wn_forward / amp_conv_act_forward, switches; 122: + amp_set_conv_blk / _conv_rg_fast /
 // _pingpong; 130 (round 3's ABI, numbered in round 4): amp_mel_desc grew four trailing fields, + amp_resblock_forward /
-// amp_set_resblock_fusion / amp_gen_kernel_name; 140: amp_mel_desc.struct_size, + amp_ampblock_forward / amp_set_ampblock_fusion / amp_mel_init
-int amp_version(void) { return 140; }
+// amp_set_resblock_fusion / amp_gen_kernel_name; 140: amp_mel_desc.struct_size, + amp_ampblock_forward / amp_set_ampblock_fusion / amp_mel_init;
+// 141 (additive): the ragged / fused entry points of the VITS text side (amp_conv_forward_ragged, amp_layer_norm_c_ragged, amp_dwconv_layer_norm_c,
+// amp_rel_attention_strided, amp_set_rel_attention_tiled, amp_expand_path_strided)
+int amp_version(void) { return 141; }
 const char* amp_last_error(void) { return g_err; }
 
 int amp_set_precision(int precision) {
@@ -1786,7 +1788,8 @@ int amp_wn_forward(const amp_conv* const* in_layers, const amp_conv* const* res_
     for (int i = 0; i < n_layers; ++i) {
         ConvArgs a;
         const int ni_in = small_conv_ni(in_layers[i]), ni_rs = small_conv_ni(res_skip_layers[i]);
-        small_args(in_layers[i], x_dev, B, T, nullptr, ni_in, &a);        // in_layers[i](x) + g_l -> tanh * sigmoid (x is masked by the update below / the caller)
+        small_args(in_layers[i], x_dev, B, T, lens_dev, ni_in, &a);       // in_layers[i](x * mask) + g_l -> tanh * sigmoid (round 4: the mask is the kernel's
+                                                                          // select at staging, so the caller's x need not be masked; tiles beyond an end are skipped)
         a.y = acts_ws_dev; a.wn_H = H;
         a.gate_cond = cond_dev ? cond_dev + (size_t)i * 2 * H : nullptr;
         a.gate_cond_bs = cond_batch_stride;
@@ -1834,6 +1837,21 @@ int amp_conv_forward_strided(const amp_conv* c, const float* x_dev, long long x_
     if (!c || !x_dev || !y_dev) { set_error("amp_conv_forward_strided: null argument"); return AMP_ERR_INVALID; }
     if (x_batch_stride < (long long)c->cin * T) { set_error("amp_conv_forward_strided: batch stride %lld < cin*T", x_batch_stride); return AMP_ERR_INVALID; }
     return conv_run(c, x_dev, B, T, slope_in, res_dev, slope_out, y_dev, 0, 1.f, (hipStream_t)stream, x_batch_stride);
+}
+
+// conv(x * mask): the sequence mask of the callers (`conv_1(x * x_mask)`, attentions.py:392-400; DDSConv / WN inputs) taken by the
+// kernel -- columns t >= lens[b] of x count as zero (a select at staging: whatever the buffer holds there, NaN included, is never
+// used) and output tiles that lie wholly beyond an utterance's end are skipped, so columns t >= lens[b] of y are UNSPECIFIED.
+int amp_conv_forward_ragged(const amp_conv* c, const float* x_dev, long long x_batch_stride, int B, int T, const int32_t* lens_dev,
+                            float slope_in, const float* res_dev, float slope_out, float* y_dev, void* stream) {
+    if (!c || !x_dev || !y_dev) { set_error("amp_conv_forward_ragged: null argument"); return AMP_ERR_INVALID; }
+    if (x_dev == y_dev) { set_error("amp_conv_forward_ragged: x and y must not alias (the conv reads a halo)"); return AMP_ERR_INVALID; }
+    if (x_batch_stride != 0 && x_batch_stride < (long long)c->cin * T) { set_error("amp_conv_forward_ragged: batch stride %lld < cin*T", x_batch_stride); return AMP_ERR_INVALID; }
+    if (lens_dev && (c->transposed || c->pad_reflect || conv_out_len(c, T) != T)) {
+        set_error("amp_conv_forward_ragged: valid lengths need a 'same' zero-padded Conv1d (output length == input length)");
+        return AMP_ERR_UNSUPPORTED;
+    }
+    return conv_run(c, x_dev, B, T, slope_in, res_dev, slope_out, y_dev, 0, 1.f, (hipStream_t)stream, x_batch_stride, lens_dev);
 }
 
 int amp_pair_forward(const amp_conv* c1, const amp_conv* c2, const float* x_dev, int B, int T, float slope,

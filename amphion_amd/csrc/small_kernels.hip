@@ -687,8 +687,10 @@ __global__ __launch_bounds__(256) void coupling_kernel(float* __restrict__ x, co
     float* x1 = x + ((size_t)b * 2 * h + h + c) * T;
     const float* mr = m + (size_t)row * T;
     for (int t = tstart; t < tend; t += 256) {
-        const float mk = t < len ? 1.f : 0.f;
-        x1[t] = reverse ? (x1[t] - mr[t]) * mk : mr[t] + x1[t] * mk;
+        // selects, not products with the mask: m may be UNSPECIFIED beyond the length (a ragged conv skips those tiles); for
+        // t < len the bits are those of (x1 - m) * 1 and m + x1 * 1
+        const float v = reverse ? x1[t] - mr[t] : mr[t] + x1[t];
+        x1[t] = t < len ? v : 0.f;
     }
 }
 

@@ -35,12 +35,16 @@ class ResidualCouplingBlock(nn.Module):
         """vits.py:105-112.  ``x_lengths`` replaces the dense ``x_mask``."""
         if x_lengths is not None:
             x_lengths = hip_ops.lens_tensor(x_lengths, x.device)   # once: every flow reuses the device tensor
+        # a coupling layer that follows a Flip works in place on the Flip's output (a fresh tensor): no clone
+        fresh = False
         if not reverse:
             for flow in self.flows:
-                x, _ = flow(x, x_lengths, g=g, reverse=reverse)
+                x, _ = flow(x, x_lengths, g=g, reverse=reverse, **({"owns_input": fresh} if isinstance(flow, ResidualCouplingLayer) else {}))
+                fresh = True
         else:
             for flow in reversed(self.flows):
-                x = flow(x, x_lengths, g=g, reverse=reverse)
+                x = flow(x, x_lengths, g=g, reverse=reverse, **({"owns_input": fresh} if isinstance(flow, ResidualCouplingLayer) else {}))
+                fresh = True
         return x
 
 
@@ -139,8 +143,8 @@ class TextEncoder(nn.Module):
         h = hip_ops.embed_tokens(tokens, w.contiguous(), lens, self.hidden_channels**0.5)   # emb * sqrt(H), [B, H, T], masked
         h = self.encoder(h, lens)
         stats = hip_ops.sequence_mask_(self.proj(h), lens)
-        m, logs = torch.split(stats, self.out_channels, dim=1)
-        return h, m.contiguous(), logs.contiguous(), lens
+        m, logs = torch.split(stats, self.out_channels, dim=1)   # views, as in the reference (:65); expand_path reads them in place
+        return h, m, logs, lens
 
 
 class SynthesizerTrn(nn.Module):

@@ -15,7 +15,8 @@ class LayerNorm(nn.Module):
         self.gamma = nn.Parameter(torch.ones(channels))
         self.beta = nn.Parameter(torch.zeros(channels))
 
-    def forward(self, x, res=None, gelu=False, post=None):
-        """post + act(LN(x + res)): the fusions its callers need (Encoder: norm(x + y); DDSConv: x + gelu(norm(y)))."""
+    def forward(self, x, res=None, gelu=False, post=None, lens=None):
+        """post + act(LN(x + res)): the fusions its callers need (Encoder: norm(x + y); DDSConv: x + gelu(norm(y))).  ``lens``:
+        the result is zero beyond each item's length, whatever x / res hold there."""
         x = _lib.require_device_tensor(x, "LayerNorm input")
-        return hip_ops.layer_norm_c(x, self.gamma.detach(), self.beta.detach(), res=res, post=post, eps=self.eps, gelu=gelu)
+        return hip_ops.layer_norm_c(x, self.gamma.detach(), self.beta.detach(), res=res, post=post, eps=self.eps, gelu=gelu, lens=lens)

@@ -45,9 +45,14 @@ class WN(nn.Module):
             rs_ch = 2 * hidden_channels if i < n_layers - 1 else hidden_channels  # last one is not necessary
             self.res_skip_layers.append(HipConv1d(hidden_channels, rs_ch, 1))
 
-    def forward(self, x, x_lengths=None, g=None, **kwargs):
-        """x [B, H, T] (not modified) -> output [B, H, T] = sum of skips * mask (modules.py:126-151)."""
-        x = _lib.require_device_tensor(x, "WN input").clone()
+    def forward(self, x, x_lengths=None, g=None, owns_input=False, input_masked=True, mask_output=True, **kwargs):
+        """x [B, H, T] (not modified) -> output [B, H, T] = sum of skips * mask (modules.py:126-151).
+        Launch savers for a caller that owns the tensors on both sides (ResidualCouplingLayer): ``owns_input`` lets x be used as
+        the working buffer (it is overwritten), ``input_masked=False`` says x is not zero beyond the lengths (the fused in-layer
+        kernels mask it at staging anyway), ``mask_output=False`` leaves the output beyond the lengths UNSPECIFIED."""
+        x = _lib.require_device_tensor(x, "WN input")
+        if not owns_input:
+            x = x.clone()
         B, H, T = x.shape
         lens = hip_ops.lens_tensor(x_lengths, x.device)
         output = torch.empty_like(x)
@@ -57,9 +62,11 @@ class WN(nn.Module):
         acts = torch.empty_like(x)
         # fused path (f16x3): in_layers[i] + gate in one launch, res_skip_layers[i] + residual / skip update in another
         if self.fused and hip_ops.wn_fused(self.in_layers, self.res_skip_layers, x, cond, lens, output, acts):
-            if lens is not None:
+            if lens is not None and mask_output:
                 hip_ops.sequence_mask_(output, lens)
             return output
+        if lens is not None and not input_masked:
+            hip_ops.sequence_mask_(x, lens)             # the unfused ops read x densely
         x_in = torch.empty((B, 2 * H, T), dtype=torch.float32, device=x.device)
         for i in range(self.n_layers):
             self.in_layers[i](x, out=x_in)
@@ -112,17 +119,18 @@ class ResidualCouplingLayer(nn.Module):
         self.post.weight.data.zero_()  # modules.py:375-376
         self.post.bias.data.zero_()
 
-    def forward(self, x, x_lengths=None, g=None, reverse=False):
-        x = _lib.require_device_tensor(x, "coupling input").clone()
+    def forward(self, x, x_lengths=None, g=None, reverse=False, owns_input=False):
+        """``owns_input``: x is a private tensor of the caller (the output of the preceding Flip) and is updated in place."""
+        x = _lib.require_device_tensor(x, "coupling input")
+        if not owns_input:
+            x = x.clone()
         B, C, T = x.shape
         lens = hip_ops.lens_tensor(x_lengths, x.device)
-        h = self.pre(x, x_batch_stride=C * T, T=T)  # x0 = x[:, :half]
-        if lens is not None:
-            hip_ops.sequence_mask_(h, lens)
-        h = self.enc(h, lens, g=g)     # the device tensor: no second host -> device copy of the lengths
-        m = self.post(h)
-        if lens is not None:
-            hip_ops.sequence_mask_(m, lens)
+        # Round 4: the three `* x_mask` of :381-388 are taken by the kernels instead of three launches -- pre / post skip the tiles
+        # beyond an utterance's end, WN's in-layers mask h at staging, and the coupling update selects on t < len.
+        h = self.pre(x, x_batch_stride=C * T, T=T, lens=lens)  # x0 = x[:, :half]
+        h = self.enc(h, lens, g=g, owns_input=True, input_masked=False, mask_output=False)
+        m = self.post(h, lens=lens)
         hip_ops.coupling_apply_(x, m, lens, reverse)
         if not reverse:
             return x, torch.zeros(B, dtype=x.dtype, device=x.device)  # logdet = sum(logs) = 0 (mean only)
@@ -165,8 +173,12 @@ class DDSConv(nn.Module):
         """:63-72 in eval mode (the optional ``x + g`` of :61-62 is fused into the conv that produces x by the callers)."""
         x = _lib.require_device_tensor(x, "DDSConv input")
         for i in range(self.n_layers):
-            y = self.convs_sep[i](x, lens)                 # conv(x * mask)
-            y = self.norms_1[i](y, gelu=True)
+            sep, n1 = self.convs_sep[i], self.norms_1[i]
+            if sep.weight.shape[-1] == 3:                  # conv(x * mask) -> norm -> gelu in one launch
+                y = hip_ops.dwconv_layer_norm_c(x, sep.weight.detach().contiguous(), sep.bias.detach().contiguous(), sep.dilation,
+                                                n1.gamma.detach(), n1.beta.detach(), lens=lens, eps=n1.eps, gelu=True)
+            else:
+                y = n1(sep(x, lens), gelu=True)
             y = self.convs_1x1[i](y)
             x = self.norms_2[i](y, gelu=True, post=x)      # x + gelu(norm(y))
         return hip_ops.sequence_mask_(x, lens) if lens is not None else x
@@ -216,7 +228,7 @@ class ConvFlow(nn.Module):
         B, _, T = x.shape
         # x0 = the conditioning channel: channel 0, or channel 1 when the preceding Flip is folded in
         x0 = x[:, 1:2] if flip_in else x[:, 0:1]
-        h = self.pre(x0.contiguous(), res=g)                # pre(x0) + g: DDSConv's "x + g" (:61-62) fused into the conv
+        h = self.pre(x0, res=g, x_batch_stride=x.stride(0), T=T)   # pre(x0) + g: DDSConv's "x + g" (:61-62) fused into the conv; x0 read in place
         h = self.convs(h, lens)
         h = self.proj(h)                                    # masked inside the spline kernel (h * x_mask, :428)
         return hip_ops.spline_flow(x, h, lens, self.num_bins, self.filter_channels, self.tail_bound, inverse=reverse,

@@ -36,8 +36,13 @@ class HipConv1d(ConvParams):
         self._fin = None
         self._sig = None
 
+    def _param_sig(self):
+        """identity + version of every parameter (a leaf module: its own ``_parameters`` only -- ``named_parameters()`` walks the
+        module tree with prefixes and costs several microseconds per launch)"""
+        return tuple((n, p.data_ptr(), p._version) for n, p in self._parameters.items() if p is not None)
+
     def _ensure(self, device):
-        sig = tuple((n, p.data_ptr(), p._version) for n, p in self.named_parameters()) + (str(device),)
+        sig = self._param_sig() + (device,)
         if self._h is not None and sig == self._sig:
             return self._h
         if self._fin is not None:
@@ -59,7 +64,7 @@ class HipConv1d(ConvParams):
     def _ensure_gated(self, device):
         """A second handle with the 2H rows packed for the gate epilogue of the fused WN layer
         (``amp_conv_create_gated``); None when this conv / arithmetic is outside what that kernel covers."""
-        sig = tuple((n, p.data_ptr(), p._version) for n, p in self.named_parameters()) + (str(device), _lib.get_precision())
+        sig = self._param_sig() + (device, _lib.get_precision())
         if getattr(self, "_sig_g", None) == sig:
             return self._hg
         if getattr(self, "_fin_g", None) is not None:
@@ -77,8 +82,10 @@ class HipConv1d(ConvParams):
         self._hg, self._fin_g = h, weakref.finalize(self, _destroy_conv, h.value)
         return h
 
-    def forward(self, x, *, slope_in=1.0, res=None, slope_out=1.0, out=None, x_batch_stride=None, T=None):
-        """x [B, cin, T] (or a channel slice of a wider tensor when ``x_batch_stride`` is given)."""
+    def forward(self, x, *, slope_in=1.0, res=None, slope_out=1.0, out=None, x_batch_stride=None, T=None, lens=None):
+        """x [B, cin, T] (or a channel slice of a wider tensor when ``x_batch_stride`` is given).  ``lens`` (int32 [B] on the
+        device): conv(x * mask) with the mask taken by the kernel -- output columns beyond an item's length are UNSPECIFIED
+        (``amp_conv_forward_ragged``)."""
         x = _lib.require_device_tensor(x, "conv input") if x_batch_stride is None else x
         dev = x.device
         B = x.shape[0]
@@ -89,12 +96,60 @@ class HipConv1d(ConvParams):
         if out is None:
             out = torch.empty((B, self.cout, Tout), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            if x_batch_stride is None:
+            if lens is not None:
+                _lib.check(L.amp_conv_forward_ragged(h, _ptr(x), int(x_batch_stride or 0), B, T, _ptr(lens), slope_in, _ptr(res),
+                                                     slope_out, _ptr(out), _lib.current_stream_ptr(dev)))
+            elif x_batch_stride is None:
                 _lib.check(L.amp_conv_forward(h, _ptr(x), B, T, slope_in, _ptr(res), slope_out, _ptr(out),
                                               _lib.current_stream_ptr(dev)))
             else:
                 _lib.check(L.amp_conv_forward_strided(h, _ptr(x), int(x_batch_stride), B, T, slope_in, _ptr(res),
                                                       slope_out, _ptr(out), _lib.current_stream_ptr(dev)))
+        return out
+
+
+class MergedConv1d:
+    """Several ``HipConv1d`` that read the same input (the q / k / v projections of an attention layer), run as ONE launch: their
+    folded weights stacked along the output rows in one handle -> [B, sum(cout), T].  Not a module and it owns no parameters: the
+    convs are passed at every call, this object only caches the packed device copy (rebuilt when a parameter changes; a copy /
+    pickle of the owning module starts with an empty cache)."""
+
+    def __init__(self):
+        self._h = self._fin = self._sig = None
+
+    def __deepcopy__(self, memo):
+        return MergedConv1d()
+
+    def __reduce__(self):
+        return (MergedConv1d, ())
+
+    def _ensure(self, convs, device):
+        sig = tuple(c._param_sig() for c in convs) + (device,)
+        if self._h is not None and sig == self._sig:
+            return self._h
+        c0 = convs[0]
+        if any(c.transposed or (c.cin, c.k, c.stride, c.dilation, c.padding) != (c0.cin, c0.k, c0.stride, c0.dilation, c0.padding)
+               or (c.bias is None) != (c0.bias is None) for c in convs):
+            raise ValueError("MergedConv1d: the convs must be Conv1d of one geometry")
+        if self._fin is not None:
+            self._fin()
+        w = torch.cat([c.folded_weight().detach().to("cpu", torch.float32) for c in convs], dim=0).contiguous()
+        b = torch.cat([c.bias.detach().to("cpu", torch.float32) for c in convs]).contiguous() if c0.bias is not None else None
+        h = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(_lib.lib().amp_conv_create(0, c0.cin, w.shape[0], c0.k, c0.stride, c0.dilation, c0.padding, _ptr(w), _ptr(b),
+                                                  ctypes.byref(h)))
+        self._h, self._fin, self._sig = h, weakref.finalize(self, _destroy_conv, h.value), sig
+        return h
+
+    def __call__(self, convs, x, lens=None):
+        x = _lib.require_device_tensor(x, "conv input")
+        B, _, T = x.shape
+        h = self._ensure(convs, x.device)
+        out = torch.empty((B, sum(c.cout for c in convs), T), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().amp_conv_forward_ragged(h, _ptr(x), 0, B, T, _ptr(lens), 1.0, None, 1.0, _ptr(out),
+                                                          _lib.current_stream_ptr(x.device)))
         return out
 
 
@@ -115,7 +170,8 @@ def wn_fused(in_layers, res_skip_layers, x, cond, lens, out, acts):
     hi, hr = [], []
     for i in range(n):
         rs = res_skip_layers[i]
-        if rs.k != 1 or rs.cin != H or rs.cout != (2 * H if i < n - 1 else H) or rs.bias is None or rs.transposed or rs.tanh or rs.pad_mode != "zeros":
+        if (rs.k != 1 or rs.cin != H or rs.cout != (2 * H if i < n - 1 else H) or rs.cout <= 64 or rs.bias is None or rs.transposed or rs.tanh
+                or rs.pad_mode != "zeros"):      # cout <= 64: fewer than the 128 rows the whole-K kernel's workgroups cover (H <= 64)
             return False
         g = in_layers[i]._ensure_gated(dev)
         if g is None:
@@ -181,12 +237,26 @@ def _stream(t):
     return _lib.current_stream_ptr(t.device)
 
 
-def layer_norm_c(x, gamma, beta, res=None, post=None, eps=1e-5, gelu=False):
-    """post + act(LN(x + res)) over the channel axis"""
+def layer_norm_c(x, gamma, beta, res=None, post=None, eps=1e-5, gelu=False, lens=None):
+    """post + act(LN(x + res)) over the channel axis; with ``lens`` the columns beyond an item's length are written as zero
+    (whatever x / res hold there)"""
     B, C, T = x.shape
     y = torch.empty_like(x)
-    _lib.check(_lib.lib().amp_layer_norm_c(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(post), B, C, T, float(eps), int(gelu), _ptr(y),
-                                           _stream(x)))
+    if lens is None:
+        _lib.check(_lib.lib().amp_layer_norm_c(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(post), B, C, T, float(eps), int(gelu),
+                                               _ptr(y), _stream(x)))
+    else:
+        _lib.check(_lib.lib().amp_layer_norm_c_ragged(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(post), _ptr(lens), B, C, T,
+                                                      float(eps), int(gelu), _ptr(y), _stream(x)))
+    return y
+
+
+def dwconv_layer_norm_c(x, weight, bias, dilation, gamma, beta, lens=None, eps=1e-5, gelu=False):
+    """act(LN(dwconv(x * mask))) in one launch (DDSConv's convs_sep + norms_1, modules/flow/modules.py:63-65); K = 3"""
+    B, C, T = x.shape
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().amp_dwconv_layer_norm_c(_ptr(x), _ptr(weight), _ptr(bias), weight.shape[-1], int(dilation), _ptr(gamma),
+                                                  _ptr(beta), _ptr(lens), B, C, T, float(eps), int(gelu), _ptr(y), _stream(x)))
     return y
 
 
@@ -202,6 +272,19 @@ def rel_attention(q, k, v, emb_k, emb_v, lens, n_heads, window):
     out = torch.empty_like(q)
     _lib.check(_lib.lib().amp_rel_attention(_ptr(q), _ptr(k), _ptr(v), _ptr(emb_k), _ptr(emb_v), _ptr(lens), B, n_heads, C // n_heads, T,
                                             int(window), _ptr(out), _stream(q)))
+    return out
+
+
+def rel_attention_qkv(qkv, emb_k, emb_v, lens, n_heads, window):
+    """the same on the output [B, 3C, T] of a merged q | k | v projection (no copies: the three slices share a batch stride)"""
+    B, C3, T = qkv.shape
+    C = C3 // 3
+    out = torch.empty((B, C, T), dtype=torch.float32, device=qkv.device)
+    p = qkv.data_ptr()
+    step = C * T * 4
+    _lib.check(_lib.lib().amp_rel_attention_strided(ctypes.c_void_p(p), ctypes.c_void_p(p + step), ctypes.c_void_p(p + 2 * step), C3 * T,
+                                                    _ptr(emb_k), _ptr(emb_v), _ptr(lens), B, n_heads, C // n_heads, T, int(window),
+                                                    _ptr(out), _stream(qkv)))
     return out
 
 
@@ -246,10 +329,15 @@ def durations(logw, lens, length_scale):
 
 
 def expand_path(src, cum, xlens, ylens, t_y, want_attn=False):
+    """src [B, D, Tx]: contiguous, or a channel slice of a wider [B, D', Tx] tensor (the halves of the text encoder's stats) --
+    read in place through its batch stride"""
     B, D, Tx = src.shape
+    if src.stride(2) != 1 or src.stride(1) != Tx or (B > 1 and src.stride(0) < D * Tx):
+        src = src.contiguous()
     out = torch.empty((B, D, t_y), dtype=torch.float32, device=src.device)
     attn = torch.empty((B, 1, t_y, Tx), dtype=torch.float32, device=src.device) if want_attn else None
-    _lib.check(_lib.lib().amp_expand_path(_ptr(src), _ptr(cum), _ptr(xlens), _ptr(ylens), B, D, Tx, int(t_y), _ptr(out), _ptr(attn), _stream(src)))
+    _lib.check(_lib.lib().amp_expand_path_strided(_ptr(src), int(src.stride(0)) if B > 1 else D * Tx, _ptr(cum), _ptr(xlens), _ptr(ylens), B, D,
+                                                  Tx, int(t_y), _ptr(out), _ptr(attn), _stream(src)))
     return out, attn
 
 

@@ -87,7 +87,8 @@ typedef struct amp_gen amp_gen;
  * amp_set_conv_blk / amp_set_conv_rg_fast / amp_set_pingpong; 130 (round 3) appended the four range_* fields to amp_mel_desc and
  * added amp_resblock_forward / amp_set_resblock_fusion / amp_gen_kernel_name; 140 (round 4): amp_mel_desc starts with struct_size
  * (an ABI break for every earlier consumer of that struct -- re-compile against this header), + amp_mel_init,
- * amp_ampblock_forward, amp_set_ampblock_fusion. */
+ * amp_ampblock_forward, amp_set_ampblock_fusion; 141 (additive): amp_conv_forward_ragged, amp_layer_norm_c_ragged,
+ * amp_dwconv_layer_norm_c, amp_rel_attention_strided, amp_set_rel_attention_tiled, amp_expand_path_strided. */
 int amp_version(void);
 const char* amp_last_error(void);
 /* Number of HIP devices visible (0 when there is no GPU); never fails. */
@@ -194,6 +195,13 @@ int amp_conv_forward(const amp_conv* c, const float* x_dev, int B, int T, float 
  * (elements).  Used by ResidualCouplingLayer.pre on x0 = x[:, :half] (modules/flow/modules.py:380-381). */
 int amp_conv_forward_strided(const amp_conv* c, const float* x_dev, long long x_batch_stride, int B, int T,
                              float slope_in, const float* res_dev, float slope_out, float* y_dev, void* stream);
+/* conv(x * mask) with the sequence mask taken by the kernel (`conv_1(x * x_mask)`, modules/transformer/attentions.py:392-400;
+ * `pre(x0) * x_mask`, modules/flow/modules.py:381): lens_dev int32 [B] valid lengths or NULL; input columns t >= lens[b] count
+ * as zero whatever the buffer holds (a select, NaN-safe); output tiles wholly beyond an utterance's end are skipped, so columns
+ * t >= lens[b] of y_dev are UNSPECIFIED (assign, do not multiply).  'same' zero-padded Conv1d only when lens_dev is given.
+ * x_batch_stride 0 = cin*T. */
+int amp_conv_forward_ragged(const amp_conv* c, const float* x_dev, long long x_batch_stride, int B, int T, const int32_t* lens_dev,
+                            float slope_in, const float* res_dev, float slope_out, float* y_dev, void* stream);
 /* amp_conv_forward with the MRF accumulation of hifigan.py:208-214 / apnet.py:355-363 exposed:
  *   v = conv(lrelu_in(x)) + bias (+ res);   mode 0: y = v   1: y = y + v   2: y = (y + v) / div. */
 int amp_conv_forward_mrf(const amp_conv* c, const float* x_dev, int B, int T, float slope_in, const float* res_dev,
@@ -225,6 +233,17 @@ int amp_fir_filter(const float* x_dev, int B, int C, int T, const float* filt_ho
  * modules/flow/modules.py:64-70: x = x + gelu(norm(y))). */
 int amp_layer_norm_c(const float* x_dev, const float* res_dev, const float* gamma_dev, const float* beta_dev,
                      const float* post_dev, int B, int C, int T, float eps, int gelu, float* y_dev, void* stream);
+/* amp_layer_norm_c whose result is ZERO in the columns t >= lens[b] (a select: x / res may hold anything there) -- the `* x_mask`
+ * that follows the Encoder's norms (attentions.py:64-76) without its own launch. */
+int amp_layer_norm_c_ragged(const float* x_dev, const float* res_dev, const float* gamma_dev, const float* beta_dev,
+                            const float* post_dev, const int* lens_dev, int B, int C, int T, float eps, int gelu, float* y_dev,
+                            void* stream);
+/* act(LN(dwconv(x * mask))) in one launch: DDSConv's convs_sep[i] -> norms_1[i] -> gelu (modules/flow/modules.py:63-65), the
+ * depthwise taps evaluated on load in amp_dwconv's order (same bits as the two launches).  K = 3 (AMP_ERR_INVALID otherwise: run
+ * amp_dwconv + amp_layer_norm_c); dw_weight [C, 1, K], dw_bias [C] or NULL; columns t >= lens[b] of y are zero; y != x. */
+int amp_dwconv_layer_norm_c(const float* x_dev, const float* dw_weight_dev, const float* dw_bias_dev, int K, int dilation,
+                            const float* gamma_dev, const float* beta_dev, const int* lens_dev, int B, int C, int T, float eps,
+                            int gelu, float* y_dev, void* stream);
 /* x[b, c, :] += cb[b, c]: the broadcast add of a length-1 condition, x + cond(g) (hifigan.py:426-427,
  * stochastic_duration_predictor.py:64-66). */
 int amp_add_channel_bias(float* x_dev, const float* cb_dev, int B, int C, int T, void* stream);
@@ -233,6 +252,13 @@ int amp_add_channel_bias(float* x_dev, const float* cb_dev, int B, int C, int T,
 int amp_rel_attention(const float* q_dev, const float* k_dev, const float* v_dev, const float* emb_k_dev,
                       const float* emb_v_dev, const int* lens_dev, int B, int H, int dk, int T, int window, float* out_dev,
                       void* stream);
+/* The same with q / k / v given as slices of ONE tensor (the merged q|k|v projection [B, 3*H*dk, T]): element (b, c, t) of each
+ * at ptr[b*qkv_batch_stride + c*T + t]; out stays [B, H*dk, T] dense. */
+int amp_rel_attention_strided(const float* q_dev, const float* k_dev, const float* v_dev, long long qkv_batch_stride,
+                              const float* emb_k_dev, const float* emb_v_dev, const int* lens_dev, int B, int H, int dk, int T,
+                              int window, float* out_dev, void* stream);
+/* 1 (default): blocks of 16 queries share the keys / values staged in LDS; 0: one workgroup per query (rounds 2-3).  Same bits. */
+int amp_set_rel_attention_tiled(int on);
 /* Depthwise dilated Conv1d of x * mask, padding (K*d - d)/2 (DDSConv.convs_sep, modules/flow/modules.py:46-56,63);
  * w [C, 1, K], bias [C] or NULL. */
 int amp_dwconv(const float* x_dev, const float* w_dev, const float* bias_dev, const int* lens_dev, int B, int C, int T, int K,
@@ -258,6 +284,10 @@ int amp_durations(const float* logw_dev, const int* lens_dev, int B, int T, floa
  * utils/util.py:625-640, vits.py:345-353); attn_dev [B, 1, Ty, Tx] receives the path itself when not NULL. */
 int amp_expand_path(const float* src_dev, const int* cum_dev, const int* xlens_dev, const int* ylens_dev, int B, int D, int Tx,
                     int Ty, float* out_dev, float* attn_dev, void* stream);
+/* The same with src a channel slice of a wider tensor (m / logs = the halves of the text encoder's stats, vits.py:65): element
+ * (b, d, x) at src_dev[b*src_batch_stride + d*Tx + x]. */
+int amp_expand_path_strided(const float* src_dev, long long src_batch_stride, const int* cum_dev, const int* xlens_dev,
+                            const int* ylens_dev, int B, int D, int Tx, int Ty, float* out_dev, float* attn_dev, void* stream);
 /* z_p = m + noise * exp(logs) * noise_scale over n elements (vits.py:355). */
 int amp_gauss_sample(const float* m_dev, const float* logs_dev, const float* noise_dev, size_t n, float noise_scale,
                      float* out_dev, void* stream);
