@@ -332,6 +332,7 @@ struct Config {
     int pingpong = 1;
     int fuse_act = 0;
     int narrow_blk = 1;        // row-blocked conv kernel for 128- / 64-row convs (amp_set_conv_blk_narrow)
+    int rb_streams = -1;       // resblocks of a stage on concurrent streams: -1 small launches only, 0 never, 1 always (amp_set_resblock_streams)
     Config() {
         auto num = [](const char* name, int lo, int hi, int dflt) {
             const char* e = getenv(name);
@@ -344,6 +345,7 @@ struct Config {
         rb_fusion = num("AMP_RB_FUSION", 0, 3, 1);
         ampb_fusion = num("AMP_AMPB_FUSION", 0, 3, 1);
         conv_blk = num("AMP_CONV_BLK", 0, 3, kConvBlkDefault);
+        rb_streams = num("AMP_RB_STREAMS", -1, 1, -1);
         const char* e = getenv("AMP_GROUP_MB");
         group_bytes = (e && atol(e) > 0) ? (size_t)atol(e) << 20 : 0;
     }
@@ -1029,8 +1031,13 @@ struct amp_gen {
     std::vector<ProfSlot> prof;          // empty = profiling off
     size_t prof_count = 0;               // forwards recorded so far
     RangeGuard guard;                    // this handle's f16 operand-range word (allocated by finalize on its device)
+    // concurrent resblocks (small launches): n_kernels - 1 side streams, per stage one fork event and n_kernels - 1 join events
+    std::vector<hipStream_t> side;
+    std::vector<hipEvent_t> ev_side;
     ~amp_gen() {
         guard_free(guard);
+        for (auto s_ : side) (void)hipStreamDestroy(s_);
+        for (auto e : ev_side) (void)hipEventDestroy(e);
         for (float* p : dev_allocs) (void)hipFree(p);
         for (auto& p : prof) {
             if (p.ev_begin) (void)hipEventDestroy(p.ev_begin);
@@ -1363,9 +1370,28 @@ static size_t gen_buf_elems(const amp_gen* g, int B, int T) {
     return (mx + 63) & ~(size_t)63;
 }
 
-// scratch tensors of a forward: X, XS, U, R, TMP (+ ACT for BigVGAN).  (Round 2 also ran BigVGAN's resblocks of a stage on concurrent
-// streams: the kernels overlapped and the forward took the same 28.1 ms, profiles/r2_i_bigvgan_streams.txt -- removed.)
+// scratch tensors of a forward: X, XS, U, R, TMP (+ ACT for BigVGAN).
 static int gen_num_bufs(const amp_gen* g) { return g->d.arch == AMP_ARCH_BIGVGAN ? 6 : 5; }
+
+// Concurrent resblocks.  The n_kernels resblocks of a stage read the same U and are independent until the MRF mean; run one after
+// the other each of them is a chain of 1-9 dependent launches, and for a single utterance no launch fills the chip (a 3-s utterance:
+// 50-300 workgroups per launch on 256 CUs, 52 launches back to back = 1.06 ms that a hipGraph replay does not shorten -- the chain
+// is serialised on the GPU, not by the host).  In this mode resblocks 1 .. n - 1 run on streams of their own with their own R / TMP
+// (/ ACT) buffers and the first one stays on the caller's stream; only the LAST launch of each resblock -- the one that accumulates
+// into XS -- is ordered after the last launch of resblock j - 1 (an event) and keeps its sequential `=` / `+=` / `(y + v) / n` mode,
+// so every sum is formed by the same kernel in the same
+// order and the bits do not change (tests/test_gpu_resblock.py).  (A post-hoc mean of separately stored results would not do: the
+// conv kernels add y into the accumulator BEFORE the products.)  Policy (amp_set_resblock_streams(-1) / AMP_RB_STREAMS unset): only
+// while B * T <= kRbStreamsMaxFrames mel frames; at full batches every launch fills the chip and the same idea measured 28.1 vs
+// 28.1 ms (round 2, BigVGAN, profiles/r2_i_bigvgan_streams.txt).  Works under stream capture (fork / join by events) once the side
+// streams exist: they are created by the first eager forward or by amp_gen_prepare_streams(), never inside a capture.
+constexpr long long kRbStreamsMaxFrames = 1024;
+static int gen_side_bufs(const amp_gen* g) { return (g->d.n_kernels - 1) * (g->d.arch == AMP_ARCH_BIGVGAN ? 3 : 2); }   // R, TMP (+ ACT) per extra resblock
+static bool gen_streams_wanted(const amp_gen* g, int B, int T) {
+    if (g->d.n_kernels < 2) return false;
+    const int m = cfg().rb_streams;
+    return m == 1 || (m < 0 && (long long)B * T <= kRbStreamsMaxFrames);
+}
 
 // Optional depth-first batch grouping: a group of items runs through the WHOLE generator before the
 // next one starts, with a working set (the scratch tensors of its largest stage) bounded by
@@ -1388,7 +1414,8 @@ static int gen_group_items(const amp_gen* g, int B, int T) {
 size_t amp_gen_workspace_bytes(const amp_gen* g, int B, int T) {
     if (!g || B <= 0 || T <= 0) return 0;
     const int G = gen_group_items(g, B, T);
-    return gen_buf_elems(g, G, T) * sizeof(float) * gen_num_bufs(g) + (size_t)G * g->d.upsample_initial_channel * sizeof(float) + 256;
+    const int nb = gen_num_bufs(g) + ((G == B && gen_streams_wanted(g, B, T)) ? gen_side_bufs(g) : 0);
+    return gen_buf_elems(g, G, T) * sizeof(float) * nb + (size_t)G * g->d.upsample_initial_channel * sizeof(float) + 256;
 }
 
 int amp_set_pair_strips(int on) {
@@ -1486,7 +1513,8 @@ int amp_gen_kernel_name(amp_gen* g, int back, int which, char* buf, size_t n) {
 static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond_dev, const int* lens, int B, int T,
                              float* wav_dev, float* base, size_t be, hipStream_t st,
                              hipEvent_t* ev_mrf /* 2 per stage, or null */, hipEvent_t* ev_rb /* (n_kernels+1) per stage */,
-                             std::vector<std::string>* rb_names = nullptr /* per (stage, resblock), or null */) {
+                             std::vector<std::string>* rb_names = nullptr /* per (stage, resblock), or null */,
+                             bool conc = false /* resblocks of a stage on g->side streams (the buffers behind the regular ones exist) */) {
     const amp_gen_desc& d = g->d;
     const bool big = d.arch == AMP_ARCH_BIGVGAN;
     float* X = base;            // stage input / MRF accumulator (ping-pong with XS)
@@ -1495,7 +1523,9 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
     float* R = base + 3 * be;   // running x inside a resblock
     float* TMP = base + 4 * be; // xt between the two convs of a pair
     float* ACT = big ? base + 5 * be : nullptr;  // anti-aliased activation output
-    float* CB = base + (size_t)gen_num_bufs(g) * be;  // cond(g): [B, C0]
+    float* SIDE = base + (size_t)gen_num_bufs(g) * be;   // concurrent mode: R, TMP (+ ACT) of resblocks 1 .. n_kernels - 1
+    const int side_per = big ? 3 : 2;
+    float* CB = base + (size_t)(gen_num_bufs(g) + (conc ? gen_side_bufs(g) : 0)) * be;  // cond(g): [B, C0]
     const float slope = 0.1f;  // LRELU_SLOPE hifigan.py:14
 
     AMP_RC(conv_run(g->conv_pre.get(), mel_dev, B, T, 1.f, nullptr, 1.f, X, 0, 1.f, st, 0, lens, 1));
@@ -1513,12 +1543,29 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
         t *= d.upsample_rates[i];
         lm *= d.upsample_rates[i];
         if (ev_mrf) AMP_HIP(hipEventRecord(ev_mrf[2 * i], st));
+        // concurrent mode: resblock 0 on `st`, resblocks 1 .. nk - 1 on the side streams.  evs[0] fork, evs[1 + j] = resblock j's
+        // accumulating launch done; the launch that accumulates resblock j >= 1 waits for evs[j], `st` joins on evs[nk].  (Measured
+        // the other way round too -- the widest resblock on `st`, the others on the side streams: the same 0.81-0.83 ms as a graph
+        // replay, but 1.08 instead of 0.90-0.95 ms eager, where the host issues the critical stream's launches last.)
+        hipEvent_t* evs = conc ? &g->ev_side[(size_t)i * (nk + 1)] : nullptr;
+        if (conc) {
+            AMP_HIP(hipEventRecord(evs[0], st));
+            for (int j = 1; j < nk; ++j) AMP_HIP(hipStreamWaitEvent(g->side[j - 1], evs[0], 0));
+        }
         for (int j = 0; j < nk; ++j) {
-            hipStream_t sj = st;
-            float* R_ = R;
-            float* TMP_ = TMP;
-            float* ACT_ = ACT;
+            const bool on_side = conc && j > 0;
+            hipStream_t sj = on_side ? g->side[j - 1] : st;
+            float* SB = SIDE + (size_t)(on_side ? j - 1 : 0) * side_per * be;
+            float* R_ = on_side ? SB : R;
+            float* TMP_ = on_side ? SB + be : TMP;
+            float* ACT_ = (on_side && big) ? SB + 2 * be : ACT;
+            // called right before the launch that writes XS: it reads what resblock j - 1 accumulated there
+            auto before_last = [&]() -> int {
+                if (conc && j > 0) AMP_HIP(hipStreamWaitEvent(sj, evs[j], 0));
+                return AMP_OK;
+            };
             if (ev_rb) AMP_HIP(hipEventRecord(ev_rb[(size_t)i * (nk + 1) + j], sj));
+            auto resblock = [&]() -> int {
             // profiled forward: every launch of this resblock logs its kernel's name (note_kernel, amp_internal.h)
             struct LogScope { LogScope(std::string* p) { tl_kernel_log = p; if (p) p->clear(); } ~LogScope() { tl_kernel_log = nullptr; } }
                 log_scope(rb_names ? &(*rb_names)[(size_t)i * nk + j] : nullptr);
@@ -1528,16 +1575,18 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
             const float* cur = U;
             if (d.resblock_type == 1 && !big && rb_supported(rb.c1, rb.c2, B, t)) {
                 // the whole resblock in one launch: U -> XS (x and the residual never leave the CU in between)
+                AMP_RC(before_last());
                 AMP_RC(rb_run(rb.c1, rb.c2, U, B, t, slope, XS, mode_last, (float)nk, sj, lens, lm));
-                continue;
+                return AMP_OK;
             }
             if (d.resblock_type == 1 && big && nd <= AMP_AMPB_MAX_STEPS / 2) {
                 const amp_conv *p1[AMP_AMPB_MAX_STEPS / 2], *p2[AMP_AMPB_MAX_STEPS / 2];
                 for (int p = 0; p < nd; ++p) { p1[p] = rb.c1[p].get(); p2[p] = rb.c2[p].get(); }
                 if (ampb_supported(p1, p2, nd, rb.acts.data(), rb.acts.size(), B, t)) {
                     // the whole AMPBlock in one launch: U -> XS (bigvgan.py:137-146)
+                    AMP_RC(before_last());
                     AMP_RC(ampb_run(p1, p2, nd, rb.acts.data(), U, B, t, XS, mode_last, (float)nk, sj, lens, lm));
-                    continue;
+                    return AMP_OK;
                 }
             }
             for (int p = 0; p < nd; ++p) {
@@ -1547,6 +1596,7 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
                         // the whole pair in one kernel; the output ping-pongs R_ <-> TMP_ (never in place:
                         // other tiles still read the input's halo)
                         float* dst = last ? XS : (cur == R_ ? TMP_ : R_);
+                        if (last) AMP_RC(before_last());
                         AMP_RC(pair_run(rb.c1[p].get(), rb.c2[p].get(), cur, B, t, slope, dst, last ? mode_last : 0, (float)nk, sj, lens, lm));
                         cur = dst;
                     } else if (!big) {
@@ -1557,7 +1607,7 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
                         }
                         AMP_RC(conv_run(rb.c1[p].get(), cur, B, t, slope, nullptr, slope, TMP_, 0, 1.f, sj, 0, lens, lm));
                         if (!last) { AMP_RC(conv_run(rb.c2[p].get(), TMP_, B, t, 1.f, cur, 1.f, R_, 0, 1.f, sj, 0, lens, lm)); cur = R_; }
-                        else AMP_RC(conv_run(rb.c2[p].get(), TMP_, B, t, 1.f, cur, 1.f, XS, mode_last, (float)nk, sj, 0, lens, lm));
+                        else { AMP_RC(before_last()); AMP_RC(conv_run(rb.c2[p].get(), TMP_, B, t, 1.f, cur, 1.f, XS, mode_last, (float)nk, sj, 0, lens, lm)); }
                     } else {
                         // xt = c2(a2(c1(a1(x)))) ; x = xt + x              bigvgan.py:137-146
                         const ActParams& a1 = rb.acts[2 * p];
@@ -1577,7 +1627,7 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
                             AMP_HIP(launch_act1d(TMP_, ACT_, B, C, t, a2.a_dev, a2.invb_dev, a2.fu_dev, a2.fd_dev, lens, lm, sj, next_rev(lens)));
                         }
                         if (!last) { AMP_RC(conv_run(rb.c2[p].get(), c2_in, B, t, 1.f, cur, 1.f, R_, 0, 1.f, sj, 0, lens, lm)); cur = R_; }
-                        else AMP_RC(conv_run(rb.c2[p].get(), c2_in, B, t, 1.f, cur, 1.f, XS, mode_last, (float)nk, sj, 0, lens, lm));
+                        else { AMP_RC(before_last()); AMP_RC(conv_run(rb.c2[p].get(), c2_in, B, t, 1.f, cur, 1.f, XS, mode_last, (float)nk, sj, 0, lens, lm)); }
                     }
                 } else {
                     // x = c(act(x)) + x                                    hifigan.py:140-145, bigvgan.py:218-224
@@ -1595,11 +1645,17 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
                         AMP_RC(conv_run(rb.c1[p].get(), in, B, t, sl, cur, 1.f, dst, 0, 1.f, sj, 0, lens, lm));
                         cur = dst;
                     } else {
+                        AMP_RC(before_last());
                         AMP_RC(conv_run(rb.c1[p].get(), in, B, t, sl, cur, 1.f, XS, mode_last, (float)nk, sj, 0, lens, lm));
                     }
                 }
             }
+            return AMP_OK;
+            };
+            AMP_RC(resblock());
+            if (conc) AMP_HIP(hipEventRecord(evs[1 + j], sj));
         }
+        if (conc) AMP_HIP(hipStreamWaitEvent(st, evs[nk], 0));   // join: the last resblock's accumulating launch follows all the others
         if (ev_rb) AMP_HIP(hipEventRecord(ev_rb[(size_t)i * (nk + 1) + nk], st));
         if (ev_mrf) AMP_HIP(hipEventRecord(ev_mrf[2 * i + 1], st));
         float* tmp = X; X = XS; XS = tmp;  // x = xs / num_kernels
@@ -1611,6 +1667,39 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
         // F.leaky_relu(x) with the DEFAULT slope 0.01 (hifigan.py:215,439), conv_post, tanh
         AMP_HIP(launch_conv_post(X, g->post_w_dev, g->post_b_dev, wav_dev, B, g->post_cin, t, 7, 0.01f, 1, lens, lm, st));
     }
+    return AMP_OK;
+}
+
+// The side streams and fork / join events of the concurrent-resblock mode; false when they do not exist and cannot be created now
+// (`st` is being captured: hipStreamCreate is not a capturable call -- the forward then runs the sequential chain, same bits).
+static bool gen_ensure_side(amp_gen* g, hipStream_t st) {
+    const size_t ns = (size_t)g->d.n_kernels - 1, ne = (size_t)g->d.n_stages * (g->d.n_kernels + 1);
+    if (g->side.size() == ns && g->ev_side.size() == ne) return true;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return false; }
+    while (g->side.size() < ns) {
+        hipStream_t s_ = nullptr;
+        if (hipStreamCreateWithFlags(&s_, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return false; }
+        g->side.push_back(s_);
+    }
+    while (g->ev_side.size() < ne) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+        g->ev_side.push_back(e);
+    }
+    return true;
+}
+
+int amp_set_resblock_streams(int mode) {
+    if (mode < -1 || mode > 1) { set_error("amp_set_resblock_streams: mode=%d", mode); return AMP_ERR_INVALID; }
+    cfg().rb_streams = mode;
+    return AMP_OK;
+}
+
+int amp_gen_prepare_streams(amp_gen* g) {
+    if (!g || !g->finalized) { set_error("amp_gen_prepare_streams: null or unfinalized handle"); return AMP_ERR_STATE; }
+    if (g->d.n_kernels < 2) return AMP_OK;
+    if (!gen_ensure_side(g, nullptr)) { set_error("amp_gen_prepare_streams: could not create the side streams"); return AMP_ERR_HIP; }
     return AMP_OK;
 }
 
@@ -1635,6 +1724,9 @@ int amp_gen_forward_ragged(amp_gen* g, const float* mel_dev, const float* cond_d
     const size_t be = gen_buf_elems(g, G, T);
     const size_t L = (size_t)T * g->hop;
     amp_gen::ProfSlot* ps = g->prof.empty() ? nullptr : &g->prof[g->prof_count % g->prof.size()];
+    // concurrent resblocks: small launches, the whole batch in one group, not while the per-resblock events are being recorded (they
+    // time one resblock after the other on `st`)
+    const bool conc = ngroups == 1 && !ps && gen_streams_wanted(g, B, T) && gen_ensure_side(g, st);
     if (ps) {
         const size_t need = 2 * (size_t)d.n_stages * ngroups;
         while (ps->ev_mrf.size() < need) {
@@ -1661,7 +1753,7 @@ int amp_gen_forward_ragged(amp_gen* g, const float* mel_dev, const float* cond_d
                                  wav_dev + (size_t)b0 * L, (float*)workspace_dev, be, st,
                                  ps ? ps->ev_mrf.data() + 2 * (size_t)d.n_stages * gi : nullptr,
                                  ps ? ps->ev_rb.data() + (size_t)d.n_stages * (d.n_kernels + 1) * gi : nullptr,
-                                 (ps && gi == 0) ? &ps->rb_kernels : nullptr));
+                                 (ps && gi == 0) ? &ps->rb_kernels : nullptr, conc));
     }
     if (ps) { AMP_HIP(hipEventRecord(ps->ev_end, st)); ps->valid = true; ++g->prof_count; }
     AMP_RC(range_publish(&g->guard, st));

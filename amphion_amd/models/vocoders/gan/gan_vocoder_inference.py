@@ -50,6 +50,13 @@ def _crops_to_host(model, out, lengths):
         return [host[i, : int(l)].clone() for i, l in enumerate(lengths)]
 
 
+def _ragged(model, batch, lens):
+    """forward_ragged, through the generator's cached hipGraph when the batch is small enough for one to pay (same bits)"""
+    if hasattr(model, "forward_graphed"):
+        return model.forward_graphed(batch, lens)
+    return model.forward_ragged(batch, lens)
+
+
 def vocoder_inference(cfg, model, mels, f0s=None, device=None, fast_inference=False):
     """gan_vocoder_inference.py:11-38.  mels [B, n_mel, T] -> audios [B, T*hop] on the CPU."""
     model.eval()
@@ -60,6 +67,8 @@ def vocoder_inference(cfg, model, mels, f0s=None, device=None, fast_inference=Fa
 
         def run():
             if f0s is None and not cfg.preprocess.extract_amplitude_phase:
+                if hasattr(model, "forward_graphed"):      # small batches of a repeated shape: a cached hipGraph (same bits)
+                    return model.forward_graphed(mels)
                 return model.forward(mels)
             if cfg.preprocess.extract_amplitude_phase:
                 return model.forward(mels)[4]
@@ -106,7 +115,7 @@ def _synthesis_audios(cfg, model, mels, f0s, batch_size, fast_inference, ragged)
                 for r, i in enumerate(grp):
                     batch[r, :, : lens[r]] = torch.as_tensor(mels[i], dtype=torch.float32)
                 batch = batch.to(device)
-                out = _reference_range(model, lambda: model.forward_ragged(batch, lens), device).squeeze(1)
+                out = _reference_range(model, lambda: _ragged(model, batch, lens), device).squeeze(1)
                 for i, a in zip(grp, _crops_to_host(model, out, [l * hop for l in lens])):
                     audios[i] = a
         return audios
@@ -133,7 +142,7 @@ def _synthesis_audios(cfg, model, mels, f0s, batch_size, fast_inference, ragged)
             model.eval()
             with torch.no_grad():
                 mel_dev = mel_batch.to(device)
-                out = _reference_range(model, lambda: model.forward_ragged(mel_dev, ext), device).squeeze(1)
+                out = _reference_range(model, lambda: _ragged(model, mel_dev, ext), device).squeeze(1)
             for a in _crops_to_host(model, out, [int(f) * hop for f in mel_frame]):
                 audios[k] = a
                 k += 1

@@ -335,6 +335,15 @@ int amp_resblock_forward(const amp_conv* const* c1, const amp_conv* const* c2, i
  * late stages when the launch fills the chip); 2: wherever the kernel is built, any grid; 3: as 2 with the four-wave
  * 512-column tiles at C = 32.  Bit-identical results in every mode (tests/test_gpu_resblock.py); env AMP_RB_FUSION. */
 int amp_set_resblock_fusion(int mode);
+/* The n_kernels resblocks of a generator stage on CONCURRENT streams (they read the same stage tensor and only meet in the MRF mean,
+ * hifigan.py:208-214 / bigvgan.py:320-327): -1 (default) while B * T <= 1024 mel frames -- single utterances, whose launches do not
+ * fill the chip and whose forward is a chain of ~50 dependent launches; 0 never; 1 always.  Only the launch of each resblock that
+ * accumulates into the mean waits for the previous resblock's (an event) and keeps its `=` / `+=` / `(y + v) / n` form: bit-identical
+ * results in every mode.  amp_gen_workspace_bytes accounts for the extra R / TMP buffers; the side streams fork from and join
+ * `stream` by events (legal under stream capture).  They are created by the first uncaptured forward or by amp_gen_prepare_streams
+ * -- a forward captured before either runs the sequential chain.  Not used while amp_gen_set_profiling is on.  Env AMP_RB_STREAMS. */
+int amp_set_resblock_streams(int mode);
+int amp_gen_prepare_streams(amp_gen* g);
 
 /* AMPBlock1.forward of BigVGAN (bigvgan.py:137-146) in ONE launch:
  *     for p < n_pairs:  x = x + c2[p]( a[2p+1]( c1[p]( a[2p](x) ) ) ),   a[i] = Activation1d(Snake | SnakeBeta)

@@ -152,6 +152,49 @@ def test_hipgraph_capture_survives_other_shapes_and_refuses_stale_weights():
         assert torch.equal(out2, m(mel))
 
 
+def test_forward_graphed_buckets_replay_bit_identically_and_follow_the_weights():
+    """forward_graphed: the second call of a (B, 32-frame bucket) captures a ragged graph, later calls of ANY length in the bucket
+    replay it -- bit-identical to the eager forward of each utterance; a weight change drops the cache instead of replaying stale
+    weights; big batches and grad-requiring inputs stay eager."""
+    import pickle
+
+    from amphion_amd.models.vocoders.gan.generator import _engine
+    from amphion_amd.models.vocoders.gan.generator.hifigan import HiFiGAN
+
+    hp = vo.hifigan_v1_hp()
+    m = HiFiGAN(NS(preprocess=NS(n_mel=80, hop_size=256), model=NS(hifigan=NS(**hp))))
+    m.load_state_dict(synth.synth_state_dict(synth.hifigan_param_shapes(80, hp), 1234))
+    m = m.cuda().eval()
+    with torch.no_grad():
+        for T in (40, 37, 64, 33, 40):                         # one bucket (64 frames): eager, capture, replay, replay, replay
+            mel = synth.synth_mel(1, 80, T, seed=T).cuda()
+            got = m.forward_graphed(mel)
+            assert got.shape == (1, 1, T * 256) and torch.equal(got, m(mel)), T
+        cache = _engine._graph_caches[m]
+        assert isinstance(cache[(1, 64, "cuda:0")], tuple)     # captured
+        # ragged batch through the same mechanism
+        mel = synth.synth_mel(3, 80, 50, seed=9).cuda()
+        lens = [50, 21, 3]
+        for _ in range(3):
+            got = m.forward_graphed(mel, lens)
+        want = m.forward_ragged(mel, lens)
+        for i, n in enumerate(lens):
+            assert torch.equal(got[i, :, : n * 256], want[i, :, : n * 256])
+        # weights change: the next call must not replay the old graph
+        mel = synth.synth_mel(1, 80, 40, seed=1).cuda()
+        before = m.forward_graphed(mel).clone()
+        m.conv_post.bias.add_(0.25)
+        after = m.forward_graphed(mel)
+        assert torch.equal(after, m(mel)) and not torch.equal(after, before)
+        assert torch.equal(m.forward_graphed(mel), after) and torch.equal(m.forward_graphed(mel), after)   # re-captured, replayed
+        # a full batch stays eager (nothing cached for it)
+        big = synth.synth_mel(8, 80, 256, seed=2).cuda()
+        assert torch.equal(m.forward_graphed(big), m(big))
+        assert not any(isinstance(k, tuple) and k[0] == 8 for k in _engine._graph_caches[m])
+    # the cache is a weak-keyed side table, not module state
+    assert not any("graph" in k for k in vars(m)) and len(pickle.dumps(m.state_dict())) > 0
+
+
 @pytest.mark.parametrize("arch", ["hifigan", "bigvgan"])
 def test_list_api_skips_dead_padding_without_changing_a_bit(arch):
     """synthesis_audios (default, the reference's pad-then-crop arithmetic) runs a padded batch as a ragged one with

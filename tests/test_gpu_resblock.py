@@ -150,3 +150,65 @@ def test_generator_with_resblock_kernel_equals_pairs(mode, fusion):
     assert torch.equal(a, b)
     for i, n in enumerate(lens):
         assert torch.equal(ar[i, :, : n * 256], br[i, :, : n * 256])
+
+
+@pytest.mark.parametrize("arch", ["hifigan", "bigvgan"])
+def test_concurrent_resblock_streams_bitwise(arch):
+    """The resblocks of a stage on concurrent streams, their accumulating launches chained by events (amp_set_resblock_streams) ==
+    the sequential chain, bit for bit: dense, ragged, and replayed from a captured hipGraph (fork / join by events)."""
+    from amphion_amd import _lib
+    from amphion_amd.utils.synthetic import randomize_, synthetic_mel
+
+    L = _lib.lib()
+    if arch == "hifigan":
+        from amphion_amd.models.vocoders.gan.generator.hifigan import HiFiGAN
+        m = randomize_(HiFiGAN(NS(preprocess=NS(n_mel=80, hop_size=256), model=NS(hifigan=NS(**V1)))), 1234).cuda().eval()
+        n_mel, frames = 80, 37
+    else:
+        from amphion_amd.models.vocoders.gan.generator.bigvgan import BigVGAN
+        hp = dict(V1, activation="snakebeta", snake_logscale=True, upsample_initial_channel=256)
+        m = randomize_(BigVGAN(NS(preprocess=NS(n_mel=100, hop_size=256), model=NS(bigvgan=NS(**hp)))), 1234, g_gain=0.75).cuda().eval()
+        n_mel, frames = 100, 19
+    mel = synthetic_mel(3, n_mel, frames, seed=3).cuda()
+    lens = [frames, frames // 2, 3]
+    try:
+        with torch.no_grad():
+            _lib.check(L.amp_set_resblock_streams(0))
+            a = m(mel).cpu()
+            ar = m.forward_ragged(mel, lens).cpu()
+            _lib.check(L.amp_set_resblock_streams(1))
+            b = m(mel).cpu()
+            br = m.forward_ragged(mel, lens).cpu()
+            b2 = m(mel).cpu()                      # the side buffers are reused: a second forward gives the same
+            replay, static_in, static_out = m.capture(3, frames)
+            static_in.copy_(mel)
+            replay()
+            torch.cuda.synchronize()
+            c = static_out.cpu()
+    finally:
+        _lib.check(L.amp_set_resblock_streams(-1))
+    assert torch.equal(a, b) and torch.equal(a, b2) and torch.equal(a, c)
+    for i, n in enumerate(lens):
+        assert torch.equal(ar[i, :, : n * 256], br[i, :, : n * 256])
+
+
+def test_resblock_streams_policy_is_small_launches_only():
+    """-1 (default): concurrent while B * T <= 1024 frames -- the workspace the library asks for tells which form a shape gets."""
+    from amphion_amd import _lib
+    from amphion_amd.models.vocoders.gan.generator.hifigan import HiFiGAN
+    from amphion_amd.utils.synthetic import randomize_, synthetic_mel
+
+    L = _lib.lib()
+    m = randomize_(HiFiGAN(NS(preprocess=NS(n_mel=80, hop_size=256), model=NS(hifigan=NS(**V1)))), 1234).cuda().eval()
+    with torch.no_grad():
+        m(synthetic_mel(1, 80, 8, seed=1).cuda())
+    h = m._amp_handle
+    try:
+        _lib.check(L.amp_set_resblock_streams(0))
+        seq_small, seq_big = L.amp_gen_workspace_bytes(h, 1, 256), L.amp_gen_workspace_bytes(h, 64, 256)
+        _lib.check(L.amp_set_resblock_streams(-1))
+        assert L.amp_gen_workspace_bytes(h, 1, 256) > seq_small          # 4 more buffers: R, TMP of two more resblocks
+        assert L.amp_gen_workspace_bytes(h, 64, 256) == seq_big          # a full batch: sequential
+        assert L.amp_set_resblock_streams(2) < 0
+    finally:
+        _lib.check(L.amp_set_resblock_streams(-1))

@@ -204,18 +204,29 @@ def lst(reps):
 
 
 def lat(reps):
-    cfg, m = hifigan()
+    """One utterance through HiFi-GAN V1, eager and as a hipGraph replay, with the resblocks of a stage one after the other
+    (amp_set_resblock_streams(0): rounds 1-3) and on concurrent streams (the default for launches this small)."""
+    from amphion_amd import _lib
     out = []
-    for T in (256, 860):
-        mel1 = synthetic_mel(1, 80, T, seed=5).to(DEV)
-        ms = timed(lambda: m(mel1), 20)
-        out.append({"config": f"latency: HiFi-GAN V1, ONE utterance of {T} frames ({T * 256 / 22050:.1f} s of audio)", "ms": ms,
-                    "x_realtime": T * 256 / 22050 / (ms * 1e-3)})
-        replay, static_in, _ = m.capture(1, T)
-        static_in.copy_(mel1)
-        ms = timed(replay, 20)
-        out.append({"config": f"latency, hipGraph replay: ONE utterance of {T} frames", "ms": ms,
-                    "x_realtime": T * 256 / 22050 / (ms * 1e-3)})
+    for streams in (0, -1):
+        _lib.check(_lib.lib().amp_set_resblock_streams(streams))
+        cfg, m = hifigan()
+        tag = "sequential resblocks" if streams == 0 else "concurrent resblocks (default)"
+        for T in (256, 860):
+            mel1 = synthetic_mel(1, 80, T, seed=5).to(DEV)
+            ms = timed(lambda: m(mel1), 20)
+            out.append({"config": f"latency: HiFi-GAN V1, ONE utterance of {T} frames ({T * 256 / 22050:.1f} s of audio), {tag}", "ms": ms,
+                        "x_realtime": T * 256 / 22050 / (ms * 1e-3)})
+            replay, static_in, _ = m.capture(1, T)
+            static_in.copy_(mel1)
+            ms = timed(replay, 20)
+            out.append({"config": f"latency, hipGraph replay: ONE utterance of {T} frames, {tag}", "ms": ms,
+                        "x_realtime": T * 256 / 22050 / (ms * 1e-3)})
+            m.forward_graphed(mel1); m.forward_graphed(mel1)     # eager, then captured: what vocoder_inference / synthesis_audios call
+            ms = timed(lambda: m.forward_graphed(mel1), 20)
+            out.append({"config": f"latency, public API path (forward_graphed: bucketed graph cache, copy in + replay + copy out): ONE utterance of {T} frames, {tag}",
+                        "ms": ms, "x_realtime": T * 256 / 22050 / (ms * 1e-3)})
+    _lib.check(_lib.lib().amp_set_resblock_streams(-1))
     return out
 
 
