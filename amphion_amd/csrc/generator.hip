@@ -1385,7 +1385,7 @@ static int gen_num_bufs(const amp_gen* g) { return g->d.arch == AMP_ARCH_BIGVGAN
 // while B * T <= kRbStreamsMaxFrames mel frames; at full batches every launch fills the chip and the same idea measured 28.1 vs
 // 28.1 ms (round 2, BigVGAN, profiles/r2_i_bigvgan_streams.txt).  Works under stream capture (fork / join by events) once the side
 // streams exist: they are created by the first eager forward or by amp_gen_prepare_streams(), never inside a capture.
-constexpr long long kRbStreamsMaxFrames = 1024;
+constexpr long long kRbStreamsMaxFrames = 4096;   // tools/streams_sweep.py, profiles/r4_streams_sweep.txt: 0.87-0.97 of the sequential time up to here, 1.00 beyond
 static int gen_side_bufs(const amp_gen* g) { return (g->d.n_kernels - 1) * (g->d.arch == AMP_ARCH_BIGVGAN ? 3 : 2); }   // R, TMP (+ ACT) per extra resblock
 static bool gen_streams_wanted(const amp_gen* g, int B, int T) {
     if (g->d.n_kernels < 2) return false;

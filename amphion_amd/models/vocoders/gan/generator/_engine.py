@@ -451,8 +451,8 @@ class HipGenerator(nn.Module):
 
     # ---- cached graphs for repeated small shapes (single utterances) ----
     GRAPH_BUCKET_FRAMES = 32        # shapes are rounded up to a multiple of this many frames
-    GRAPH_MAX_FRAMES = 1024         # B * T beyond this fills the chip per launch: a graph buys nothing
-    GRAPH_MAX_ENTRIES = 8
+    GRAPH_MAX_FRAMES = 1024         # larger batches run eagerly: a graph owns its buffers (~0.3 MB per frame for HiFi-GAN V1) and gains less and less
+    GRAPH_MAX_ENTRIES = 4
 
     def forward_graphed(self, x, lengths=None):
         """``forward`` / ``forward_ragged`` of a small batch through a cached hipGraph: the (B, T) shape is rounded up to a bucket of

@@ -336,7 +336,7 @@ int amp_resblock_forward(const amp_conv* const* c1, const amp_conv* const* c2, i
  * 512-column tiles at C = 32.  Bit-identical results in every mode (tests/test_gpu_resblock.py); env AMP_RB_FUSION. */
 int amp_set_resblock_fusion(int mode);
 /* The n_kernels resblocks of a generator stage on CONCURRENT streams (they read the same stage tensor and only meet in the MRF mean,
- * hifigan.py:208-214 / bigvgan.py:320-327): -1 (default) while B * T <= 1024 mel frames -- single utterances, whose launches do not
+ * hifigan.py:208-214 / bigvgan.py:320-327): -1 (default) while B * T <= 4096 mel frames -- small batches, whose launches do not
  * fill the chip and whose forward is a chain of ~50 dependent launches; 0 never; 1 always.  Only the launch of each resblock that
  * accumulates into the mean waits for the previous resblock's (an event) and keeps its `=` / `+=` / `(y + v) / n` form: bit-identical
  * results in every mode.  amp_gen_workspace_bytes accounts for the extra R / TMP buffers; the side streams fork from and join

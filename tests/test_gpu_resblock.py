@@ -193,7 +193,7 @@ def test_concurrent_resblock_streams_bitwise(arch):
 
 
 def test_resblock_streams_policy_is_small_launches_only():
-    """-1 (default): concurrent while B * T <= 1024 frames -- the workspace the library asks for tells which form a shape gets."""
+    """-1 (default): concurrent while B * T <= 4096 frames -- the workspace the library asks for tells which form a shape gets."""
     from amphion_amd import _lib
     from amphion_amd.models.vocoders.gan.generator.hifigan import HiFiGAN
     from amphion_amd.utils.synthetic import randomize_, synthetic_mel
