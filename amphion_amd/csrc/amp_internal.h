@@ -193,6 +193,16 @@ hipError_t launch_act1d(const float* x, float* y, int B, int C, int T, const flo
 
 // y[b,c,t] += cond[b,c]   (HiFiGAN_vits `x + self.cond(g)` with g of length 1)
 hipError_t launch_add_channel_bias(float* y, const float* cb, int B, int C, int T, hipStream_t stream);
+// y = ((y + p[0]) + p[1] ...) / div over `count` floats (16-byte aligned): the MRF mean of resblocks that stored their results separately
+constexpr int AMP_MRF_MAX_PARTS = 3;
+struct MrfSumArgs {
+    float* y;
+    const float* p[AMP_MRF_MAX_PARTS];
+    int n;
+    float div;
+    size_t count;
+};
+hipError_t launch_mrf_sum(const MrfSumArgs& a, hipStream_t stream);
 
 // VITS posterior-encoder / flow element-wise kernels (small_kernels.hip)
 hipError_t launch_wn_gate(const float* a, const float* cond, long long cond_bs, float* out, int B, int H, int T,

@@ -1386,7 +1386,7 @@ static int gen_num_bufs(const amp_gen* g) { return g->d.arch == AMP_ARCH_BIGVGAN
 // 28.1 ms (round 2, BigVGAN, profiles/r2_i_bigvgan_streams.txt).  Works under stream capture (fork / join by events) once the side
 // streams exist: they are created by the first eager forward or by amp_gen_prepare_streams(), never inside a capture.
 constexpr long long kRbStreamsMaxFrames = 4096;   // tools/streams_sweep.py, profiles/r4_streams_sweep.txt: 0.87-0.97 of the sequential time up to here, 1.00 beyond
-static int gen_side_bufs(const amp_gen* g) { return (g->d.n_kernels - 1) * (g->d.arch == AMP_ARCH_BIGVGAN ? 3 : 2); }   // R, TMP (+ ACT) per extra resblock
+static int gen_side_bufs(const amp_gen* g) { return (g->d.n_kernels - 1) * (g->d.arch == AMP_ARCH_BIGVGAN ? 4 : 3); }   // R, TMP, XS (+ ACT) per extra resblock
 static bool gen_streams_wanted(const amp_gen* g, int B, int T) {
     if (g->d.n_kernels < 2) return false;
     const int m = cfg().rb_streams;
@@ -1523,8 +1523,8 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
     float* R = base + 3 * be;   // running x inside a resblock
     float* TMP = base + 4 * be; // xt between the two convs of a pair
     float* ACT = big ? base + 5 * be : nullptr;  // anti-aliased activation output
-    float* SIDE = base + (size_t)gen_num_bufs(g) * be;   // concurrent mode: R, TMP (+ ACT) of resblocks 1 .. n_kernels - 1
-    const int side_per = big ? 3 : 2;
+    float* SIDE = base + (size_t)gen_num_bufs(g) * be;   // concurrent mode: R, TMP, XS (+ ACT) of resblocks 1 .. n_kernels - 1
+    const int side_per = big ? 4 : 3;
     float* CB = base + (size_t)(gen_num_bufs(g) + (conc ? gen_side_bufs(g) : 0)) * be;  // cond(g): [B, C0]
     const float slope = 0.1f;  // LRELU_SLOPE hifigan.py:14
 
@@ -1548,6 +1548,15 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
         // the other way round too -- the widest resblock on `st`, the others on the side streams: the same 0.81-0.83 ms as a graph
         // replay, but 1.08 instead of 0.90-0.95 ms eager, where the host issues the critical stream's launches last.)
         hipEvent_t* evs = conc ? &g->ev_side[(size_t)i * (nk + 1)] : nullptr;
+        // A stage whose resblocks ALL end in a fused pair / whole-resblock kernel (HiFi-GAN, C <= 128) needs no chain: those kernels add
+        // the accumulated y to their finished, rounded result, so each resblock stores its own result (mode 0) and one small launch forms
+        // ((XS0 + XS1) + XS2) / n afterwards -- the same bits with one join instead of two chained cross-queue waits (~12 us each).
+        bool sum_stage = conc && d.resblock_type == 1 && !big && nk - 1 <= AMP_MRF_MAX_PARTS;
+        for (int j = 0; sum_stage && j < nk; ++j) {
+            const ResBlock& rb = g->rbs[(size_t)i * nk + j];
+            const size_t last = rb.dil.size() - 1;
+            sum_stage = rb_supported(rb.c1, rb.c2, B, t) || pair_supported(rb.c1[last].get(), rb.c2[last].get());
+        }
         if (conc) {
             AMP_HIP(hipEventRecord(evs[0], st));
             for (int j = 1; j < nk; ++j) AMP_HIP(hipStreamWaitEvent(g->side[j - 1], evs[0], 0));
@@ -1558,10 +1567,11 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
             float* SB = SIDE + (size_t)(on_side ? j - 1 : 0) * side_per * be;
             float* R_ = on_side ? SB : R;
             float* TMP_ = on_side ? SB + be : TMP;
-            float* ACT_ = (on_side && big) ? SB + 2 * be : ACT;
+            float* XSJ = (on_side && sum_stage) ? SB + 2 * be : XS;      // where this resblock's result goes
+            float* ACT_ = (on_side && big) ? SB + 3 * be : ACT;
             // called right before the launch that writes XS: it reads what resblock j - 1 accumulated there
             auto before_last = [&]() -> int {
-                if (conc && j > 0) AMP_HIP(hipStreamWaitEvent(sj, evs[j], 0));
+                if (conc && !sum_stage && j > 0) AMP_HIP(hipStreamWaitEvent(sj, evs[j], 0));
                 return AMP_OK;
             };
             if (ev_rb) AMP_HIP(hipEventRecord(ev_rb[(size_t)i * (nk + 1) + j], sj));
@@ -1571,21 +1581,21 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
                 log_scope(rb_names ? &(*rb_names)[(size_t)i * nk + j] : nullptr);
             const ResBlock& rb = g->rbs[(size_t)i * nk + j];
             const int nd = (int)rb.dil.size();
-            const int mode_last = (nk == 1) ? 0 : (j == 0 ? 0 : (j == nk - 1 ? 2 : 1));
+            const int mode_last = (nk == 1 || sum_stage) ? 0 : (j == 0 ? 0 : (j == nk - 1 ? 2 : 1));
             const float* cur = U;
             if (d.resblock_type == 1 && !big && rb_supported(rb.c1, rb.c2, B, t)) {
-                // the whole resblock in one launch: U -> XS (x and the residual never leave the CU in between)
+                // the whole resblock in one launch: U -> XSJ (x and the residual never leave the CU in between)
                 AMP_RC(before_last());
-                AMP_RC(rb_run(rb.c1, rb.c2, U, B, t, slope, XS, mode_last, (float)nk, sj, lens, lm));
+                AMP_RC(rb_run(rb.c1, rb.c2, U, B, t, slope, XSJ, mode_last, (float)nk, sj, lens, lm));
                 return AMP_OK;
             }
             if (d.resblock_type == 1 && big && nd <= AMP_AMPB_MAX_STEPS / 2) {
                 const amp_conv *p1[AMP_AMPB_MAX_STEPS / 2], *p2[AMP_AMPB_MAX_STEPS / 2];
                 for (int p = 0; p < nd; ++p) { p1[p] = rb.c1[p].get(); p2[p] = rb.c2[p].get(); }
                 if (ampb_supported(p1, p2, nd, rb.acts.data(), rb.acts.size(), B, t)) {
-                    // the whole AMPBlock in one launch: U -> XS (bigvgan.py:137-146)
+                    // the whole AMPBlock in one launch: U -> XSJ (bigvgan.py:137-146)
                     AMP_RC(before_last());
-                    AMP_RC(ampb_run(p1, p2, nd, rb.acts.data(), U, B, t, XS, mode_last, (float)nk, sj, lens, lm));
+                    AMP_RC(ampb_run(p1, p2, nd, rb.acts.data(), U, B, t, XSJ, mode_last, (float)nk, sj, lens, lm));
                     return AMP_OK;
                 }
             }
@@ -1595,7 +1605,7 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
                     if (!big && pair_supported(rb.c1[p].get(), rb.c2[p].get())) {
                         // the whole pair in one kernel; the output ping-pongs R_ <-> TMP_ (never in place:
                         // other tiles still read the input's halo)
-                        float* dst = last ? XS : (cur == R_ ? TMP_ : R_);
+                        float* dst = last ? XSJ : (cur == R_ ? TMP_ : R_);
                         if (last) AMP_RC(before_last());
                         AMP_RC(pair_run(rb.c1[p].get(), rb.c2[p].get(), cur, B, t, slope, dst, last ? mode_last : 0, (float)nk, sj, lens, lm));
                         cur = dst;
@@ -1607,7 +1617,7 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
                         }
                         AMP_RC(conv_run(rb.c1[p].get(), cur, B, t, slope, nullptr, slope, TMP_, 0, 1.f, sj, 0, lens, lm));
                         if (!last) { AMP_RC(conv_run(rb.c2[p].get(), TMP_, B, t, 1.f, cur, 1.f, R_, 0, 1.f, sj, 0, lens, lm)); cur = R_; }
-                        else { AMP_RC(before_last()); AMP_RC(conv_run(rb.c2[p].get(), TMP_, B, t, 1.f, cur, 1.f, XS, mode_last, (float)nk, sj, 0, lens, lm)); }
+                        else { AMP_RC(before_last()); AMP_RC(conv_run(rb.c2[p].get(), TMP_, B, t, 1.f, cur, 1.f, XSJ, mode_last, (float)nk, sj, 0, lens, lm)); }
                     } else {
                         // xt = c2(a2(c1(a1(x)))) ; x = xt + x              bigvgan.py:137-146
                         const ActParams& a1 = rb.acts[2 * p];
@@ -1627,7 +1637,7 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
                             AMP_HIP(launch_act1d(TMP_, ACT_, B, C, t, a2.a_dev, a2.invb_dev, a2.fu_dev, a2.fd_dev, lens, lm, sj, next_rev(lens)));
                         }
                         if (!last) { AMP_RC(conv_run(rb.c2[p].get(), c2_in, B, t, 1.f, cur, 1.f, R_, 0, 1.f, sj, 0, lens, lm)); cur = R_; }
-                        else { AMP_RC(before_last()); AMP_RC(conv_run(rb.c2[p].get(), c2_in, B, t, 1.f, cur, 1.f, XS, mode_last, (float)nk, sj, 0, lens, lm)); }
+                        else { AMP_RC(before_last()); AMP_RC(conv_run(rb.c2[p].get(), c2_in, B, t, 1.f, cur, 1.f, XSJ, mode_last, (float)nk, sj, 0, lens, lm)); }
                     }
                 } else {
                     // x = c(act(x)) + x                                    hifigan.py:140-145, bigvgan.py:218-224
@@ -1646,7 +1656,7 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
                         cur = dst;
                     } else {
                         AMP_RC(before_last());
-                        AMP_RC(conv_run(rb.c1[p].get(), in, B, t, sl, cur, 1.f, XS, mode_last, (float)nk, sj, 0, lens, lm));
+                        AMP_RC(conv_run(rb.c1[p].get(), in, B, t, sl, cur, 1.f, XSJ, mode_last, (float)nk, sj, 0, lens, lm));
                     }
                 }
             }
@@ -1655,7 +1665,16 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
             AMP_RC(resblock());
             if (conc) AMP_HIP(hipEventRecord(evs[1 + j], sj));
         }
-        if (conc) AMP_HIP(hipStreamWaitEvent(st, evs[nk], 0));   // join: the last resblock's accumulating launch follows all the others
+        if (conc && !sum_stage) AMP_HIP(hipStreamWaitEvent(st, evs[nk], 0));   // join: the last resblock's accumulating launch follows all the others
+        if (sum_stage) {
+            MrfSumArgs ma{};
+            ma.y = XS; ma.n = nk - 1; ma.div = (float)nk; ma.count = (size_t)B * C * t;
+            for (int j = 1; j < nk; ++j) {
+                AMP_HIP(hipStreamWaitEvent(st, evs[1 + j], 0));
+                ma.p[j - 1] = SIDE + ((size_t)(j - 1) * side_per + 2) * be;
+            }
+            AMP_HIP(launch_mrf_sum(ma, st));
+        }
         if (ev_rb) AMP_HIP(hipEventRecord(ev_rb[(size_t)i * (nk + 1) + nk], st));
         if (ev_mrf) AMP_HIP(hipEventRecord(ev_mrf[2 * i + 1], st));
         float* tmp = X; X = XS; XS = tmp;  // x = xs / num_kernels

@@ -616,6 +616,41 @@ hipError_t launch_add_channel_bias(float* y, const float* cb, int B, int C, int 
     return hipGetLastError();
 }
 
+// MRF combination of resblocks that ran side by side and stored their results separately (generator.hip, concurrent mode, stages whose
+// resblocks all end in a fused pair / whole-resblock kernel): y = ((y + p0) + p1 ...) / div.  Those kernels add the accumulated y to
+// their finished, rounded result (`acc += y; acc /= div`), so this order and the true division give the bits of the sequential chain.
+__global__ __launch_bounds__(256) void mrf_sum_kernel(MrfSumArgs a) {
+    const size_t n4 = a.count >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 v = reinterpret_cast<const float4*>(a.y)[i];
+        float4 p[AMP_MRF_MAX_PARTS];
+#pragma unroll
+        for (int k = 0; k < AMP_MRF_MAX_PARTS; ++k)
+            if (k < a.n) p[k] = reinterpret_cast<const float4*>(a.p[k])[i];      // uniform condition: all loads before the first add
+#pragma unroll
+        for (int k = 0; k < AMP_MRF_MAX_PARTS; ++k) {
+            if (k < a.n) { v.x += p[k].x; v.y += p[k].y; v.z += p[k].z; v.w += p[k].w; }
+        }
+        v.x = v.x / a.div; v.y = v.y / a.div; v.z = v.z / a.div; v.w = v.w / a.div;
+        reinterpret_cast<float4*>(a.y)[i] = v;
+    }
+    if (blockIdx.x == 0) {
+        for (size_t i = (n4 << 2) + threadIdx.x; i < a.count; i += 256) {
+            float v = a.y[i];
+            for (int k = 0; k < a.n; ++k) v += a.p[k][i];
+            a.y[i] = v / a.div;
+        }
+    }
+}
+
+hipError_t launch_mrf_sum(const MrfSumArgs& a, hipStream_t stream) {
+    size_t blocks = ((a.count >> 2) + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(mrf_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------
 // VITS posterior encoder / flow element-wise kernels.  All are one pass over [B, C, T] with
 // time-contiguous float4-free coalesced access (T is arbitrary), grid = B*C rows x time blocks.

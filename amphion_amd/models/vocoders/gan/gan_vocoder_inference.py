@@ -53,7 +53,7 @@ def _crops_to_host(model, out, lengths):
 def _ragged(model, batch, lens):
     """forward_ragged, through the generator's cached hipGraph when the batch is small enough for one to pay (same bits)"""
     if hasattr(model, "forward_graphed"):
-        return model.forward_graphed(batch, lens)
+        return model.forward_graphed(batch, lens, clone=False)     # copied to the host by the caller before the next forward
     return model.forward_ragged(batch, lens)
 
 
@@ -68,7 +68,7 @@ def vocoder_inference(cfg, model, mels, f0s=None, device=None, fast_inference=Fa
         def run():
             if f0s is None and not cfg.preprocess.extract_amplitude_phase:
                 if hasattr(model, "forward_graphed"):      # small batches of a repeated shape: a cached hipGraph (same bits)
-                    return model.forward_graphed(mels)
+                    return model.forward_graphed(mels, clone=False)     # .cpu() below, before any other forward
                 return model.forward(mels)
             if cfg.preprocess.extract_amplitude_phase:
                 return model.forward(mels)[4]

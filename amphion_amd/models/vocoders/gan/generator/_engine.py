@@ -454,7 +454,7 @@ class HipGenerator(nn.Module):
     GRAPH_MAX_FRAMES = 1024         # larger batches run eagerly: a graph owns its buffers (~0.3 MB per frame for HiFi-GAN V1) and gains less and less
     GRAPH_MAX_ENTRIES = 4
 
-    def forward_graphed(self, x, lengths=None):
+    def forward_graphed(self, x, lengths=None, clone=True):
         """``forward`` / ``forward_ragged`` of a small batch through a cached hipGraph: the (B, T) shape is rounded up to a bucket of
         ``GRAPH_BUCKET_FRAMES`` frames, the bucket's graph -- captured the SECOND time the bucket is seen -- runs the ragged forward
         with the valid lengths in a device buffer, and ``out[b, 0, : lengths[b] * hop]`` (``lengths`` defaults to T for every item) is
@@ -462,7 +462,9 @@ class HipGenerator(nn.Module):
         tests/test_gpu_inference_api.py).  What it buys: one ``hipGraphLaunch`` instead of ~85 launch / event calls, and the
         concurrent-resblock launch order without host gaps -- a 3-s utterance 0.95 -> 0.83 ms.  Falls back to the eager call for
         batches beyond ``GRAPH_MAX_FRAMES`` frames, conditioned generators, profiling runs and inputs that require grad.  The graphs
-        die with the packed weights (``load_state_dict`` / ``.to()`` / precision switch: the cache is dropped and rebuilt)."""
+        die with the packed weights (``load_state_dict`` / ``.to()`` / precision switch: the cache is dropped and rebuilt).
+        ``clone=False`` returns a view of the graph's own output buffer -- valid until the next call for the same bucket -- for callers
+        that copy it away at once (``vocoder_inference`` / ``synthesis_audios``: straight to the host)."""
         x = _lib.require_device_tensor(x, "generator input")
         B, C, T = x.shape
         eager = lambda: self._amp_forward(x, lengths=lengths)
@@ -493,10 +495,14 @@ class HipGenerator(nn.Module):
                 ent = cache[key] = self.capture(B, Tb, ragged=True)
             replay, static_in, static_out = ent
             static_in[:, :, :T].copy_(x)            # frames beyond an item's length are never read (the kernels select on the lengths)
-            replay.static_lens.copy_(lt, non_blocking=True)
+            lens_key = tuple(lt.tolist())
+            if getattr(replay, "lens_key", None) != lens_key:      # the lengths the buffer already holds need no second upload
+                replay.static_lens.copy_(lt)
+                replay.lens_key = lens_key
             replay()
             hop = static_out.shape[-1] // Tb
-            return static_out[:, :, : T * hop].clone()
+            out = static_out[:, :, : T * hop]
+            return out.clone() if clone else out
 
     # ---- profiling hooks used by bench.py ----
     def set_profiling(self, slots=1):
