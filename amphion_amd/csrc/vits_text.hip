@@ -486,6 +486,61 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
 // then `* mask` on both channels.  The channel Flips around a ConvFlow (:315-321) are folded in: flip_in swaps the
 // two channels on load, flip_out on store (x0 = the conditioning channel, x1 = the transformed one).
 constexpr int SPL_MAXK = 16;
+// the transform of one element: `hv(i)` = parameter row i of this column ALREADY scaled and masked as the reference does
+// (widths / heights: h * filter_channels^-0.5 * mask, derivatives: h * mask)
+template <class HV>
+__device__ __forceinline__ float spline_eval(float x1, HV hv, int K, float tail, int inverse) {
+    float out = x1;
+    if (x1 >= -tail && x1 <= tail) {
+        const float min_w = 1e-3f, min_h = 1e-3f, min_d = 1e-3f;
+        float xk[SPL_MAXK + 1], yk[SPL_MAXK + 1], dd[SPL_MAXK + 1];
+        // softmax -> bin fractions -> knots in [-tail, tail] with exact end points
+        for (int pass = 0; pass < 2; ++pass) {
+            float* kn = pass == 0 ? xk : yk;
+            const float lo = pass == 0 ? min_w : min_h;
+            float mxv = -3.0e38f;
+            for (int i = 0; i < K; ++i) mxv = fmaxf(mxv, hv(pass * K + i));
+            float se = 0.f;
+            for (int i = 0; i < K; ++i) se += expf(hv(pass * K + i) - mxv);
+            float cum = 0.f;
+            kn[0] = -tail;
+            for (int i = 0; i < K; ++i) {
+                const float frac = lo + (1.f - lo * K) * (expf(hv(pass * K + i) - mxv) / se);
+                cum += frac;
+                kn[i + 1] = 2.f * tail * cum - tail;
+            }
+            kn[K] = tail;
+        }
+        dd[0] = 1.f;                                     // min_d + softplus(log(exp(1 - min_d) - 1)) = 1 at both ends
+        dd[K] = 1.f;
+        for (int i = 1; i < K; ++i) {
+            const float u = hv(2 * K + i - 1);
+            dd[i] = min_d + (u > 20.f ? u : log1pf(expf(u)));   // F.softplus (threshold 20)
+        }
+        const float* kn = inverse ? yk : xk;
+        int bin = 0;
+        for (int i = 1; i < K; ++i) bin += (x1 >= kn[i]) ? 1 : 0;   // searchsorted over the interior knots (last += eps)
+        const float xa = xk[bin], wb = xk[bin + 1] - xk[bin];
+        const float ya = yk[bin], hbin = yk[bin + 1] - yk[bin];
+        const float d0 = dd[bin], d1 = dd[bin + 1];
+        const float sl = hbin / wb;
+        if (inverse) {
+            const float dy = x1 - ya;
+            const float e = d0 + d1 - 2.f * sl;
+            const float qa = dy * e + hbin * (sl - d0);
+            const float qb = hbin * d0 - dy * e;
+            const float qc = -sl * dy;
+            const float root = (2.f * qc) / (-qb - sqrtf(qb * qb - 4.f * qa * qc));
+            out = root * wb + xa;
+        } else {
+            const float th = (x1 - xa) / wb;
+            const float tt = th * (1.f - th);
+            out = ya + hbin * (sl * th * th + d0 * tt) / (sl + (d0 + d1 - 2.f * sl) * tt);
+        }
+    }
+    return out;
+}
+
 __global__ __launch_bounds__(256) void spline_flow_kernel(const float* __restrict__ z, const float* __restrict__ h,
                                                           const int* __restrict__ lens, float* __restrict__ zo, int T,
                                                           int K, float inv_sqrt_fc, float tail, int inverse,
@@ -497,57 +552,92 @@ __global__ __launch_bounds__(256) void spline_flow_kernel(const float* __restric
     const float x0 = z[((size_t)b * 2 + (flip_in ? 1 : 0)) * T + t];
     const float x1 = z[((size_t)b * 2 + (flip_in ? 0 : 1)) * T + t];
     const float* hb = h + (size_t)b * (3 * K - 1) * T + t;
-    float out = x1;
-    if (x1 >= -tail && x1 <= tail) {
-        const float min_w = 1e-3f, min_h = 1e-3f, min_d = 1e-3f;
-        float xk[SPL_MAXK + 1], yk[SPL_MAXK + 1], dd[SPL_MAXK + 1];
-        // softmax -> bin fractions -> knots in [-tail, tail] with exact end points
-        for (int pass = 0; pass < 2; ++pass) {
-            float* kn = pass == 0 ? xk : yk;
-            const float lo = pass == 0 ? min_w : min_h;
-            float mxv = -3.0e38f;
-            for (int i = 0; i < K; ++i) mxv = fmaxf(mxv, hb[(size_t)(pass * K + i) * T] * inv_sqrt_fc * m);
-            float se = 0.f;
-            for (int i = 0; i < K; ++i) se += expf(hb[(size_t)(pass * K + i) * T] * inv_sqrt_fc * m - mxv);
-            float cum = 0.f;
-            kn[0] = -tail;
-            for (int i = 0; i < K; ++i) {
-                const float frac = lo + (1.f - lo * K) * (expf(hb[(size_t)(pass * K + i) * T] * inv_sqrt_fc * m - mxv) / se);
-                cum += frac;
-                kn[i + 1] = 2.f * tail * cum - tail;
-            }
-            kn[K] = tail;
-        }
-        dd[0] = 1.f;                                     // min_d + softplus(log(exp(1 - min_d) - 1)) = 1 at both ends
-        dd[K] = 1.f;
-        for (int i = 1; i < K; ++i) {
-            const float u = hb[(size_t)(2 * K + i - 1) * T] * m;
-            dd[i] = min_d + (u > 20.f ? u : log1pf(expf(u)));   // F.softplus (threshold 20)
-        }
-        const float* kn = inverse ? yk : xk;
-        int bin = 0;
-        for (int i = 1; i < K; ++i) bin += (x1 >= kn[i]) ? 1 : 0;   // searchsorted over the interior knots (last += eps)
-        const float xa = xk[bin], wb = xk[bin + 1] - xk[bin];
-        const float ya = yk[bin], hbin = yk[bin + 1] - yk[bin];
-        const float d0 = dd[bin], d1 = dd[bin + 1];
-        const float s = hbin / wb;
-        if (inverse) {
-            const float dy = x1 - ya;
-            const float e = d0 + d1 - 2.f * s;
-            const float qa = dy * e + hbin * (s - d0);
-            const float qb = hbin * d0 - dy * e;
-            const float qc = -s * dy;
-            const float root = (2.f * qc) / (-qb - sqrtf(qb * qb - 4.f * qa * qc));
-            out = root * wb + xa;
-        } else {
-            const float th = (x1 - xa) / wb;
-            const float tt = th * (1.f - th);
-            out = ya + hbin * (s * th * th + d0 * tt) / (s + (d0 + d1 - 2.f * s) * tt);
-        }
-    }
+    const float out = spline_eval(x1, [&](int i) { return i < 2 * K ? hb[(size_t)i * T] * inv_sqrt_fc * m : hb[(size_t)i * T] * m; }, K, tail,
+                                  inverse);
     const float o0 = x0 * m, o1 = out * m;
     zo[((size_t)b * 2 + (flip_out ? 1 : 0)) * T + t] = o0;
     zo[((size_t)b * 2 + (flip_out ? 0 : 1)) * T + t] = o1;
+}
+
+// The same with ConvFlow's `proj` (a 1 x 1 conv C -> 3K - 1, modules/flow/modules.py:418,427) evaluated here instead of by a conv launch of
+// 29 output rows (16 workgroups, 25 us) followed by this kernel on 16 workgroups of 100 live threads (20 us, its 49 parameter loads sunk
+// into the branches one by one).  A workgroup = 32 columns of one item: the [C, 32] tile of the DDSConv output and the [3K - 1, C] weights
+// go to LDS in one batch of loads, thread (column, g) forms rows g, g + 8, ... as plain fp32 dot products over ascending c (more exact
+// than the f16x3 conv it replaces, not bit-equal to it), and the first 32 threads run the transform from LDS.
+constexpr int SPP_TT = 32, SPP_MAXC = 256, SPP_MAXR = 3 * SPL_MAXK - 1;
+__global__ __launch_bounds__(256) void spline_flow_proj_kernel(const float* __restrict__ z, const float* __restrict__ hc,
+                                                               const float* __restrict__ pw, const float* __restrict__ pb,
+                                                               const int* __restrict__ lens, float* __restrict__ zo, int C, int T,
+                                                               int K, float inv_sqrt_fc, float tail, int inverse, int flip_in,
+                                                               int flip_out) {
+    extern __shared__ float sm[];
+    const int R = 3 * K - 1;
+    float* xs = sm;                          // [C][SPP_TT + 1]
+    float* ws = xs + C * (SPP_TT + 1);       // [R][C + 1]
+    float* hs = ws + R * (C + 1);            // [R][SPP_TT + 1]
+    const int tid = threadIdx.x, tx = tid & (SPP_TT - 1), g = tid >> 5;
+    const int t0 = blockIdx.x * SPP_TT, b = blockIdx.y;
+    const int t = t0 + tx;
+    const int tc = t < T ? t : T - 1;
+    {
+        constexpr int XU = SPP_MAXC / 8, WU = (SPP_MAXR * SPP_MAXC + 255) / 256;   // 32 rows of x, 47 weights per thread at the limits
+        float tx_[XU], tw[WU];
+        const float* xb = hc + (size_t)b * C * T + tc;
+        const int nw = R * C;
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int c = g + 8 * u;
+            tx_[u] = xb[(size_t)(c < C ? c : C - 1) * T];
+        }
+#pragma unroll
+        for (int u = 0; u < WU; ++u) {
+            const int e = tid + 256 * u;
+            tw[u] = pw[e < nw ? e : nw - 1];
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int c = g + 8 * u < C ? g + 8 * u : C - 1;       // (clamped like the load: the same value to the same place)
+            xs[c * (SPP_TT + 1) + tx] = tx_[u];
+        }
+#pragma unroll
+        for (int u = 0; u < WU; ++u) {
+            const int e = tid + 256 * u < nw ? tid + 256 * u : nw - 1;
+            const int r = e / C, c = e - r * C;
+            ws[r * (C + 1) + c] = tw[u];
+        }
+    }
+    __syncthreads();
+    {
+        float acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int r = g + 8 * q; acc[q] = pb ? pb[r < R ? r : R - 1] : 0.f; }
+#pragma unroll 4
+        for (int c = 0; c < C; ++c) {
+            const float xv = xs[c * (SPP_TT + 1) + tx];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = g + 8 * q;
+                acc[q] = fmaf(ws[(r < R ? r : R - 1) * (C + 1) + c], xv, acc[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = g + 8 * q;
+            if (r < R) hs[r * (SPP_TT + 1) + tx] = acc[q];
+        }
+    }
+    __syncthreads();
+    if (g != 0 || t >= T) return;
+    const bool live = lens ? t < lens[b] : true;
+    const float m = live ? 1.f : 0.f;
+    const float x0 = z[((size_t)b * 2 + (flip_in ? 1 : 0)) * T + t];
+    const float x1 = z[((size_t)b * 2 + (flip_in ? 0 : 1)) * T + t];
+    // (a select where the unfused kernel multiplies by the mask: whatever the conditioning tensor holds beyond the length stays out)
+    const float out = spline_eval(x1, [&](int i) { const float v = live ? hs[i * (SPP_TT + 1) + tx] : 0.f; return i < 2 * K ? v * inv_sqrt_fc * m : v * m; },
+                                  K, tail, inverse);
+    zo[((size_t)b * 2 + (flip_out ? 1 : 0)) * T + t] = x0 * m;
+    zo[((size_t)b * 2 + (flip_out ? 0 : 1)) * T + t] = out * m;
 }
 
 // ElementwiseAffine reverse: (x - m[c]) * exp(-logs[c]) * mask    (modules/flow/modules.py:338-340)
@@ -790,6 +880,28 @@ int amp_spline_flow(const float* z_dev, const float* h_dev, const int* lens_dev,
     hipLaunchKernelGGL(spline_flow_kernel, dim3((T + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, z_dev, h_dev, lens_dev,
                        z_out_dev, T, num_bins, 1.0f / sqrtf((float)filter_channels), tail_bound, inverse, flip_in, flip_out);
     VT_LAUNCHED("amp_spline_flow");
+    return AMP_OK;
+}
+
+int amp_spline_flow_proj(const float* z_dev, const float* hc_dev, const float* proj_w_dev, const float* proj_b_dev, const int* lens_dev,
+                         int B, int C, int T, int num_bins, int filter_channels, float tail_bound, int inverse, int flip_in, int flip_out,
+                         float* z_out_dev, void* stream) {
+    VT_CHECK(z_dev && hc_dev && proj_w_dev && z_out_dev && z_dev != z_out_dev && B > 0 && C > 0 && T > 0 && filter_channels > 0 &&
+                 tail_bound > 0.f && B <= 65535, "amp_spline_flow_proj: bad argument");
+    if (num_bins < 2 || num_bins > SPL_MAXK || C > SPP_MAXC) {
+        set_error("amp_spline_flow_proj: %d bins (2..%d), %d channels (<= %d): run the 1x1 conv and amp_spline_flow", num_bins, SPL_MAXK, C, SPP_MAXC);
+        return AMP_ERR_UNSUPPORTED;
+    }
+    const int R = 3 * num_bins - 1;
+    const size_t lds = (size_t)(C * (SPP_TT + 1) + R * (C + 1) + R * (SPP_TT + 1)) * sizeof(float);
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spline_flow_proj_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    });
+    hipLaunchKernelGGL(spline_flow_proj_kernel, dim3((T + SPP_TT - 1) / SPP_TT, B), dim3(256), lds, (hipStream_t)stream, z_dev, hc_dev,
+                       proj_w_dev, proj_b_dev, lens_dev, z_out_dev, C, T, num_bins, 1.0f / sqrtf((float)filter_channels), tail_bound, inverse,
+                       flip_in, flip_out);
+    VT_LAUNCHED("amp_spline_flow_proj");
     return AMP_OK;
 }
 

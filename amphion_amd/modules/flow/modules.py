@@ -169,8 +169,9 @@ class DDSConv(nn.Module):
             self.norms_1.append(LayerNorm(channels))
             self.norms_2.append(LayerNorm(channels))
 
-    def forward(self, x, lens=None):
-        """:63-72 in eval mode (the optional ``x + g`` of :61-62 is fused into the conv that produces x by the callers)."""
+    def forward(self, x, lens=None, mask_output=True):
+        """:63-72 in eval mode (the optional ``x + g`` of :61-62 is fused into the conv that produces x by the callers).
+        ``mask_output=False``: the caller masks (ConvFlow's fused projection + spline)."""
         x = _lib.require_device_tensor(x, "DDSConv input")
         for i in range(self.n_layers):
             sep, n1 = self.convs_sep[i], self.norms_1[i]
@@ -181,7 +182,7 @@ class DDSConv(nn.Module):
                 y = n1(sep(x, lens), gelu=True)
             y = self.convs_1x1[i](y)
             x = self.norms_2[i](y, gelu=True, post=x)      # x + gelu(norm(y))
-        return hip_ops.sequence_mask_(x, lens) if lens is not None else x
+        return hip_ops.sequence_mask_(x, lens) if (lens is not None and mask_output) else x
 
 
 class Log(nn.Module):
@@ -229,6 +230,14 @@ class ConvFlow(nn.Module):
         # x0 = the conditioning channel: channel 0, or channel 1 when the preceding Flip is folded in
         x0 = x[:, 1:2] if flip_in else x[:, 0:1]
         h = self.pre(x0, res=g, x_batch_stride=x.stride(0), T=T)   # pre(x0) + g: DDSConv's "x + g" (:61-62) fused into the conv; x0 read in place
+        pj = self.proj
+        if self.convs.channels <= 256 and pj.k == 1 and pj.bias is not None:
+            # proj + `* x_mask` + spline in one launch (the mask is a select on the lengths there, so DDSConv's own final mask launch
+            # is not needed either)
+            h = self.convs(h, lens, mask_output=False)
+            return hip_ops.spline_flow_proj(x, h, pj.folded_weight().detach().reshape(pj.cout, pj.cin).contiguous(), pj.bias.detach(), lens,
+                                            self.num_bins, self.filter_channels, self.tail_bound, inverse=reverse, flip_in=flip_in,
+                                            flip_out=flip_out)
         h = self.convs(h, lens)
         h = self.proj(h)                                    # masked inside the spline kernel (h * x_mask, :428)
         return hip_ops.spline_flow(x, h, lens, self.num_bins, self.filter_channels, self.tail_bound, inverse=reverse,

@@ -303,6 +303,18 @@ def spline_flow(z, h, lens, num_bins, filter_channels, tail_bound, inverse, flip
     return out
 
 
+def spline_flow_proj(z, hc, proj_w, proj_b, lens, num_bins, filter_channels, tail_bound, inverse, flip_in=False, flip_out=False):
+    """ConvFlow's ``proj`` (1 x 1 conv to the 3K - 1 spline parameters) and the spline step in one launch; hc [B, C, T] is the DDSConv
+    output (its columns beyond the lengths are never used)"""
+    B, _, T = z.shape
+    C = hc.shape[1]
+    out = torch.empty_like(z)
+    _lib.check(_lib.lib().amp_spline_flow_proj(_ptr(z), _ptr(hc), _ptr(proj_w), _ptr(proj_b), _ptr(lens), B, C, T, int(num_bins),
+                                               int(filter_channels), float(tail_bound), int(inverse), int(flip_in), int(flip_out), _ptr(out),
+                                               _stream(z)))
+    return out
+
+
 def affine_reverse(x, m, logs, lens):
     B, C, T = x.shape
     y = torch.empty_like(x)

@@ -269,6 +269,12 @@ int amp_dwconv(const float* x_dev, const float* w_dev, const float* bias_dev, co
 int amp_spline_flow(const float* z_dev, const float* h_dev, const int* lens_dev, int B, int T, int num_bins,
                     int filter_channels, float tail_bound, int inverse, int flip_in, int flip_out, float* z_out_dev,
                     void* stream);
+/* amp_spline_flow with ConvFlow's `proj` (modules/flow/modules.py:418,427: Conv1d(C, 3*num_bins - 1, 1)) evaluated inside: hc_dev [B, C, T] is
+ * the DDSConv output, proj_w_dev [3*num_bins - 1, C] / proj_b_dev [3*num_bins - 1] (or NULL) the conv's parameters as stored, on the
+ * device.  The projection is a plain fp32 dot product (not the f16x3 conv arithmetic).  C <= 256; AMP_ERR_UNSUPPORTED otherwise. */
+int amp_spline_flow_proj(const float* z_dev, const float* hc_dev, const float* proj_w_dev, const float* proj_b_dev, const int* lens_dev,
+                         int B, int C, int T, int num_bins, int filter_channels, float tail_bound, int inverse, int flip_in, int flip_out,
+                         float* z_out_dev, void* stream);
 /* ElementwiseAffine reverse: (x - m) * exp(-logs) * mask (modules/flow/modules.py:338-340); m, logs [C]. */
 int amp_affine_reverse(const float* x_dev, const float* m_dev, const float* logs_dev, const int* lens_dev, int B, int C, int T,
                        float* y_dev, void* stream);

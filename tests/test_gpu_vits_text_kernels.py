@@ -207,3 +207,34 @@ def test_encoder_ragged_batch_equals_single_items():
             for got, want in ((h, h1), (m, m1), (logs, logs1)):
                 assert (got[b, :, :n] - want[0]).abs().max().item() <= 2e-5, (b, n)
                 assert (got[b, :, n:] == 0).all()
+
+
+@pytest.mark.parametrize("inverse", [True, False])
+@pytest.mark.parametrize("flip", [False, True])
+def test_spline_flow_with_fused_projection(inverse, flip):
+    """amp_spline_flow_proj == the 1 x 1 projection (here in fp64 on the host) followed by the spline step, and == the oracle's
+    transform; the conditioning tensor is poisoned beyond the lengths."""
+    from amphion_amd.modules import hip_ops
+
+    g = torch.Generator().manual_seed(17)
+    B, C, T, K = 3, 192, 70, 10
+    lt = torch.tensor([70, 33, 1])
+    ld = lt.to(torch.int32).cuda()
+    mask = _mask(lt, T).float()
+    z = torch.randn(B, 2, T, generator=g) * 3
+    hc = torch.randn(B, C, T, generator=g)
+    w = torch.randn(3 * K - 1, C, generator=g) / C**0.5 * 3
+    bias = torch.randn(3 * K - 1, generator=g)
+    h = (torch.einsum("rc,bct->brt", w.double(), hc.double()) + bias.double().view(1, -1, 1)).float().contiguous()
+    zin = torch.flip(z, [1]) if flip else z
+    want = hip_ops.spline_flow(zin.cuda(), h.cuda(), ld, K, 64, 5.0, inverse, flip_in=flip, flip_out=flip).cpu()
+    got = hip_ops.spline_flow_proj(zin.cuda(), _poison(hc, lt).cuda(), w.cuda(), bias.cuda(), ld, K, 64, 5.0, inverse, flip_in=flip,
+                                   flip_out=flip).cpu()
+    assert torch.isfinite(got).all()
+    # (the projection is summed in another order than the host's: ~1e-6 on h, which the steepest bins of the inverse magnify)
+    assert (got - want).abs().max().item() <= 5e-5, (got - want).abs().max().item()
+    hm = (h * mask).reshape(B, 1, 3 * K - 1, T).permute(0, 1, 3, 2)
+    y1 = vio.rq_spline(z[:, 1:], hm[..., :K] / 8.0, hm[..., K:2 * K] / 8.0, hm[..., 2 * K:], inverse, 5.0)
+    ref = torch.cat([z[:, :1], y1], 1) * mask
+    ref = torch.flip(ref, [1]) if flip else ref
+    assert (got - ref).abs().max().item() <= 2e-4, (got - ref).abs().max().item()

@@ -226,6 +226,19 @@ def lat(reps):
             ms = timed(lambda: m.forward_graphed(mel1, clone=False), 20)
             out.append({"config": f"latency, public API path (forward_graphed as vocoder_inference calls it: bucketed graph cache, copy in + replay): ONE utterance of {T} frames, {tag}",
                         "ms": ms, "x_realtime": T * 256 / 22050 / (ms * 1e-3)})
+    # BigVGAN-base, one 3-s utterance: its resblocks end in convs / AMPBlock kernels, so the accumulating launches are chained
+    from amphion_amd.models.vocoders.gan.generator.bigvgan import BigVGAN
+    hp = dict(V1, activation="snakebeta", snake_logscale=True)
+    for streams in (0, -1):
+        _lib.check(_lib.lib().amp_set_resblock_streams(streams))
+        m = randomize_(BigVGAN(NS(preprocess=NS(n_mel=100, hop_size=256), model=NS(bigvgan=NS(**hp)))), 1234, g_gain=0.75).to(DEV).eval()
+        mel1 = torch.randn(1, 100, 256, generator=torch.Generator().manual_seed(0)).to(DEV)
+        m(mel1)
+        replay, static_in, _ = m.capture(1, 256)
+        static_in.copy_(mel1)
+        ms = timed(replay, 20)
+        out.append({"config": "latency, hipGraph replay: BigVGAN-base, ONE utterance of 256 frames, " + ("sequential resblocks" if streams == 0 else "concurrent resblocks (default)"),
+                    "ms": ms, "x_realtime": 256 * 256 / 24000 / (ms * 1e-3)})
     _lib.check(_lib.lib().amp_set_resblock_streams(-1))
     return out
 
