@@ -108,6 +108,8 @@ _SIGNATURES = {
     "amp_layer_norm_c": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
     "amp_add_channel_bias": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "amp_layer_norm_c_ragged": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
+    "amp_dds_seam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float,
+                             c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "amp_dwconv_layer_norm_c": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
     "amp_rel_attention_strided": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "amp_set_rel_attention_tiled": (c_int, [c_int]),

@@ -13,7 +13,29 @@
 
 namespace amp {
 
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
+// GELU and the two places of a LayerNorm where hipcc is free to contract a multiply into a following add -- or not, depending on the
+// code around them (dds_seam_kernel fused gelu's last product into its caller's `+ x`, layer_norm_c_kernel, where that add sits behind
+// a run-time `if (post)`, did not; hipcc's __fmul_rn is a plain multiply and does not stop it).  Contraction is switched off inside
+// these helpers and the fused operations are written out, so every kernel that normalises rounds alike and the fused forms can be
+// tested bit for bit; the opaque move keeps a CALLER from contracting across the return value.
+__device__ __forceinline__ float fp_opaque(float v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ float gelu_erf(float v) {
+#pragma clang fp contract(off)
+    const float e = 1.0f + fp_opaque(erff(v * 0.70710678118654752f));
+    return fp_opaque((0.5f * v) * e);
+}
+__device__ __forceinline__ float ln_sq_acc(float part, float d, bool on) {
+    const float dd = on ? d : 0.f;
+    return fmaf(dd, dd, part);
+}
+__device__ __forceinline__ float ln_affine(float v, float mu, float rstd, float gamma, float beta) {
+#pragma clang fp contract(off)
+    const float t = fp_opaque((v - mu) * rstd);
+    return fp_opaque(fmaf(t, gamma, beta));
+}
 
 // LayerNorm over the CHANNEL axis (modules/base/base_module.py:20-23), optionally of x + res (Encoder's
 // norm(x + y), modules/transformer/attentions.py:69,73) and optionally followed by GELU (DDSConv,
@@ -153,17 +175,14 @@ __global__ __launch_bounds__(256) void layer_norm_c_kernel(const float* __restri
     const float mu = reduce(part) / (float)C;
     part = 0.f;
 #pragma unroll
-    for (int i = 0; i < NC; ++i) {
-        const float d = v[i] - mu;
-        part += (g + LN_G * i < C) ? d * d : 0.f;
-    }
-    for (int c = g + LN_G * NC; c < C; c += LN_G) { const float d = (ok ? value(c) : 0.f) - mu; part += d * d; }
+    for (int i = 0; i < NC; ++i) part = ln_sq_acc(part, v[i] - mu, g + LN_G * i < C);
+    for (int c = g + LN_G * NC; c < C; c += LN_G) part = ln_sq_acc(part, (ok ? value(c) : 0.f) - mu, true);
     const float rstd = 1.0f / sqrtf(reduce(part) / (float)C + eps);
     if (!ok) return;
     float* yb = y + base;
     const bool live = t < len;
     auto emit = [&](int c, float xv) {
-        float o = (xv - mu) * rstd * gamma[c] + beta[c];
+        float o = ln_affine(xv, mu, rstd, gamma[c], beta[c]);
         if (gelu) o = gelu_erf(o);
         if (post) o += post[base + (size_t)c * T];
         yb[(size_t)c * T] = live ? o : 0.f;
@@ -171,12 +190,154 @@ __global__ __launch_bounds__(256) void layer_norm_c_kernel(const float* __restri
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
         const int c = g + LN_G * i;
-        float o = (v[i] - mu) * rstd * gr[i] + br[i];
+        float o = ln_affine(v[i], mu, rstd, gr[i], br[i]);
         if (gelu) o = gelu_erf(o);
         if (post) o += po[i];
         if (c < C) yb[(size_t)c * T] = live ? o : 0.f;
     }
     for (int c = g + LN_G * NC; c < C; c += LN_G) emit(c, value(c));
+}
+
+// The seam between two DDSConv layers (modules/flow/modules.py:63-70) in ONE launch instead of two LayerNorm launches:
+//     x_new = x + gelu(LN_2(y))                        (layer i:   norms_2[i] on the 1 x 1 conv's output, residual)
+//     z     = gelu(LN_1'(dwconv'(x_new * mask)))        (layer i+1: convs_sep[i+1] -> norms_1[i+1])
+// The depthwise conv needs x_new at t - d, t, t + d: a workgroup (32 columns x 8 channel groups, 24 channels per thread: C <= 192)
+// evaluates LN_2 at those three column sets -- the two shifted ones are recomputed, not exchanged: LN is ~1 us of arithmetic, a
+// launch 14 -- with all 144 loads of a thread in flight at once, the three pairs of reductions batched through LDS, then forms the
+// depthwise taps and LN_1' exactly as layer_norm_c_kernel<3> does.  Per element every operation and every summation order is that of
+// the two launches it replaces: same bits (tests/test_gpu_vits_text_kernels.py::test_dds_seam_bitwise).  z is zero beyond the lengths
+// (as amp_dwconv_layer_norm_c), x_new is stored unmasked (as amp_layer_norm_c).
+constexpr int DS_NC = 24;
+__global__ __launch_bounds__(256) void dds_seam_kernel(const float* __restrict__ y, const float* __restrict__ x,
+                                                       const float* __restrict__ g2, const float* __restrict__ b2,
+                                                       const float* __restrict__ dw_w, const float* __restrict__ dw_b,
+                                                       const float* __restrict__ g1, const float* __restrict__ b1,
+                                                       const int* __restrict__ lens, float* __restrict__ xo, float* __restrict__ zo,
+                                                       int C, int T, int dil, float eps2, float eps1) {
+    __shared__ float red[3][LN_G][LN_TT + 1];
+    __shared__ float par[8 * LN_G * DS_NC];              // per channel: g2 | b2 | g1 | b1 | w0 | w1 | w2 | bias
+    const int tx = threadIdx.x & (LN_TT - 1), g = threadIdx.x / LN_TT;
+    const int t = blockIdx.x * LN_TT + tx;
+    const int b = blockIdx.y;
+    const bool ok = t < T;
+    const int len = lens ? lens[b] : T;
+    const size_t ibase = (size_t)b * C * T;
+    constexpr int CP = LN_G * DS_NC;                     // 192
+    for (int i = threadIdx.x; i < CP; i += 256) {
+        const int c = i < C ? i : C - 1;
+        par[i] = g2[c];
+        par[CP + i] = b2[c];
+        par[2 * CP + i] = g1[c];
+        par[3 * CP + i] = b1[c];
+        par[4 * CP + i] = dw_w[c * 3];
+        par[5 * CP + i] = dw_w[c * 3 + 1];
+        par[6 * CP + i] = dw_w[c * 3 + 2];
+        par[7 * CP + i] = dw_b ? dw_b[c] : 0.f;
+    }
+    int tu[3];
+    bool tv[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int u = t - dil + j * dil;
+        tv[j] = u >= 0 && u < len;
+        tu[j] = u < 0 ? 0 : (u > T - 1 ? T - 1 : u);
+    }
+    float yv[3][DS_NC], xv[3][DS_NC];
+#pragma unroll
+    for (int i = 0; i < DS_NC; ++i) {
+        const int c = g + LN_G * i;
+        const size_t row = ibase + (size_t)(c < C ? c : C - 1) * T;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            yv[j][i] = y[row + tu[j]];
+            xv[j][i] = x[row + tu[j]];
+        }
+    }
+    asm volatile("" ::: "memory");
+    auto reduce3 = [&](float (&p)[3]) {                  // the three column sets at once; per set the order of layer_norm_c_kernel
+#pragma unroll
+        for (int j = 0; j < 3; ++j) red[j][g][tx] = p[j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float s_ = 0.f;
+#pragma unroll
+            for (int k = 0; k < LN_G; ++k) s_ += red[j][k][tx];
+            p[j] = s_;
+        }
+        __syncthreads();
+    };
+    // ---- LN_2 + gelu + residual at the three column sets (columns beyond T are clamped duplicates: computed, never used) ----
+    float part[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        part[j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < DS_NC; ++i) {
+            yv[j][i] = (g + LN_G * i < C) ? yv[j][i] : 0.f;
+            part[j] += yv[j][i];
+        }
+    }
+    reduce3(part);                                       // (also orders the parameter table before its first use)
+    float mu[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        mu[j] = part[j] / (float)C;
+        part[j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < DS_NC; ++i) part[j] = ln_sq_acc(part[j], yv[j][i] - mu[j], g + LN_G * i < C);
+    }
+    reduce3(part);
+    float xn[3][DS_NC];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float rstd = 1.0f / sqrtf(part[j] / (float)C + eps2);
+#pragma unroll
+        for (int i = 0; i < DS_NC; ++i) {
+            const int c = g + LN_G * i;
+            float o = ln_affine(yv[j][i], mu[j], rstd, par[c], par[CP + c]);
+            o = gelu_erf(o);
+            o += xv[j][i];
+            xn[j][i] = o;
+        }
+    }
+    if (ok) {
+#pragma unroll
+        for (int i = 0; i < DS_NC; ++i) {
+            const int c = g + LN_G * i;
+            if (c < C) xo[ibase + (size_t)c * T + t] = xn[1][i];
+        }
+    }
+    // ---- depthwise taps on x_new * mask, LN_1', gelu ----
+    float v[DS_NC];
+    float p1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < DS_NC; ++i) {
+        const int c = g + LN_G * i;
+        float a = par[7 * CP + c];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) a = fmaf(par[(4 + j) * CP + c], tv[j] ? xn[j][i] : 0.f, a);
+        v[i] = (ok && c < C) ? a : 0.f;
+        p1 += v[i];
+    }
+    float pr[3] = {p1, 0.f, 0.f};
+    reduce3(pr);
+    const float mu1 = pr[0] / (float)C;
+    p1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < DS_NC; ++i) p1 = ln_sq_acc(p1, v[i] - mu1, g + LN_G * i < C);
+    pr[0] = p1; pr[1] = 0.f; pr[2] = 0.f;
+    reduce3(pr);
+    const float rstd1 = 1.0f / sqrtf(pr[0] / (float)C + eps1);
+    if (!ok) return;
+    const bool live = t < len;
+#pragma unroll
+    for (int i = 0; i < DS_NC; ++i) {
+        const int c = g + LN_G * i;
+        float o = ln_affine(v[i], mu1, rstd1, par[2 * CP + c], par[3 * CP + c]);
+        o = gelu_erf(o);
+        if (c < C) zo[ibase + (size_t)c * T + t] = live ? o : 0.f;
+    }
 }
 
 // Self-attention with windowed relative-position embeddings, heads_share = True
@@ -798,6 +959,23 @@ int amp_layer_norm_c_ragged(const float* x_dev, const float* res_dev, const floa
                             void* stream) {
     return layer_norm_run("amp_layer_norm_c_ragged", x_dev, res_dev, gamma_dev, beta_dev, post_dev, lens_dev, nullptr, nullptr, 0, 1, B,
                           C, T, eps, gelu, y_dev, stream);
+}
+
+int amp_dds_seam(const float* y_dev, const float* x_dev, const float* gamma2_dev, const float* beta2_dev, float eps2,
+                 const float* dw_weight_dev, const float* dw_bias_dev, int K, int dilation, const float* gamma1_dev, const float* beta1_dev,
+                 float eps1, const int* lens_dev, int B, int C, int T, float* x_out_dev, float* z_out_dev, void* stream) {
+    VT_CHECK(y_dev && x_dev && gamma2_dev && beta2_dev && dw_weight_dev && gamma1_dev && beta1_dev && x_out_dev && z_out_dev && B > 0 &&
+                 C > 0 && T > 0 && B <= 65535 && dilation > 0, "amp_dds_seam: bad argument");
+    VT_CHECK(x_out_dev != y_dev && z_out_dev != y_dev && z_out_dev != x_dev && x_out_dev != x_dev && x_out_dev != z_out_dev,
+             "amp_dds_seam: the outputs must not alias the inputs (neighbouring columns are re-read)");
+    if (K != 3 || C > LN_G * DS_NC) {
+        set_error("amp_dds_seam: K = %d, C = %d outside the fused form (K = 3, C <= %d): run amp_layer_norm_c + amp_dwconv_layer_norm_c", K, C, LN_G * DS_NC);
+        return AMP_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(dds_seam_kernel, dim3((T + LN_TT - 1) / LN_TT, B), dim3(256), 0, (hipStream_t)stream, y_dev, x_dev, gamma2_dev,
+                       beta2_dev, dw_weight_dev, dw_bias_dev, gamma1_dev, beta1_dev, lens_dev, x_out_dev, z_out_dev, C, T, dilation, eps2, eps1);
+    VT_LAUNCHED("amp_dds_seam");
+    return AMP_OK;
 }
 
 int amp_dwconv_layer_norm_c(const float* x_dev, const float* dw_weight_dev, const float* dw_bias_dev, int K, int dilation,

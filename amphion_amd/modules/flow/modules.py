@@ -173,14 +173,23 @@ class DDSConv(nn.Module):
         """:63-72 in eval mode (the optional ``x + g`` of :61-62 is fused into the conv that produces x by the callers).
         ``mask_output=False``: the caller masks (ConvFlow's fused projection + spline)."""
         x = _lib.require_device_tensor(x, "DDSConv input")
+        z = None                                           # gelu(norm_1(conv_sep(x * mask))) of the NEXT layer when the seam kernel made it
         for i in range(self.n_layers):
             sep, n1 = self.convs_sep[i], self.norms_1[i]
-            if sep.weight.shape[-1] == 3:                  # conv(x * mask) -> norm -> gelu in one launch
+            if z is not None:
+                y = z
+            elif sep.weight.shape[-1] == 3:                # conv(x * mask) -> norm -> gelu in one launch
                 y = hip_ops.dwconv_layer_norm_c(x, sep.weight.detach().contiguous(), sep.bias.detach().contiguous(), sep.dilation,
                                                 n1.gamma.detach(), n1.beta.detach(), lens=lens, eps=n1.eps, gelu=True)
             else:
                 y = n1(sep(x, lens), gelu=True)
             y = self.convs_1x1[i](y)
+            z = None
+            if i + 1 < self.n_layers:                      # x + gelu(norm_2(y)) AND the next layer's conv_sep -> norm_1 -> gelu: one launch
+                r = hip_ops.dds_seam(y, x, self.norms_2[i], self.convs_sep[i + 1], self.norms_1[i + 1], lens)
+                if r is not None:
+                    x, z = r
+                    continue
             x = self.norms_2[i](y, gelu=True, post=x)      # x + gelu(norm(y))
         return hip_ops.sequence_mask_(x, lens) if (lens is not None and mask_output) else x
 

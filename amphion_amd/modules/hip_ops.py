@@ -260,6 +260,20 @@ def dwconv_layer_norm_c(x, weight, bias, dilation, gamma, beta, lens=None, eps=1
     return y
 
 
+def dds_seam(y, x, n2, sep, n1, lens=None):
+    """The seam between DDSConv layers i and i + 1 in one launch: ``x_new = x + gelu(n2(y))``; ``z = gelu(n1(sep(x_new * mask)))``
+    -> (x_new, z), or None when the shape is outside the fused kernel (depthwise K = 3, C <= 192)."""
+    B, C, T = y.shape
+    w = sep.weight.detach()
+    if w.shape[-1] != 3 or C > 192:
+        return None
+    xo, zo = torch.empty_like(y), torch.empty_like(y)
+    _lib.check(_lib.lib().amp_dds_seam(_ptr(y), _ptr(x), _ptr(n2.gamma.detach()), _ptr(n2.beta.detach()), float(n2.eps), _ptr(w.contiguous()),
+                                       _ptr(sep.bias.detach()), 3, int(sep.dilation), _ptr(n1.gamma.detach()), _ptr(n1.beta.detach()),
+                                       float(n1.eps), _ptr(lens), B, C, T, _ptr(xo), _ptr(zo), _stream(y)))
+    return xo, zo
+
+
 def add_channel_bias_(x, cb):
     """x [B, C, T] += cb [B, C, 1] in place (x + cond(g) for a length-1 condition)"""
     B, C, T = x.shape

@@ -244,6 +244,14 @@ int amp_layer_norm_c_ragged(const float* x_dev, const float* res_dev, const floa
 int amp_dwconv_layer_norm_c(const float* x_dev, const float* dw_weight_dev, const float* dw_bias_dev, int K, int dilation,
                             const float* gamma_dev, const float* beta_dev, const int* lens_dev, int B, int C, int T, float eps,
                             int gelu, float* y_dev, void* stream);
+/* The seam between DDSConv layers i and i + 1 (modules/flow/modules.py:63-70) in one launch:
+ *     x_out = x + gelu(LN(y; gamma2, beta2))                    norms_2[i] on the 1 x 1 conv's output y, residual x
+ *     z_out = gelu(LN(dwconv(x_out * mask); gamma1, beta1))     convs_sep[i+1] -> norms_1[i+1]
+ * Same bits as amp_layer_norm_c (gelu, post = x) followed by amp_dwconv_layer_norm_c.  K = 3 and C <= 192, AMP_ERR_UNSUPPORTED
+ * otherwise; z_out is zero beyond lens[b], x_out is not masked; the outputs must not alias the inputs. */
+int amp_dds_seam(const float* y_dev, const float* x_dev, const float* gamma2_dev, const float* beta2_dev, float eps2,
+                 const float* dw_weight_dev, const float* dw_bias_dev, int K, int dilation, const float* gamma1_dev, const float* beta1_dev,
+                 float eps1, const int* lens_dev, int B, int C, int T, float* x_out_dev, float* z_out_dev, void* stream);
 /* x[b, c, :] += cb[b, c]: the broadcast add of a length-1 condition, x + cond(g) (hifigan.py:426-427,
  * stochastic_duration_predictor.py:64-66). */
 int amp_add_channel_bias(float* x_dev, const float* cb_dev, int B, int C, int T, void* stream);

@@ -238,3 +238,58 @@ def test_spline_flow_with_fused_projection(inverse, flip):
     ref = torch.cat([z[:, :1], y1], 1) * mask
     ref = torch.flip(ref, [1]) if flip else ref
     assert (got - ref).abs().max().item() <= 2e-4, (got - ref).abs().max().item()
+
+
+@pytest.mark.parametrize("C,T,dil,lens", [(192, 100, 3, [100, 37, 1]), (192, 100, 9, [100, 60, 8]), (24, 70, 3, [33, 70, 64]), (7, 5, 1, [5, 2, 1])])
+def test_dds_seam_bitwise(C, T, dil, lens):
+    """amp_dds_seam == amp_layer_norm_c (gelu, post) followed by amp_dwconv_layer_norm_c, bit for bit."""
+    from amphion_amd.modules import hip_ops
+    from amphion_amd.modules.base import LayerNorm
+    from amphion_amd.modules.flow.modules import DepthwiseConv1d
+
+    torch.manual_seed(C + T + dil)
+    B = len(lens)
+    ld = torch.tensor(lens, dtype=torch.int32).cuda()
+    n2, n1 = LayerNorm(C).cuda(), LayerNorm(C).cuda()
+    sep = DepthwiseConv1d(C, 3, dil).cuda()
+    with torch.no_grad():
+        for n in (n2, n1):
+            n.gamma.normal_(1.0, 0.2)
+            n.beta.normal_(0.0, 0.1)
+    y, x = torch.randn(B, C, T).cuda(), torch.randn(B, C, T).cuda()
+    with torch.no_grad():
+        x_ref = n2(y, gelu=True, post=x)
+        z_ref = hip_ops.dwconv_layer_norm_c(x_ref, sep.weight.detach().contiguous(), sep.bias.detach().contiguous(), dil, n1.gamma.detach(),
+                                            n1.beta.detach(), lens=ld, eps=n1.eps, gelu=True)
+        x_new, z = hip_ops.dds_seam(y, x, n2, sep, n1, ld)
+    assert torch.equal(x_new, x_ref)
+    assert torch.equal(z, z_ref)
+    with torch.no_grad():                                  # no lengths
+        z_ref = hip_ops.dwconv_layer_norm_c(x_ref, sep.weight.detach().contiguous(), sep.bias.detach().contiguous(), dil, n1.gamma.detach(),
+                                            n1.beta.detach(), eps=n1.eps, gelu=True)
+        assert torch.equal(hip_ops.dds_seam(y, x, n2, sep, n1, None)[1], z_ref)
+
+
+def test_ddsconv_module_equals_unfused_layers():
+    """DDSConv.forward (seam kernel between the layers) == its layers run one launch at a time."""
+    from amphion_amd.modules import hip_ops
+    from amphion_amd.modules.flow.modules import DDSConv
+
+    torch.manual_seed(3)
+    m = DDSConv(192, 3, 3).cuda().eval()
+    with torch.no_grad():
+        for n in list(m.norms_1) + list(m.norms_2):
+            n.gamma.normal_(1.0, 0.2)
+            n.beta.normal_(0.0, 0.1)
+    x = torch.randn(3, 192, 90).cuda()
+    ld = torch.tensor([90, 41, 7], dtype=torch.int32).cuda()
+    with torch.no_grad():
+        got = m(x, ld)
+        r = x
+        for i in range(3):
+            yy = hip_ops.dwconv(r, m.convs_sep[i].weight.detach().contiguous(), m.convs_sep[i].bias.detach().contiguous(), ld, m.convs_sep[i].dilation)
+            yy = m.norms_1[i](yy, gelu=True)
+            yy = m.convs_1x1[i](yy)
+            r = m.norms_2[i](yy, gelu=True, post=r)
+        want = hip_ops.sequence_mask_(r, ld)
+    assert torch.equal(got, want)
