@@ -92,10 +92,11 @@ class HipConv1d(ConvParams):
         T = x.shape[-1] if T is None else T
         L = _lib.lib()
         h = self._ensure(dev)
-        Tout = L.amp_conv_out_len(h, T)
+        # amp_conv_out_len, without the call
+        Tout = (T - 1) * self.stride - 2 * self.padding + self.k if self.transposed else T + 2 * self.padding - self.dilation * (self.k - 1)
         if out is None:
             out = torch.empty((B, self.cout, Tout), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             if lens is not None:
                 _lib.check(L.amp_conv_forward_ragged(h, _ptr(x), int(x_batch_stride or 0), B, T, _ptr(lens), slope_in, _ptr(res),
                                                      slope_out, _ptr(out), _lib.current_stream_ptr(dev)))
@@ -147,7 +148,7 @@ class MergedConv1d:
         B, _, T = x.shape
         h = self._ensure(convs, x.device)
         out = torch.empty((B, sum(c.cout for c in convs), T), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.lib().amp_conv_forward_ragged(h, _ptr(x), 0, B, T, _ptr(lens), 1.0, None, 1.0, _ptr(out),
                                                           _lib.current_stream_ptr(x.device)))
         return out
@@ -185,7 +186,7 @@ def wn_fused(in_layers, res_skip_layers, x, cond, lens, out, acts):
     arr_i = (ctypes.c_void_p * n)(*hi)
     arr_r = (ctypes.c_void_p * n)(*hr)
     bs = cond.stride(0) if cond is not None else 0
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.check(_lib.lib().amp_wn_forward(arr_i, arr_r, n, _ptr(x), _ptr(cond), bs, _ptr(lens), B, T, _ptr(acts), _ptr(out),
                                              _lib.current_stream_ptr(dev)))
     return True
