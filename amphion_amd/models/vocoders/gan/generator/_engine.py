@@ -8,6 +8,7 @@ inside the handle is rebuilt lazily whenever a parameter changes.
 from __future__ import annotations
 
 import ctypes
+import os
 import threading
 import warnings
 import weakref
@@ -22,6 +23,7 @@ from amphion_amd import _lib
 # locks must not travel with torch.save(model) / copy.deepcopy(model).
 _graph_caches = weakref.WeakKeyDictionary()
 _graph_lock = threading.Lock()
+_GRAPH_CACHE_ON = os.environ.get("AMP_GRAPH_CACHE", "1") != "0"      # AMP_GRAPH_CACHE=0: forward_graphed always runs eagerly (A/B switch)
 
 
 def _norm_except_dim0(v: torch.Tensor) -> torch.Tensor:
@@ -397,7 +399,7 @@ class HipGenerator(nn.Module):
         return self._amp_forward(x, g, lengths=lengths)
 
     # ---- hipGraph capture (launch-bound small batches) ----
-    def capture(self, B, T, g_shape=None, ragged=False):
+    def capture(self, B, T, g_shape=None, ragged=False, workspace=None):
         """Capture one forward at a fixed shape into a hipGraph and return ``(replay, static_in, static_out)``.
 
         A forward is 51 (HiFi-GAN V1) dependent kernel launches; for a single utterance each of them runs a few
@@ -427,7 +429,11 @@ class HipGenerator(nn.Module):
         with torch.cuda.stream(side), torch.no_grad():
             self._amp_forward(static_in, static_g, lens_dev=static_lens)      # warm-up: handle, function attributes, side streams
             need = _lib.lib().amp_gen_workspace_bytes(self._amp_handle, B, T)
-            ws = torch.empty(need, dtype=torch.uint8, device=dev)   # the graph's own scratch
+            # the graph's own scratch -- or the caller's (forward_graphed: one scratch shared by all of a generator's graphs, which
+            # replay one at a time on one stream)
+            ws = workspace if workspace is not None else torch.empty(need, dtype=torch.uint8, device=dev)
+            if ws.numel() < need or ws.device != dev:
+                raise ValueError("capture(): workspace too small for this (B, T)")
             self._amp_forward(static_in, static_g, workspace=ws, lens_dev=static_lens)
         torch.cuda.current_stream(dev).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
@@ -436,8 +442,9 @@ class HipGenerator(nn.Module):
         self.set_profiling(was_profiling)
         epoch, handle = self._amp_epoch, self._amp_handle.value
 
-        def replay():
-            if self._amp_epoch != epoch or self._amp_handle is None or self._amp_handle.value != handle or not self._amp_unchanged():
+        def replay(check=True):
+            # (check=False: the caller has just run _amp_ensure, whose walk over every parameter is the expensive part of this test)
+            if self._amp_epoch != epoch or self._amp_handle is None or self._amp_handle.value != handle or (check and not self._amp_unchanged()):
                 raise RuntimeError("captured graph is stale: the generator's parameters / device / precision changed "
                                    "after capture(); capture again")
             graph.replay()
@@ -451,8 +458,8 @@ class HipGenerator(nn.Module):
 
     # ---- cached graphs for repeated small shapes (single utterances) ----
     GRAPH_BUCKET_FRAMES = 32        # shapes are rounded up to a multiple of this many frames
-    GRAPH_MAX_FRAMES = 1024         # larger batches run eagerly: a graph owns its buffers (~0.3 MB per frame for HiFi-GAN V1) and gains less and less
-    GRAPH_MAX_ENTRIES = 4
+    GRAPH_MAX_FRAMES = 1024         # larger batches run eagerly: the gain shrinks with the batch
+    GRAPH_MAX_ENTRIES = 48          # graphs share ONE scratch (sized for GRAPH_MAX_FRAMES); each owns only its input / output tensors (~1.3 MB)
 
     def forward_graphed(self, x, lengths=None, clone=True):
         """``forward`` / ``forward_ragged`` of a small batch through a cached hipGraph: the (B, T) shape is rounded up to a bucket of
@@ -468,7 +475,7 @@ class HipGenerator(nn.Module):
         x = _lib.require_device_tensor(x, "generator input")
         B, C, T = x.shape
         eager = lambda: self._amp_forward(x, lengths=lengths)
-        if (B * T > self.GRAPH_MAX_FRAMES or self._amp_profiling or torch.is_grad_enabled() and (x.requires_grad or self.training)
+        if (not _GRAPH_CACHE_ON or B * T > self.GRAPH_MAX_FRAMES or self._amp_profiling or torch.is_grad_enabled() and (x.requires_grad or self.training)
                 or torch.cuda.is_current_stream_capturing()):
             return eager()
         if lengths is not None:
@@ -488,21 +495,46 @@ class HipGenerator(nn.Module):
             ent = cache.get(key)
             if ent is None:                         # first sight of this bucket: run it eagerly, capture if it comes again
                 cache[key] = "seen"
-                while len(cache) > self.GRAPH_MAX_ENTRIES + 1:
-                    cache.pop(next(k for k in cache if k != "epoch"))
+                while sum(1 for k in cache if isinstance(k, tuple)) > self.GRAPH_MAX_ENTRIES:
+                    cache.pop(next(k for k in cache if isinstance(k, tuple)))
                 return eager()
             if ent == "seen":
-                ent = cache[key] = self.capture(B, Tb, ragged=True)
+                ws = cache.get("ws")
+                need = _lib.lib().amp_gen_workspace_bytes(self._amp_handle, B, Tb)
+                if ws is None or ws.device != x.device:
+                    cap = _lib.lib().amp_gen_workspace_bytes(self._amp_handle, 1, self.GRAPH_MAX_FRAMES)
+                    ws = cache["ws"] = torch.empty(max(need, cap + cap // 8), dtype=torch.uint8, device=x.device)
+                if ws.numel() < need:                   # (a shape whose scratch outgrows the shared one: leave it eager)
+                    return eager()
+                ent = cache[key] = self.capture(B, Tb, ragged=True, workspace=ws)
             replay, static_in, static_out = ent
+            # the graphs share one scratch: a replay on ANOTHER stream than the previous one first waits for that one to finish
+            st = torch.cuda.current_stream(x.device)
+            last = cache.get("last")
+            if last is not None and last[0] != st:
+                st.wait_event(last[1])
             static_in[:, :, :T].copy_(x)            # frames beyond an item's length are never read (the kernels select on the lengths)
             lens_key = tuple(lt.tolist())
             if getattr(replay, "lens_key", None) != lens_key:      # the lengths the buffer already holds need no second upload
-                replay.static_lens.copy_(lt)
+                pin = getattr(replay, "lens_pin", None)
+                if pin is None:
+                    pin = replay.lens_pin = torch.empty(B, dtype=torch.int32).pin_memory()
+                st.synchronize() if getattr(replay, "lens_inflight", False) else None   # (the pinned staging of the previous upload)
+                pin.copy_(lt)
+                replay.static_lens.copy_(pin, non_blocking=True)   # stream-ordered before the replay, no host synchronisation
+                replay.lens_inflight = True
                 replay.lens_key = lens_key
-            replay()
+            replay(check=False)
+            if last is None or last[0] != st:
+                ev = torch.cuda.Event()
+                cache["last"] = (st, ev)
+            else:
+                ev = last[1]
             hop = static_out.shape[-1] // Tb
             out = static_out[:, :, : T * hop]
-            return out.clone() if clone else out
+            out = out.clone() if clone else out
+            ev.record(st)
+            return out
 
     # ---- profiling hooks used by bench.py ----
     def set_profiling(self, slots=1):
