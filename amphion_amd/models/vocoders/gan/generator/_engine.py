@@ -516,13 +516,22 @@ class HipGenerator(nn.Module):
             static_in[:, :, :T].copy_(x)            # frames beyond an item's length are never read (the kernels select on the lengths)
             lens_key = tuple(lt.tolist())
             if getattr(replay, "lens_key", None) != lens_key:      # the lengths the buffer already holds need no second upload
-                pin = getattr(replay, "lens_pin", None)
-                if pin is None:
-                    pin = replay.lens_pin = torch.empty(B, dtype=torch.int32).pin_memory()
-                st.synchronize() if getattr(replay, "lens_inflight", False) else None   # (the pinned staging of the previous upload)
-                pin.copy_(lt)
-                replay.static_lens.copy_(pin, non_blocking=True)   # stream-ordered before the replay, no host synchronisation
-                replay.lens_inflight = True
+                if B == 1:
+                    replay.static_lens.fill_(int(lt[0]))           # a one-element fill kernel on the stream: no staging at all
+                else:
+                    # pinned staging, four slots used in turn: a slot is rewritten only after the copy that read it has completed
+                    ring = getattr(replay, "lens_ring", None)
+                    if ring is None:
+                        ring = replay.lens_ring = [[torch.empty(B, dtype=torch.int32).pin_memory(), None] for _ in range(4)]
+                        replay.lens_slot = 0
+                    slot = ring[replay.lens_slot]
+                    replay.lens_slot = (replay.lens_slot + 1) % len(ring)
+                    if slot[1] is not None:
+                        slot[1].synchronize()
+                    slot[0].copy_(lt)
+                    replay.static_lens.copy_(slot[0], non_blocking=True)   # stream-ordered before the replay
+                    slot[1] = torch.cuda.Event()
+                    slot[1].record(st)
                 replay.lens_key = lens_key
             replay(check=False)
             if last is None or last[0] != st:
