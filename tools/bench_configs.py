@@ -162,7 +162,7 @@ def c1(reps):
             outs.append(wav_to_pcm16(wav[0, :, : mel.shape[-1] * 256]).cpu())
         return outs
 
-    one_pass(); torch.cuda.synchronize()
+    one_pass(); one_pass(); torch.cuda.synchronize()     # the second pass is where forward_graphed captures its buckets (~2 ms per bucket, once)
     wall = []
     for _ in range(max(3, reps)):
         t0 = time.perf_counter(); outs = one_pass(); torch.cuda.synchronize(); wall.append((time.perf_counter() - t0) * 1e3)
