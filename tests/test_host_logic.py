@@ -115,6 +115,42 @@ def test_kernel_policy_switches_validate_without_device():
         assert L.amp_set_pingpong(on) == 0
 
 
+def test_round4_switches_validate_without_device():
+    """amp_version 141; the concurrent-resblock and attention switches are plain host state with range checks; a handle-less
+    amp_gen_prepare_streams is refused with a message instead of touching a device."""
+    L = _lib.lib()
+    assert L.amp_version() >= 141
+    for mode in (0, 1, -1):
+        assert L.amp_set_resblock_streams(mode) == 0
+    with pytest.raises(_lib.AmpError) as ei:
+        _lib.check(L.amp_set_resblock_streams(2))
+    assert "amp_set_resblock_streams" in str(ei.value)
+    for on in (0, 1):
+        assert L.amp_set_rel_attention_tiled(on) == 0
+    with pytest.raises(_lib.AmpError) as ei:
+        _lib.check(L.amp_gen_prepare_streams(None))
+    assert "amp_gen_prepare_streams" in str(ei.value)
+
+
+def test_forward_graphed_cache_is_not_module_state():
+    """The graph cache and its lock live in a weak-keyed side table of _engine: a generator pickles / deep-copies without them
+    (a lock or a CUDAGraph in __dict__ would make torch.save(model) raise)."""
+    import copy
+    import pickle
+    from types import SimpleNamespace as NS
+
+    from amphion_amd.models.vocoders.gan.generator import _engine
+    from amphion_amd.models.vocoders.gan.generator.hifigan import HiFiGAN
+
+    hp = dict(resblock="1", upsample_rates=[4, 4], upsample_kernel_sizes=[8, 8], upsample_initial_channel=32,
+              resblock_kernel_sizes=[3, 5], resblock_dilation_sizes=[[1, 3], [1, 3]])
+    m = HiFiGAN(NS(preprocess=NS(n_mel=8, hop_size=16), model=NS(hifigan=NS(**hp))))
+    _engine._graph_caches.setdefault(m, {})["epoch"] = 0
+    m2 = copy.deepcopy(m)
+    assert m2 not in _engine._graph_caches and len(pickle.dumps(m)) > 0
+    assert _engine.HipGenerator.GRAPH_MAX_FRAMES <= 4096 and _engine.HipGenerator.GRAPH_BUCKET_FRAMES >= 8
+
+
 def test_c_abi_from_plain_c(tmp_path):
     """include/amphion_hip.h compiles as C99 and a plain-C program links against the library and exercises the
     no-GPU paths (tests/c/abi_smoke.c) -- the boundary is a C ABI, not a Python extension."""
