@@ -333,6 +333,8 @@ struct Config {
     int fuse_act = 0;
     int narrow_blk = 1;        // row-blocked conv kernel for 128- / 64-row convs (amp_set_conv_blk_narrow)
     int rb_streams = -1;       // resblocks of a stage on concurrent streams: -1 small launches only, 0 never, 1 always (amp_set_resblock_streams)
+    int rb_sum_frames = 1 << 20;   // concurrent mode: per-resblock results + one MRF-mean launch while B * T <= this many frames (AMP_RB_SUM_FRAMES, A/B switch;
+                                   // 0 = always chain).  Same-box sweep, profiles/r4_streams_sum_vs_chain.txt: the summed form wins at every batch size
     Config() {
         auto num = [](const char* name, int lo, int hi, int dflt) {
             const char* e = getenv(name);
@@ -346,6 +348,7 @@ struct Config {
         ampb_fusion = num("AMP_AMPB_FUSION", 0, 3, 1);
         conv_blk = num("AMP_CONV_BLK", 0, 3, kConvBlkDefault);
         rb_streams = num("AMP_RB_STREAMS", -1, 1, -1);
+        rb_sum_frames = num("AMP_RB_SUM_FRAMES", 0, 1 << 20, 1 << 20);
         const char* e = getenv("AMP_GROUP_MB");
         group_bytes = (e && atol(e) > 0) ? (size_t)atol(e) << 20 : 0;
     }
@@ -1551,7 +1554,7 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
         // A stage whose resblocks ALL end in a fused pair / whole-resblock kernel (HiFi-GAN, C <= 128) needs no chain: those kernels add
         // the accumulated y to their finished, rounded result, so each resblock stores its own result (mode 0) and one small launch forms
         // ((XS0 + XS1) + XS2) / n afterwards -- the same bits with one join instead of two chained cross-queue waits (~12 us each).
-        bool sum_stage = conc && d.resblock_type == 1 && !big && nk - 1 <= AMP_MRF_MAX_PARTS;
+        bool sum_stage = conc && d.resblock_type == 1 && !big && nk - 1 <= AMP_MRF_MAX_PARTS && (long long)B * T <= cfg().rb_sum_frames;
         for (int j = 0; sum_stage && j < nk; ++j) {
             const ResBlock& rb = g->rbs[(size_t)i * nk + j];
             const size_t last = rb.dil.size() - 1;

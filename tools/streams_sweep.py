@@ -13,7 +13,7 @@ cfg, m = bc.hifigan()
 L = _lib.lib()
 print(f"{'B':>3} {'frames':>7} {'sequential ms':>14} {'concurrent ms':>14} {'ratio':>6}")
 with torch.no_grad():
-    for B in (1, 2, 4, 8, 12, 16, 24, 32):
+    for B in [int(b) for b in os.environ.get("SWEEP_B", "1,2,4,8,12,16,24,32").split(",")]:
         mel = synthetic_mel(B, 80, 256, seed=5).to(bc.DEV)
         res = []
         for mode in (0, 1):
