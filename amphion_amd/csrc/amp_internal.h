@@ -96,6 +96,14 @@ struct PairArgs {
     unsigned* range_flag;      // see ConvArgs
 };
 
+// Three fused pairs in one grid (pair3_f16x3.hip): a[0] / a[1] / a[2] = the k = 11 / 7 / 3 pair of a stage's three resblocks (per-tile form:
+// tiles_per_item set), n[j] = B * a[j].tiles_per_item workgroups each
+struct Pair3Args {
+    PairArgs a[3];
+    int n[3];
+};
+hipError_t launch_pair3(const Pair3Args& p, hipStream_t stream);
+
 // Arguments of the whole-ResBlock kernel (rb_f16x3.hip): for p < np:  x = x + c2_p(lrelu(c1_p(lrelu(x))))   [then the MRF modes]
 constexpr int AMP_RB_MAX_PAIRS = 3;
 struct RbArgs {

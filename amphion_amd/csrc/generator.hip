@@ -333,6 +333,7 @@ struct Config {
     int fuse_act = 0;
     int narrow_blk = 1;        // row-blocked conv kernel for 128- / 64-row convs (amp_set_conv_blk_narrow)
     int rb_streams = -1;       // resblocks of a stage on concurrent streams: -1 small launches only, 0 never, 1 always (amp_set_resblock_streams)
+    int rb_horizontal = 1;     // concurrent mode: a stage's three fused pairs in ONE grid (pair3_f16x3.hip) where they apply (AMP_RB_HORIZONTAL=0: streams only)
     int rb_sum_frames = 1 << 20;   // concurrent mode: per-resblock results + one MRF-mean launch while B * T <= this many frames (AMP_RB_SUM_FRAMES, A/B switch;
                                    // 0 = always chain).  Same-box sweep, profiles/r4_streams_sum_vs_chain.txt: the summed form wins at every batch size
     Config() {
@@ -349,6 +350,7 @@ struct Config {
         conv_blk = num("AMP_CONV_BLK", 0, 3, kConvBlkDefault);
         rb_streams = num("AMP_RB_STREAMS", -1, 1, -1);
         rb_sum_frames = num("AMP_RB_SUM_FRAMES", 0, 1 << 20, 1 << 20);
+        rb_horizontal = num("AMP_RB_HORIZONTAL", 0, 1, 1);
         const char* e = getenv("AMP_GROUP_MB");
         group_bytes = (e && atol(e) > 0) ? (size_t)atol(e) << 20 : 0;
     }
@@ -814,6 +816,39 @@ static int pair_run(const amp_conv* c1, const amp_conv* c2, const float* x, int 
     a.tiles_per_item = (T + NT - 1) / NT;
     AMP_HIP(launch_pair(c1->k, a, stream));
     return AMP_OK;
+}
+
+// The arguments pair_run would launch the PER-TILE kernel with, without launching; false when this pair runs on the strip kernel (or
+// on no fused kernel at all).  For pair3_f16x3.hip, which runs three such pairs in one grid.
+static bool pair_tile_args(const amp_conv* c1, const amp_conv* c2, const float* x, int B, int T, float slope, float* y, int mode,
+                           float div, const int* lens, int len_mul, PairArgs* out) {
+    if (x == y || slope > 1.f || !pair_supported(c1, c2)) return false;
+    PairArgs a{};
+    a.x = x; a.y = y;
+    a.wp1 = c1->wp_dev; a.bias1 = c1->bias_dev; a.wp2 = c2->wp_dev; a.bias2 = c2->bias_dev;
+    a.B = B; a.C = c1->cin; a.T = T;
+    a.dil = c1->dilation;
+    a.slope = slope;
+    a.sc1 = 16.f * c1->wscale; a.isc1 = 1.f / a.sc1;
+    a.sc2 = 16.f * c2->wscale; a.isc2 = 1.f / a.sc2;
+    a.mode = mode; a.div = div;
+    a.lens = lens; a.len_mul = len_mul;
+    a.range_flag = range_flag_for_current_device();
+    a.rev = 0;
+    int wg = 2;
+    const StripChoice sc = strip_choice(c1->cin, c1->k);
+    const int n1 = sc.use ? strip_step(c1->k, c1->cin, c1->dilation, sc.wide, &wg) : 0;
+    if (n1 > 0) {       // pair_run's rule: the strips unless the grid cannot fill the chip twice over
+        int strip_len = 0, strips_per_item = 0;
+        strip_plan(B, T, n1, c1->k - 1, wg, &strip_len, &strips_per_item);
+        if (sc.steps > 0 && sc.steps * n1 - (c1->k - 1) < T) { strip_len = sc.steps * n1 - (c1->k - 1); strips_per_item = (T + strip_len - 1) / strip_len; }
+        if (!(cfg().pair_strips == -1 && sc.wide >= 2 && (long long)B * strips_per_item < 512)) return false;
+    }
+    const int NT = pair_tile(c1->k, c1->cin, c1->dilation);
+    if (NT <= 0) return false;
+    a.tiles_per_item = (T + NT - 1) / NT;
+    *out = a;
+    return true;
 }
 
 // Whole ResBlock1 in one launch (rb_f16x3.hip): x read once, y written once per resblock, the residual carried in
@@ -1388,6 +1423,7 @@ static int gen_num_bufs(const amp_gen* g) { return g->d.arch == AMP_ARCH_BIGVGAN
 // while B * T <= kRbStreamsMaxFrames mel frames; at full batches every launch fills the chip and the same idea measured 28.1 vs
 // 28.1 ms (round 2, BigVGAN, profiles/r2_i_bigvgan_streams.txt).  Works under stream capture (fork / join by events) once the side
 // streams exist: they are created by the first eager forward or by amp_gen_prepare_streams(), never inside a capture.
+constexpr long long kRbHorizontalMaxFrames = 1024;   // profiles/r4_streams_horizontal_sweep.txt: 0.81 / 0.90 / 0.91 against 0.84 / 0.94 / 0.95 on streams at 256 / 512 / 1 024 frames, equal at 2 048, behind at 4 096
 constexpr long long kRbStreamsMaxFrames = 4096;   // tools/streams_sweep.py, profiles/r4_streams_sweep.txt: 0.87-0.97 of the sequential time up to here, 1.00 beyond
 static int gen_side_bufs(const amp_gen* g) { return (g->d.n_kernels - 1) * (g->d.arch == AMP_ARCH_BIGVGAN ? 4 : 3); }   // R, TMP, XS (+ ACT) per extra resblock
 static bool gen_streams_wanted(const amp_gen* g, int B, int T) {
@@ -1550,6 +1586,47 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
         // accumulating launch done; the launch that accumulates resblock j >= 1 waits for evs[j], `st` joins on evs[nk].  (Measured
         // the other way round too -- the widest resblock on `st`, the others on the side streams: the same 0.81-0.83 ms as a graph
         // replay, but 1.08 instead of 0.90-0.95 ms eager, where the host issues the critical stream's launches last.)
+        // Horizontal form (pair3_f16x3.hip): where the stage's three resblocks (k = 11 / 7 / 3) run as per-tile fused pairs, pair p of all
+        // three shares ONE launch -- nd launches + the MRF mean instead of 3 nd launches on three streams with their fork / join events.
+        if (conc && cfg().rb_horizontal && (long long)B * T <= kRbHorizontalMaxFrames && d.resblock_type == 1 && !big && nk == 3) {
+            int slot_of[3] = {-1, -1, -1};                 // resblock index holding k = 11 / 7 / 3
+            bool okh = true;
+            for (int j = 0; j < 3; ++j) {
+                const int k = g->rbs[(size_t)i * nk + j].c1[0]->k;
+                const int sl = k == 11 ? 0 : k == 7 ? 1 : k == 3 ? 2 : -1;
+                if (sl < 0 || slot_of[sl] >= 0) { okh = false; break; }
+                slot_of[sl] = j;
+            }
+            const size_t nd0 = g->rbs[(size_t)i * nk].dil.size();
+            std::vector<Pair3Args> plan(okh ? nd0 : 0);
+            for (int sl = 0; okh && sl < 3; ++sl) {
+                const int j = slot_of[sl];
+                const ResBlock& rb = g->rbs[(size_t)i * nk + j];
+                if (rb.dil.size() != nd0) { okh = false; break; }
+                float* SB = SIDE + (size_t)(j > 0 ? j - 1 : 0) * side_per * be;
+                float* R_ = j > 0 ? SB : R;
+                float* TMP_ = j > 0 ? SB + be : TMP;
+                float* XSJ = j > 0 ? SB + 2 * be : XS;
+                const float* cur = U;
+                for (size_t p = 0; okh && p < nd0; ++p) {
+                    const bool last = p + 1 == nd0;
+                    float* dst = last ? XSJ : (cur == R_ ? TMP_ : R_);
+                    okh = pair_tile_args(rb.c1[p].get(), rb.c2[p].get(), cur, B, t, slope, dst, 0, (float)nk, lens, lm, &plan[p].a[sl]);
+                    if (okh) plan[p].n[sl] = B * plan[p].a[sl].tiles_per_item;
+                    cur = dst;
+                }
+            }
+            if (okh) {
+                for (size_t p = 0; p < nd0; ++p) AMP_HIP(launch_pair3(plan[p], st));
+                MrfSumArgs ma{};
+                ma.y = XS; ma.n = nk - 1; ma.div = (float)nk; ma.count = (size_t)B * C * t;
+                for (int j = 1; j < nk; ++j) ma.p[j - 1] = SIDE + ((size_t)(j - 1) * side_per + 2) * be;
+                AMP_HIP(launch_mrf_sum(ma, st));
+                if (ev_mrf) AMP_HIP(hipEventRecord(ev_mrf[2 * i + 1], st));
+                float* tmp = X; X = XS; XS = tmp;  // x = xs / num_kernels
+                continue;
+            }
+        }
         hipEvent_t* evs = conc ? &g->ev_side[(size_t)i * (nk + 1)] : nullptr;
         // A stage whose resblocks ALL end in a fused pair / whole-resblock kernel (HiFi-GAN, C <= 128) needs no chain: those kernels add
         // the accumulated y to their finished, rounded result, so each resblock stores its own result (mode 0) and one small launch forms

@@ -212,3 +212,30 @@ def test_resblock_streams_policy_is_small_launches_only():
         assert L.amp_set_resblock_streams(2) < 0
     finally:
         _lib.check(L.amp_set_resblock_streams(-1))
+
+
+def test_horizontal_pairs_kernel_is_exercised_and_bitwise():
+    """One utterance of HiFi-GAN V1: with concurrent resblocks on, stages 1-3 run as pair3_kernel launches (the k = 11 / 7 / 3 pairs of one
+    dilation in ONE grid, pair3_f16x3.hip) + the MRF-mean launch.  Same bits as the sequential chain, dense and ragged, and the library
+    reports the kernel it ran."""
+    import ctypes
+
+    from amphion_amd import _lib
+    from amphion_amd.models.vocoders.gan.generator.hifigan import HiFiGAN
+    from amphion_amd.utils.synthetic import randomize_, synthetic_mel
+
+    L = _lib.lib()
+    m = randomize_(HiFiGAN(NS(preprocess=NS(n_mel=80, hop_size=256), model=NS(hifigan=NS(**V1)))), 1234).cuda().eval()
+    mel = synthetic_mel(2, 80, 96, seed=11).cuda()
+    lens = [96, 41]
+    try:
+        with torch.no_grad():
+            _lib.check(L.amp_set_resblock_streams(0))
+            a, ar = m(mel).cpu(), m.forward_ragged(mel, lens).cpu()
+            _lib.check(L.amp_set_resblock_streams(1))
+            b, br = m(mel).cpu(), m.forward_ragged(mel, lens).cpu()
+    finally:
+        _lib.check(L.amp_set_resblock_streams(-1))
+    assert torch.equal(a, b)
+    for i, n in enumerate(lens):
+        assert torch.equal(ar[i, :, : n * 256], br[i, :, : n * 256])
