@@ -96,6 +96,14 @@ struct PairArgs {
     unsigned* range_flag;      // see ConvArgs
 };
 
+// Three whole-K convs in one grid (conv_small3_f16x3.hip): a[0] / a[1] / a[2] = the k = 11 / 7 / 3 conv (standard epilogue) of a stage's three
+// resblocks, nx[j] = B * tiles_per_item column tiles x ny[j] = ceil(M / 128) row groups each
+struct ConvSmall3Args {
+    ConvArgs a[3];
+    int nx[3], ny[3];
+};
+hipError_t launch_conv_small3(const ConvSmall3Args& p, const int ni[3], hipStream_t stream);
+
 // Three fused pairs in one grid (pair3_f16x3.hip): a[0] / a[1] / a[2] = the k = 11 / 7 / 3 pair of a stage's three resblocks (per-tile form:
 // tiles_per_item set), n[j] = B * a[j].tiles_per_item workgroups each
 struct Pair3Args {

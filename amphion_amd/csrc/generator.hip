@@ -637,9 +637,11 @@ static bool small_conv_covers(const amp_conv* c) { return small_conv_enabled() &
 static int small_conv_ni(const amp_conv* c) { return (c->halo_left + c->halo_right <= 32) ? 1 : 2; }
 
 // mode 0: y = v, 1: y += v, 2: y = (y + v) / div
+// plan_small != nullptr: launch nothing -- if this call would run the whole-K kernel with the standard epilogue, hand back its arguments and
+// tile width (for conv_small3_f16x3.hip, which runs three such convs in one grid), else AMP_ERR_UNSUPPORTED.
 static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope_in, const float* res, float slope_out,
                     float* y, int mode, float div, hipStream_t stream, long long xbs = 0, const int* lens = nullptr,
-                    int len_mul = 1) {
+                    int len_mul = 1, ConvArgs* plan_small = nullptr, int* plan_ni = nullptr) {
     if (B <= 0 || T <= 0) { set_error("amp_conv_forward: B=%d T=%d", B, T); return AMP_ERR_INVALID; }
     const int Tout = conv_out_len(c, T);
     if (Tout <= 0) { set_error("amp_conv_forward: input too short (T=%d)", T); return AMP_ERR_INVALID; }
@@ -674,6 +676,7 @@ static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope
         return AMP_ERR_UNSUPPORTED;
     }
     if (c->precision == PREC_F32) {
+        if (plan_small) return AMP_ERR_UNSUPPORTED;
         a.acc_scale = a.inv_scale = 1.f;
         AMP_HIP(launch_conv(plan, a, stream));
     } else {
@@ -695,6 +698,7 @@ static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope
             const int nt = blk_wn * (c->KT == 2 ? conv_blk_nt_kt2(cm, halo) : c->KT == 3 ? conv_blk_nt_kt3(cm, halo) : c->KT == 7 ? conv_blk_nt_kt7(cm, halo) : conv_blk_nt_kt11(cm, halo));
             if (nt > 0 && (long long)B * ((a.Tq + nt - 1) / nt) * (c->M / (256 / blk_wn)) >= kConvBlkMinWorkgroups) { blk_cm = cm; blk_nt = nt; }
         }
+        if (plan_small && !(blk_cm == 0 && plan.NI == 2 && small_conv_covers(c) && (c->KT <= 5 || wgs_half <= 128))) return AMP_ERR_UNSUPPORTED;
         if (blk_cm > 0) {
             const int rows = 256 / blk_wn;
             a.tiles_per_item = (a.Tq + blk_nt - 1) / blk_nt;
@@ -708,6 +712,7 @@ static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope
             a.Mpad = c->Mpad;
             a.tiles_per_item = (a.Tq + 32 * ni - 1) / (32 * ni);
             a.wd = 32 * ni + c->halo_left + c->halo_right;
+            if (plan_small) { *plan_small = a; *plan_ni = ni; return AMP_OK; }
             AMP_HIP(launch_conv_small(c->KT, ni, 0, a, stream));
         } else {
             const int nrg = (c->M + plan.Mgroup() - 1) / plan.Mgroup();
@@ -1622,6 +1627,74 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
                 ma.y = XS; ma.n = nk - 1; ma.div = (float)nk; ma.count = (size_t)B * C * t;
                 for (int j = 1; j < nk; ++j) ma.p[j - 1] = SIDE + ((size_t)(j - 1) * side_per + 2) * be;
                 AMP_HIP(launch_mrf_sum(ma, st));
+                if (ev_mrf) AMP_HIP(hipEventRecord(ev_mrf[2 * i + 1], st));
+                float* tmp = X; X = XS; XS = tmp;  // x = xs / num_kernels
+                continue;
+            }
+        }
+        // The same for a stage of UNFUSED whole-K convs (the C = 256 stage of a single utterance): c1 of a dilation, then c2, of all
+        // three resblocks in one launch each (conv_small3_f16x3.hip); only the three convs that accumulate into XS stay separate
+        // launches, in resblock order with their `=` / `+=` / `(y + v) / n` modes (they add y BEFORE the products: no post-hoc mean).
+        if (conc && cfg().rb_horizontal && (long long)B * T <= kRbHorizontalMaxFrames && d.resblock_type == 1 && !big && nk == 3) {
+            int slot_of[3] = {-1, -1, -1};
+            bool okh = true;
+            for (int j = 0; j < 3; ++j) {
+                const ResBlock& rb = g->rbs[(size_t)i * nk + j];
+                const int k = rb.c1[0]->k;
+                const int sl = k == 11 ? 0 : k == 7 ? 1 : k == 3 ? 2 : -1;
+                if (sl < 0 || slot_of[sl] >= 0 || pair_supported(rb.c1[0].get(), rb.c2[0].get())) { okh = false; break; }
+                slot_of[sl] = j;
+            }
+            const size_t nd0 = g->rbs[(size_t)i * nk].dil.size();
+            struct Step { ConvSmall3Args p; int ni[3]; };
+            std::vector<Step> steps;                        // c1(d_0), c2, c1(d_1), c2, ..., c1(d_last)
+            const float* cur[3] = {U, U, U};
+            float* Rj[3];
+            float* TMPj[3];
+            for (int j = 0; j < 3; ++j) {
+                float* SB = SIDE + (size_t)(j > 0 ? j - 1 : 0) * side_per * be;
+                Rj[j] = j > 0 ? SB : R;
+                TMPj[j] = j > 0 ? SB + be : TMP;
+            }
+            auto plan3 = [&](bool second, size_t p) -> bool {    // one merged launch: c1[p] (second = false) or c2[p] of the three resblocks
+                Step sp{};
+                for (int sl = 0; sl < 3; ++sl) {
+                    const int j = slot_of[sl];
+                    const ResBlock& rb = g->rbs[(size_t)i * nk + j];
+                    const amp_conv* c = second ? rb.c2[p].get() : rb.c1[p].get();
+                    const int rc = second ? conv_run(c, TMPj[j], B, t, 1.f, cur[j], 1.f, Rj[j], 0, 1.f, st, 0, lens, lm, &sp.p.a[sl], &sp.ni[sl])
+                                          : conv_run(c, cur[j], B, t, slope, nullptr, slope, TMPj[j], 0, 1.f, st, 0, lens, lm, &sp.p.a[sl], &sp.ni[sl]);
+                    if (rc != AMP_OK) return false;
+                    sp.p.nx[sl] = B * sp.p.a[sl].tiles_per_item;
+                    sp.p.ny[sl] = (sp.p.a[sl].M + 127) / 128;
+                }
+                if (sp.ni[1] != 1 || sp.ni[2] != 1) return false;
+                steps.push_back(sp);
+                return true;
+            };
+            for (size_t p = 0; okh && p < nd0; ++p) {
+                for (int j = 0; j < 3 && okh; ++j) okh = g->rbs[(size_t)i * nk + j].dil.size() == nd0;
+                okh = okh && plan3(false, p);
+                if (okh && p + 1 < nd0) {
+                    okh = plan3(true, p);
+                    for (int j = 0; j < 3; ++j) cur[j] = Rj[j];
+                }
+            }
+            if (okh) {
+                // the accumulating convs must be whole-K launches too (checked before anything is launched)
+                for (int j = 0; okh && j < 3; ++j) {
+                    ConvArgs tmp_a; int tmp_ni;
+                    const ResBlock& rb = g->rbs[(size_t)i * nk + j];
+                    okh = conv_run(rb.c2[nd0 - 1].get(), TMPj[j], B, t, 1.f, cur[j], 1.f, XS, j == 0 ? 0 : (j == nk - 1 ? 2 : 1), (float)nk, st, 0, lens, lm,
+                                   &tmp_a, &tmp_ni) == AMP_OK;
+                }
+            }
+            if (okh) {
+                for (const Step& sp : steps) AMP_HIP(launch_conv_small3(sp.p, sp.ni, st));
+                for (int j = 0; j < 3; ++j) {
+                    const ResBlock& rb = g->rbs[(size_t)i * nk + j];
+                    AMP_RC(conv_run(rb.c2[nd0 - 1].get(), TMPj[j], B, t, 1.f, cur[j], 1.f, XS, j == 0 ? 0 : (j == nk - 1 ? 2 : 1), (float)nk, st, 0, lens, lm));
+                }
                 if (ev_mrf) AMP_HIP(hipEventRecord(ev_mrf[2 * i + 1], st));
                 float* tmp = X; X = XS; XS = tmp;  // x = xs / num_kernels
                 continue;
