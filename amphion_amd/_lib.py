@@ -114,6 +114,7 @@ _SIGNATURES = {
     "amp_rel_attention_strided": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "amp_set_rel_attention_tiled": (c_int, [c_int]),
     "amp_set_resblock_streams": (c_int, [c_int]),
+    "amp_set_wn_layer_fusion": (c_int, [c_int]),
     "amp_gen_prepare_streams": (c_int, [c_void_p]),
     "amp_rel_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "amp_dwconv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -96,6 +96,15 @@ struct PairArgs {
     unsigned* range_flag;      // see ConvArgs
 };
 
+// A whole WN layer in one launch (wn_layer_f16x3.hip): g = the gated in-layer conv's arguments (EPI_GATE fields; y unused), r = the res_skip
+// conv's (EPI_WNACC fields; wn_x = the x this layer READS, x unused), x_out = where x' = (x + rs[:H]) * mask goes (never wn_x itself)
+struct WnLayerArgs {
+    ConvArgs g;
+    ConvArgs r;
+    float* x_out;
+};
+hipError_t launch_wn_layer(int kt, int nw, const WnLayerArgs& p, hipStream_t stream);
+
 // Three whole-K convs in one grid (conv_small3_f16x3.hip): a[0] / a[1] / a[2] = the k = 11 / 7 / 3 conv (standard epilogue) of a stage's three
 // resblocks, nx[j] = B * tiles_per_item column tiles x ny[j] = ceil(M / 128) row groups each
 struct ConvSmall3Args {

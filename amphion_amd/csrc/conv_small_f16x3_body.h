@@ -354,7 +354,8 @@ __device__ __forceinline__ void conv_small_body(const ConvArgs a, const int bx, 
                 float* yr = yw + (size_t)(i + 8 * u) * a.Tout;     // channel 16*mb + i + 4*hi + 8*u
 #pragma unroll
                 for (int t = 0; t < NI; ++t) {
-                    if (qok[t] && mb_ok) {
+                    if (qok[t] && mb * 32 < a.M) {     // (M = 2H; the packed rows are padded to a multiple of 128: a block beyond M holds no channel --
+                                                       //  round 4: it was stored, over the next item's first rows, when H was no multiple of 64)
                         const float at = acc[t][4 * (2 * u) + i] * a.inv_scale;
                         const float as = acc[t][4 * (2 * u + 1) + i] * a.inv_scale;
                         yr[hi4T + (unsigned)(qw + 32 * t)] = fast_tanh(at) * fast_sigmoid(as);

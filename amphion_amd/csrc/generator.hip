@@ -333,6 +333,8 @@ struct Config {
     int fuse_act = 0;
     int narrow_blk = 1;        // row-blocked conv kernel for 128- / 64-row convs (amp_set_conv_blk_narrow)
     int rb_streams = -1;       // resblocks of a stage on concurrent streams: -1 small launches only, 0 never, 1 always (amp_set_resblock_streams)
+    int wn_layer = 0;          // one-launch WN layer (wn_layer_f16x3.hip): 0 = two launches per layer (default: the fused form measured EQUAL),
+                               // 4 / 8 / 12 = waves per workgroup (amp_set_wn_layer_fusion)
     int rb_horizontal = 1;     // concurrent mode: a stage's three fused pairs in ONE grid (pair3_f16x3.hip) where they apply (AMP_RB_HORIZONTAL=0: streams only)
     int rb_sum_frames = 1 << 20;   // concurrent mode: per-resblock results + one MRF-mean launch while B * T <= this many frames (AMP_RB_SUM_FRAMES, A/B switch;
                                    // 0 = always chain).  Same-box sweep, profiles/r4_streams_sum_vs_chain.txt: the summed form wins at every batch size
@@ -2049,9 +2051,29 @@ int amp_wn_forward(const amp_conv* const* in_layers, const amp_conv* const* res_
             return AMP_ERR_INVALID;
         }
     }
+    // one launch per layer (wn_layer_f16x3.hip) where the layers qualify: x ping-pongs between x_dev and acts_ws_dev (acts itself never
+    // leaves the CU); else two launches per layer with acts through acts_ws_dev
+    bool one_launch = cfg().wn_layer != 0;
+    for (int i = 0; one_launch && i < n_layers; ++i)
+        one_launch = small_conv_ni(in_layers[i]) == 1 && small_conv_ni(res_skip_layers[i]) == 1 && (in_layers[i]->KT == 1 || in_layers[i]->KT == 3 || in_layers[i]->KT == 5);
+    float* xc = x_dev;            // the x the next layer reads
+    float* xn = acts_ws_dev;
     for (int i = 0; i < n_layers; ++i) {
         ConvArgs a;
         const int ni_in = small_conv_ni(in_layers[i]), ni_rs = small_conv_ni(res_skip_layers[i]);
+        if (one_launch) {
+            WnLayerArgs p{};
+            small_args(in_layers[i], xc, B, T, lens_dev, 1, &p.g);
+            p.g.wn_H = H;
+            p.g.gate_cond = cond_dev ? cond_dev + (size_t)i * 2 * H : nullptr;
+            p.g.gate_cond_bs = cond_batch_stride;
+            small_args(res_skip_layers[i], xc, B, T, lens_dev, 1, &p.r);
+            p.r.wn_H = H; p.r.wn_x = xc; p.r.wn_out = out_dev; p.r.wn_first = i == 0; p.r.wn_last = i == n_layers - 1;
+            p.x_out = xn;
+            AMP_HIP(launch_wn_layer(in_layers[i]->KT, cfg().wn_layer, p, stream));
+            if (i < n_layers - 1) { float* t_ = xc; xc = xn; xn = t_; }
+            continue;
+        }
         small_args(in_layers[i], x_dev, B, T, lens_dev, ni_in, &a);       // in_layers[i](x * mask) + g_l -> tanh * sigmoid (round 4: the mask is the kernel's
                                                                           // select at staging, so the caller's x need not be masked; tiles beyond an end are skipped)
         a.y = acts_ws_dev; a.wn_H = H;
@@ -2063,6 +2085,12 @@ int amp_wn_forward(const amp_conv* const* in_layers, const amp_conv* const* res_
         a.wn_H = H; a.wn_x = x_dev; a.wn_out = out_dev; a.wn_first = i == 0; a.wn_last = i == n_layers - 1;
         AMP_HIP(launch_conv_small(1, ni_rs, 2, a, stream));
     }
+    return AMP_OK;
+}
+
+int amp_set_wn_layer_fusion(int mode) {
+    if (mode != -1 && mode != 0 && mode != 4 && mode != 8 && mode != 12) { set_error("amp_set_wn_layer_fusion: mode=%d (0 off, 4 / 8 / 12 waves, -1 default)", mode); return AMP_ERR_INVALID; }
+    cfg().wn_layer = mode < 0 ? 0 : mode;
     return AMP_OK;
 }
 

@@ -429,6 +429,12 @@ int amp_wn_forward(const amp_conv* const* in_layers, const amp_conv* const* res_
                    const float* cond_dev, long long cond_batch_stride, const int32_t* lens_dev, int B, int T,
                    float* acts_ws_dev, float* out_dev, void* stream);
 
+/* 4 / 8 / 12: every layer of amp_wn_forward is ONE launch (csrc/wn_layer_f16x3.hip: gated conv -> acts in LDS -> res_skip conv ->
+ * residual / skip update, that many waves per workgroup; x then ping-pongs between x_dev and acts_ws_dev, and which of the two holds
+ * the final x is unspecified); 0 (default; also -1): two launches per layer.  Same bits in every mode; measured equal in time
+ * (DESIGN.md 3.1b), so the default stays with the older path. */
+int amp_set_wn_layer_fusion(int mode);
+
 /* ---- VITS posterior encoder + flow (config 5): element-wise pieces between the convs ---- */
 
 /* fused_add_tanh_sigmoid_multiply (utils/util.py:602-609) as called by WN.forward
