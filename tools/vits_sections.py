@@ -10,6 +10,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
+SKIP_DEC = "--no-decoder" in sys.argv      # text side only, back to back: its weights stay hot in L2 / the Infinity Cache
+
+
 def main():
     import bench_configs as bc
     from amphion_amd import _lib
@@ -52,7 +55,7 @@ def main():
         z = net.flow(z_p, y_lengths, g=None, reverse=True)
         ev[5].record(); ts.append(time.perf_counter())
         zm = hip_ops.sequence_mask_(z.clone(), y_lengths)
-        o = net._dec_exact(zm, None)
+        o = net._dec_exact(zm, None) if not SKIP_DEC else zm
         ev[6].record(); ts.append(time.perf_counter())
         _lib.range_check(x.device)
         ev[7].record(); ts.append(time.perf_counter())
