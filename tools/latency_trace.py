@@ -10,8 +10,15 @@ if "--run" in sys.argv:
     import bench_configs as bc
     from amphion_amd.utils.synthetic import synthetic_mel
     T = int(sys.argv[sys.argv.index("--frames") + 1]) if "--frames" in sys.argv else 256
-    cfg, m = bc.hifigan()
-    mel = synthetic_mel(1, 80, T, seed=5).cuda()
+    if "--bigvgan" in sys.argv:
+        from types import SimpleNamespace as NS
+        from amphion_amd.models.vocoders.gan.generator.bigvgan import BigVGAN
+        hp = dict(bc.V1, activation="snakebeta", snake_logscale=True)
+        m = bc.randomize_(BigVGAN(NS(preprocess=NS(n_mel=100, hop_size=256), model=NS(bigvgan=NS(**hp)))), 1234, g_gain=0.75).cuda().eval()
+        mel = torch.randn(1, 100, T, generator=torch.Generator().manual_seed(0)).cuda()
+    else:
+        cfg, m = bc.hifigan()
+        mel = synthetic_mel(1, 80, T, seed=5).cuda()
     with torch.no_grad():
         for _ in range(12):
             m(mel)
