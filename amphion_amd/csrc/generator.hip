@@ -336,6 +336,7 @@ struct Config {
     int wn_layer = 0;          // one-launch WN layer (wn_layer_f16x3.hip): 0 = two launches per layer (default: the fused form measured EQUAL),
                                // 4 / 8 / 12 = waves per workgroup (amp_set_wn_layer_fusion)
     int rb_horizontal = 1;     // concurrent mode: a stage's three fused pairs in ONE grid (pair3_f16x3.hip) where they apply (AMP_RB_HORIZONTAL=0: streams only)
+    int rb_horizontal_frames = 0;  // ... while B * T <= this many frames (AMP_RB_HORIZONTAL_FRAMES; 0 = kRbHorizontalMaxFrames)
     int rb_sum_frames = 1 << 20;   // concurrent mode: per-resblock results + one MRF-mean launch while B * T <= this many frames (AMP_RB_SUM_FRAMES, A/B switch;
                                    // 0 = always chain).  Same-box sweep, profiles/r4_streams_sum_vs_chain.txt: the summed form wins at every batch size
     Config() {
@@ -353,6 +354,7 @@ struct Config {
         rb_streams = num("AMP_RB_STREAMS", -1, 1, -1);
         rb_sum_frames = num("AMP_RB_SUM_FRAMES", 0, 1 << 20, 1 << 20);
         rb_horizontal = num("AMP_RB_HORIZONTAL", 0, 1, 1);
+        rb_horizontal_frames = num("AMP_RB_HORIZONTAL_FRAMES", 0, 1 << 20, 0);
         const char* e = getenv("AMP_GROUP_MB");
         group_bytes = (e && atol(e) > 0) ? (size_t)atol(e) << 20 : 0;
     }
@@ -1595,7 +1597,7 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
         // replay, but 1.08 instead of 0.90-0.95 ms eager, where the host issues the critical stream's launches last.)
         // Horizontal form (pair3_f16x3.hip): where the stage's three resblocks (k = 11 / 7 / 3) run as per-tile fused pairs, pair p of all
         // three shares ONE launch -- nd launches + the MRF mean instead of 3 nd launches on three streams with their fork / join events.
-        if (conc && cfg().rb_horizontal && (long long)B * T <= kRbHorizontalMaxFrames && d.resblock_type == 1 && !big && nk == 3) {
+        if (conc && cfg().rb_horizontal && (long long)B * T <= (cfg().rb_horizontal_frames > 0 ? cfg().rb_horizontal_frames : kRbHorizontalMaxFrames) && d.resblock_type == 1 && !big && nk == 3) {
             int slot_of[3] = {-1, -1, -1};                 // resblock index holding k = 11 / 7 / 3
             bool okh = true;
             for (int j = 0; j < 3; ++j) {
@@ -1637,7 +1639,7 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
         // The same for a stage of UNFUSED whole-K convs (the C = 256 stage of a single utterance): c1 of a dilation, then c2, of all
         // three resblocks in one launch each (conv_small3_f16x3.hip); only the three convs that accumulate into XS stay separate
         // launches, in resblock order with their `=` / `+=` / `(y + v) / n` modes (they add y BEFORE the products: no post-hoc mean).
-        if (conc && cfg().rb_horizontal && (long long)B * T <= kRbHorizontalMaxFrames && d.resblock_type == 1 && !big && nk == 3) {
+        if (conc && cfg().rb_horizontal && (long long)B * T <= (cfg().rb_horizontal_frames > 0 ? cfg().rb_horizontal_frames : kRbHorizontalMaxFrames) && d.resblock_type == 1 && !big && nk == 3) {
             int slot_of[3] = {-1, -1, -1};
             bool okh = true;
             for (int j = 0; j < 3; ++j) {
