@@ -1,6 +1,7 @@
 // Internal declarations shared by the translation units of libamphion_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -262,18 +263,47 @@ void set_error(const char* fmt, ...);
 // while the calling thread points tl_kernel_log at a string (a profiled amp_gen_forward does, per resblock), every launch
 // appends its kernel's name once (" | "-joined) -- bench.py reports the variant the policy actually picked, not a literal.
 extern thread_local std::string* tl_kernel_log;
+// AMP_LAUNCH_MANIFEST=<file> (read once per process): every launch appends one line
+//     <kernel name with its template arguments>\t<workgroups>\t<algorithmic GFLOP>\t<algorithmic MB>\t<what it computes>
+// -- the launcher's OWN statement of the work a launch does, which tools/roofline_table.py joins with rocprofv3's per-dispatch durations
+// by (name, workgroups) instead of guessing shapes from template arguments.  Off: one predictable branch per launch.
+bool manifest_on();
+void manifest_add(const char* name, unsigned long long workgroups, double gflop, double mb, const char* what);
+extern thread_local char tl_last_kernel[160];
 template <typename... A>
 inline void note_kernel(const char* base, A... args) {
-    if (!tl_kernel_log) return;
-    char buf[128];
+    if (!tl_kernel_log && !manifest_on()) return;
+    char* buf = tl_last_kernel;
+    constexpr int cap = (int)sizeof(tl_last_kernel);
     const int v[] = {static_cast<int>(args)...};
-    int n = snprintf(buf, sizeof(buf), "%s<", base);
-    for (size_t i = 0; i < sizeof...(args) && n < (int)sizeof(buf) - 16; ++i)
-        n += snprintf(buf + n, sizeof(buf) - n, i ? ", %d" : "%d", v[i]);
-    snprintf(buf + n, sizeof(buf) - n, ">");
+    int n = snprintf(buf, cap, "%s<", base);
+    for (size_t i = 0; i < sizeof...(args) && n < cap - 16; ++i)
+        n += snprintf(buf + n, cap - n, i ? ", %d" : "%d", v[i]);
+    snprintf(buf + n, cap - n, ">");
+    if (!tl_kernel_log) return;
     if (tl_kernel_log->find(buf) != std::string::npos) return;
     if (!tl_kernel_log->empty()) *tl_kernel_log += " | ";
     *tl_kernel_log += buf;
+}
+// after note_kernel(): the launch's grid and algorithmic work (manifest only)
+inline void note_work(unsigned long long workgroups, double gflop, double mb, const char* fmt, ...) __attribute__((format(printf, 4, 5)));
+inline void note_work(unsigned long long workgroups, double gflop, double mb, const char* fmt, ...) {
+    if (!manifest_on()) return;
+    char what[160];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(what, sizeof(what), fmt, ap);
+    va_end(ap);
+    manifest_add(tl_last_kernel, workgroups, gflop, mb, what);
+}
+// a Conv1d / ConvTranspose1d launch: GEMM M = Cout * up rows, K = Cin * KT, N = B * Tq columns; bytes = x read once + y written once
+// (+ the residual / running sum read)
+inline void note_conv_work(const ConvArgs& a, int KT, dim3 grid) {
+    if (!manifest_on()) return;
+    const double gf = 2.0 * a.M * a.Cin * KT * (double)a.Tq * a.B / 1e9;
+    const double mb = 4.0 * a.B * ((double)a.Cin * a.Tin + (double)a.Cout * a.Tout * (1 + (a.res ? 1 : 0) + (a.mode ? 1 : 0))) / 1e6;
+    note_work((unsigned long long)grid.x * grid.y, gf, mb, "%s %d->%d k=%d d=%d T=%d->%d B=%d%s%s", a.up > 1 ? "ConvT" : "conv", a.Cin, a.Cout,
+              a.up > 1 ? KT * a.up : KT, a.dstep, a.Tin, a.Tout, a.B, a.res ? " +res" : "", a.mode ? " +sum" : "");
 }
 
 // The f16x3 kernels stage fp32 activations as hi + lo f16 pairs after an exact x16: anything beyond |x| = 4094 (or

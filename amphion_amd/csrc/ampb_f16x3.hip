@@ -52,6 +52,9 @@
 #define AMP_AMPB_SCATTER 1     // 0: the register-transpose form of the tile write (same bits; kept for the A/B, profiles/r4_u_*)
 #endif
 #include <type_traits>
+#ifndef AMP_AMPB_KO
+#define AMP_AMPB_KO 0          // timing-only knock-outs (wrong results): 1 no Activation1d, 2 no tile write, 4 no conv K loop, 8 no halo exchange, 16 no load of x, 32 no store of y
+#endif
 
 namespace amp {
 
@@ -286,7 +289,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void ampb_f16x3_kernel(const AmpbA
 
     f32x16 xv[4];                             // x (then x + pair_0(x), ...): the residual, P layout
     f32x16 acc[4];                            // accumulators / the activation's operand and result (P layout)
+#if AMP_AMPB_KO & 16
+    for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) xv[t][r] = 0.001f * (float)(lane + r);
+#else
     load_rows(a.x, qw, Tv, xv);
+#endif
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = xv[t];
 
@@ -308,12 +315,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void ampb_f16x3_kernel(const AmpbA
         const bool last = s + 1 == ns;
         // ---------------- halo exchange: 5 columns either side of every run ----------------
         float hl[5], hr[5];
+#if AMP_AMPB_KO & 8
+        for (int i = 0; i < 5; ++i) { hl[i] = acc[0][i]; hr[i] = acc[3][11 + i]; }
+        if (false)
+#endif
         {
             float* my = xch + ((wave * 2 + h) * 32 + m) * 5;      // side 0: my first five (h = 0), side 1: my last five (h = 1)
 #pragma unroll
             for (int i = 0; i < 5; ++i) my[i] = h ? acc[AMP_PT(59 + i)][AMP_PR(59 + i)] : acc[AMP_PT(i)][AMP_PR(i)];
         }
         __syncthreads();                          // ... and every wave is through the previous conv: the tile may be overwritten
+#if AMP_AMPB_KO & 8
+        if (false)
+#endif
         {
             const int wl = wn > 0 ? wave - 1 : wave, wr = wn + 1 < WN ? wave + 1 : wave;   // (tile edges: finite filler)
             const float* nb = h ? xch + ((wr * 2 + 0) * 32 + m) * 5 : xch + ((wl * 2 + 1) * 32 + m) * 5;
@@ -365,7 +379,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void ampb_f16x3_kernel(const AmpbA
         }
 
         // ---------------- Activation1d, in place ----------------
+#if !(AMP_AMPB_KO & 1)
         act_run(acc, hl, hr, aa, invb, fu2, fd);
+#else
+        acc[0][0] += hl[0] * aa + hr[4] * invb + fu2[3] + fd[2];
+#endif
 
         // the conv's first weight fragments: in flight under the transposes
         {
@@ -379,7 +397,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void ampb_f16x3_kernel(const AmpbA
         AMP_PIN_VMEM();
 
         // ---------------- x16, hi / lo, the conv's zero padding -> the operand tile ----------------
-#if AMP_AMPB_SCATTER
+#if AMP_AMPB_KO & 2
+        range_max = __builtin_fmaxf(range_max, acc[1][3]);
+#elif AMP_AMPB_SCATTER
         // A lane holds ONE channel of 64 columns; the tile wants 8 channels of one column per 16-B unit.  The transposition is left to
         // the LDS: every value goes to its own 2-byte slot (ds_write_b16 / _d16_hi of the packed conversions, 128 per step).  The kernel is
         // VALU-bound with the LDS pipe ~10 % busy, and the register transposes of the first version (below) were 384 of its ~2 500 vector
@@ -488,7 +508,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void ampb_f16x3_kernel(const AmpbA
             // run column 16 t + r of this lane
             const int rd = h * WL + G + 128 * wn + 64 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3) - H2 * d;
 #pragma unroll 1
-            for (int c = 0; c < NCH; ++c) {
+            for (int c = 0; c < ((AMP_AMPB_KO & 4) ? 0 : NCH); ++c) {
                 const uint4* wcur = wa + (size_t)c * (KT * 128);
                 const uint4* wan = (c + 1) < NCH ? wa + (size_t)(c + 1) * (KT * 128) : wa;   // (last chunk: a reload nobody uses)
                 const uint4* base = smem4 + c * CHS + rd;
@@ -549,7 +569,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void ampb_f16x3_kernel(const AmpbA
         for (int i = 0; i < 16; ++i) {
             const int col = colr + 4 * i;
             const int q = q0 + col;
-            if (col >= RH && col < W - RH && q < T)
+            if (col >= RH && col < W - RH && q < T && (!(AMP_AMPB_KO & 32) || xv[0][0] == 1234.5f))
                 *reinterpret_cast<float4*>(row + q) = make_float4(xv[AMP_PT(4 * i)][AMP_PR(4 * i)], xv[AMP_PT(4 * i)][AMP_PR(4 * i) + 1],
                                                                   xv[AMP_PT(4 * i)][AMP_PR(4 * i) + 2], xv[AMP_PT(4 * i)][AMP_PR(4 * i) + 3]);
         }
@@ -572,6 +592,8 @@ static hipError_t launch_ampb_one(const AmpbArgs& a, hipStream_t stream) {
     }
     dim3 grid((unsigned)(a.B * a.tiles_per_item));
     note_kernel("ampb_f16x3_kernel", KT, WM, WN, RING, G);
+    note_work(grid.x, a.ns * 2.0 * a.C * a.C * KT * (double)a.T * a.B / 1e9, 4.0 * a.B * (double)a.C * a.T * (2 + (a.mode ? 1 : 0)) / 1e6,
+              "whole AMPBlock C=%d k=%d T=%d B=%d: %d convs + %d Activation1d%s", a.C, KT, a.T, a.B, a.ns, a.ns, a.mode ? " +sum" : "");
     hipLaunchKernelGGL((ampb_f16x3_kernel<KT, WM, WN, RING, G>), grid, dim3(64 * WM * WN), lds, stream, a);
     return hipGetLastError();
 }

@@ -524,6 +524,7 @@ static hipError_t launch_one_h(const ConvArgs& a, hipStream_t stream) {
     dim3 grid((unsigned)(a.B * a.tiles_per_item), (unsigned)((a.M + 32 * WM - 1) / (32 * WM)));
     if (a.row_groups > 0) grid = dim3((unsigned)(a.B * a.tiles_per_item * a.row_groups), 1u);   // conv_run: row_groups == grid.y
     note_kernel("conv_f16x3_kernel", KT, WM, WN, NI, HALO, 0);
+    note_conv_work(a, KT, grid);
     hipLaunchKernelGGL((conv_f16x3_kernel<KT, WM, WN, NI, HALO>), grid, dim3(256), lds, stream, a);
     return hipGetLastError();
 }
@@ -548,6 +549,7 @@ static hipError_t launch_one_h_act(const ConvArgs& a, hipStream_t stream) {
     }
     dim3 grid((unsigned)(a.B * a.tiles_per_item), (unsigned)((a.M + 32 * WM - 1) / (32 * WM)));
     note_kernel("conv_f16x3_kernel", KT, WM, WN, NI, HALO, 1);
+    note_conv_work(a, KT, grid);
     hipLaunchKernelGGL((conv_f16x3_kernel<KT, WM, WN, NI, HALO, 1>), grid, dim3(256), lds, stream, a);
     return hipGetLastError();
 }

@@ -252,6 +252,7 @@ static hipError_t launch_one(const ConvArgs& a, hipStream_t stream) {
     const size_t lds = (size_t)2 * KC * S * sizeof(float);
     dim3 grid((unsigned)(a.B * a.tiles_per_item), (unsigned)((a.M + 32 * WM - 1) / (32 * WM)));
     note_kernel("conv_mfma_kernel", KT, WM, WN, NI, HALO);
+    note_conv_work(a, KT, grid);
     hipLaunchKernelGGL((conv_mfma_kernel<KT, WM, WN, NI, HALO>), grid, dim3(256), lds, stream, a);
     return hipGetLastError();
 }

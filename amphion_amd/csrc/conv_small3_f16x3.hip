@@ -39,6 +39,7 @@ static hipError_t launch_small3_one(const ConvSmall3Args& p, hipStream_t stream)
     }
     dim3 grid((unsigned)(p.nx[0] * p.ny[0] + p.nx[1] * p.ny[1] + p.nx[2] * p.ny[2]));
     note_kernel("conv_small3_kernel", NI0, HALO0);
+    note_work(grid.x, 0.0, 0.0, "three frame-rate convs side by side (work not itemised)");
     hipLaunchKernelGGL((conv_small3_kernel<NI0, HALO0>), grid, dim3(256), lds, stream, p);
     return hipGetLastError();
 }

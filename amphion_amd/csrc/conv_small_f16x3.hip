@@ -60,6 +60,7 @@ static hipError_t launch_small_one(const ConvArgs& a, hipStream_t stream) {
     }
     dim3 grid((unsigned)(a.B * a.tiles_per_item), (unsigned)((a.M + 127) / 128));
     note_kernel("conv_small_kernel", KT, NI, HALO, EPI);
+    note_conv_work(a, KT, grid);
     hipLaunchKernelGGL((conv_small_kernel<KT, NI, HALO, EPI>), grid, dim3(256), lds, stream, a);
     return hipGetLastError();
 }

@@ -8,6 +8,7 @@
 
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -70,6 +71,27 @@ struct RangeGuard {
 };
 static RangeGuard g_guard[64];                    // op-level launches (amp_conv_forward, amp_pair_forward, ...): one word per device
 thread_local std::string* tl_kernel_log = nullptr;    // amp_internal.h: note_kernel()
+thread_local char tl_last_kernel[160] = "";
+// launch manifest (amp_internal.h): AMP_LAUNCH_MANIFEST=<file>, read once; lines are appended and flushed per launch (profiling runs only)
+static FILE* manifest_file() {
+    static FILE* f = [] {
+        const char* p = getenv("AMP_LAUNCH_MANIFEST");
+        return (p && *p) ? fopen(p, "a") : nullptr;
+    }();
+    return f;
+}
+bool manifest_on() {
+    static const bool on = manifest_file() != nullptr;
+    return on;
+}
+void manifest_add(const char* name, unsigned long long workgroups, double gflop, double mb, const char* what) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    FILE* f = manifest_file();
+    if (!f) return;
+    fprintf(f, "%s\t%llu\t%.6f\t%.6f\t%s\n", name, workgroups, gflop, mb, what);
+    fflush(f);
+}
 static thread_local unsigned* tl_range_flag = nullptr;   // set while an amp_gen forward is launching: that handle's own word
 
 static bool guard_init(RangeGuard& g) {

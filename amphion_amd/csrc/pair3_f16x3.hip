@@ -35,6 +35,7 @@ static hipError_t launch_pair3_one(const Pair3Args& p, hipStream_t stream) {
     }
     dim3 grid((unsigned)(p.n[0] + p.n[1] + p.n[2]));
     note_kernel("pair3_kernel", 11, 7, 3, WM, WN);
+    note_work(grid.x, 0.0, 0.0, "three fused pairs side by side (work not itemised)");
     hipLaunchKernelGGL((pair3_kernel<11, 7, 3, WM, WN, NI, SX>), grid, dim3(256), lds, stream, p);
     return hipGetLastError();
 }

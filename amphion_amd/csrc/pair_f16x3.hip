@@ -48,6 +48,8 @@ static hipError_t launch_pair_one(const PairArgs& a, hipStream_t stream) {
     }
     dim3 grid((unsigned)(a.B * a.tiles_per_item));
     note_kernel("pair_f16x3_kernel", KT, WM, WN, NI, SX);
+    note_work(grid.x, 2 * 2.0 * a.C * a.C * KT * (double)a.T * a.B / 1e9, 2 * 4.0 * a.B * (double)a.C * a.T * (1.0 + (a.mode ? 0.5 : 0.0)) / 1e6,
+              "fused pair C=%d k=%d d=%d T=%d B=%d%s", a.C, KT, a.dil, a.T, a.B, a.mode ? " +sum" : "");
     hipLaunchKernelGGL((pair_f16x3_kernel<KT, WM, WN, NI, SX>), grid, dim3(256), lds, stream, a);
     return hipGetLastError();
 }

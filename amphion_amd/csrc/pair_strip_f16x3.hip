@@ -428,6 +428,8 @@ static hipError_t launch_strip_one(const PairArgs& a, hipStream_t stream) {
     }
     dim3 grid((unsigned)(a.B * a.strips_per_item));
     note_kernel("pair_strip_kernel", KT, WM, WN, NI, SX, MI, RING, SBUF);
+    note_work(grid.x, 2 * 2.0 * a.C * a.C * KT * (double)a.T * a.B / 1e9, 2 * 4.0 * a.B * (double)a.C * a.T * (1.0 + (a.mode ? 0.5 : 0.0)) / 1e6,
+              "fused pair C=%d k=%d d=%d T=%d B=%d%s", a.C, KT, a.dil, a.T, a.B, a.mode ? " +sum" : "");
     hipLaunchKernelGGL((pair_strip_kernel<KT, WM, WN, NI, SX, MI, RING, SBUF>), grid, dim3(64 * WM * WN), lds, stream, a);
     return hipGetLastError();
 }

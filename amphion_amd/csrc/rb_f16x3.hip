@@ -301,6 +301,8 @@ static hipError_t launch_rb_one(const RbArgs& a, hipStream_t stream) {
     }
     dim3 grid((unsigned)(a.B * a.tiles_per_item));
     note_kernel("rb_f16x3_kernel", KT, WM, WN, NI, RING, RB_G);
+    note_work(grid.x, a.np * 2 * 2.0 * a.C * a.C * KT * (double)a.T * a.B / 1e9, 4.0 * a.B * (double)a.C * a.T * (2 + (a.mode ? 1 : 0)) / 1e6,
+              "whole ResBlock C=%d k=%d T=%d B=%d: %d convs%s", a.C, KT, a.T, a.B, 2 * a.np, a.mode ? " +sum" : "");
     hipLaunchKernelGGL((rb_f16x3_kernel<KT, WM, WN, NI, RING, RB_G>), grid, dim3(64 * WM * WN), lds, stream, a);
     return hipGetLastError();
 }

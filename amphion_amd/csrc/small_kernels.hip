@@ -147,6 +147,9 @@ hipError_t launch_conv_post(const float* x, const float* w_dev, const float* bia
     const bool aligned = (T & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
     if (aligned && (K == 7 || K == 3 || K == 5)) {
         dim3 grid((unsigned)((T + CP_TT - 1) / CP_TT), (unsigned)B);
+        note_kernel("conv_post_stream_kernel", K);
+        note_work((unsigned long long)grid.x * grid.y, 2.0 * Cin * K * (double)T * B / 1e9, 4.0 * B * (double)T * (Cin + 1) / 1e6,
+                  "conv_post %d->1 k=%d T=%d B=%d%s", Cin, K, T, B, apply_tanh ? " + tanh" : "");
         if (K == 7) hipLaunchKernelGGL(conv_post_stream_kernel<7>, grid, dim3(256), 0, stream, x, w_dev, bias_dev, y, Cin, T, slope_in, apply_tanh, lens, len_mul);
         else if (K == 5) hipLaunchKernelGGL(conv_post_stream_kernel<5>, grid, dim3(256), 0, stream, x, w_dev, bias_dev, y, Cin, T, slope_in, apply_tanh, lens, len_mul);
         else hipLaunchKernelGGL(conv_post_stream_kernel<3>, grid, dim3(256), 0, stream, x, w_dev, bias_dev, y, Cin, T, slope_in, apply_tanh, lens, len_mul);
@@ -412,6 +415,7 @@ static hipError_t launch_act1d_n(const float* x, float* y, int B, int C, int T, 
     const int ngroups = (ntiles + NTILE - 1) / NTILE;
     dim3 grid((unsigned)((size_t)ngroups * (size_t)(B * C)));
     note_kernel("act1d_kernel", NTILE);
+    note_work(grid.x, 0.0, 2 * 4.0 * B * (double)C * T / 1e6, "Activation1d C=%d T=%d B=%d", C, T, B);
     hipLaunchKernelGGL(act1d_kernel<NTILE>, grid, dim3(256), 0, stream, x, y, C, T, a_dev, invb_dev, fu, fd, lens,
                        len_mul, rev);
     return hipGetLastError();

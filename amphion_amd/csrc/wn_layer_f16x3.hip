@@ -278,6 +278,8 @@ static hipError_t launch_wn_one(const WnLayerArgs& p, hipStream_t stream) {
         attr_set |= 1ull << dev;
     }
     note_kernel("wn_layer_kernel", KT, NW);
+    note_work((unsigned long long)p.g.B * p.g.tiles_per_item, (2.0 * p.g.M * p.g.Cin * KT + 2.0 * p.r.M * p.r.Cin) * (double)p.g.Tq * p.g.B / 1e9,
+              4.0 * p.g.B * (double)p.g.Tin * (3.0 * p.g.Cin) / 1e6, "WN layer H=%d k=%d T=%d B=%d", p.g.Cin, KT, p.g.Tin, p.g.B);
     hipLaunchKernelGGL((wn_layer_kernel<KT, NW>), dim3((unsigned)(p.g.B * p.g.tiles_per_item)), dim3(64 * NW), lds, stream, p);
     return hipGetLastError();
 }

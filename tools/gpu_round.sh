@@ -3,7 +3,7 @@
 #   usage (repo root on the GPU box):  bash tools/gpu_round.sh <tag> [step ...]        default steps: tests bench prof pmc smoke
 #   steps   tests     pytest -m gpu -x -q (what the driver runs at round end); PYTEST_N=<n> adds xdist workers
 #           bench     the full bench.py line (CPU / library baselines, other configs)            -> bench.json
-#           prof      rocprofv3 --kernel-trace --stats over bench.py --no-cpu-baseline           -> prof/kt_kernel_stats.csv
+#           prof      rocprofv3 --kernel-trace --stats over bench.py --no-cpu-baseline           -> prof/kt_kernel_stats.csv, manifest.tsv, roofline_table.txt
 #           pmc       FETCH_SIZE and WRITE_SIZE passes (separate runs, kernel-trace only)         -> pmc_fetch/, pmc_write/
 #           sq        four SQ counter passes over ONE config-2 forward (or $SQCMD)                -> sq_table.csv, sq_summary.txt
 #           configs   tools/bench_configs.py (C3, C5, mel, list API, latency)                     -> other_configs.jsonl
@@ -18,6 +18,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$PWD
 python -c "import torch; print(torch.cuda.get_device_name(0))" > $OUT/device.txt 2>&1
+[ -f .commit_stamp ] && cp .commit_stamp $OUT/commit.txt      # tools/gpu.sh: the commit this snapshot was cut from
 PROF="rocprofv3 --output-format csv --kernel-trace"
 # PROFCMD=<command>: what the prof / pmc steps profile (default: the config-2 bench line; e.g. "python $PWD/tools/bench_configs.py --only c3")
 PROFCMD=${PROFCMD:-"python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline"}
@@ -31,7 +32,9 @@ for STEP in $STEPS; do
     bench)
       ( timeout 600 python bench.py --steps 10 --warmup 3 2> $OUT/bench.err | tail -1 ) > $OUT/bench.json; cut -c1-1500 $OUT/bench.json ;;
     prof)
-      ( cd /tmp && timeout 600 $PROF --stats -d $REPO/$OUT/prof -o kt -- $PROFCMD > $REPO/$OUT/prof_bench.json 2> $REPO/$OUT/prof.err ) ;;
+      rm -f $REPO/$OUT/manifest.tsv     # the library's launch manifest of the same run (amp_internal.h), joined by tools/roofline_table.py
+      ( cd /tmp && AMP_LAUNCH_MANIFEST=$REPO/$OUT/manifest.tsv timeout 600 $PROF --stats -d $REPO/$OUT/prof -o kt -- $PROFCMD > $REPO/$OUT/prof_bench.json 2> $REPO/$OUT/prof.err )
+      python tools/roofline_table.py $OUT --title "$PROFCMD" > $OUT/roofline_table.txt 2> $OUT/roofline_table.err ;;
     pmc)
       ( cd /tmp && timeout 600 $PROF --pmc FETCH_SIZE -d $REPO/$OUT/pmc_fetch -o pf -- $PMCCMD > /dev/null 2> $REPO/$OUT/pmc_fetch.err )
       ( cd /tmp && timeout 600 $PROF --pmc WRITE_SIZE -d $REPO/$OUT/pmc_write -o pw -- $PMCCMD > /dev/null 2> $REPO/$OUT/pmc_write.err ) ;;

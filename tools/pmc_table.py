@@ -50,6 +50,11 @@ def summary(path):
     def mean(rs, c):
         v = [float(r[c]) for r in rs if r.get(c) not in (None, "")]
         return sum(v) / len(v) if v else 0.0
+    import os
+    for c in (os.path.join(os.path.dirname(path), "commit.txt"), ".commit_stamp"):
+        if os.path.exists(c):
+            print("# tree " + " ".join(open(c).read().split()))
+            break
     print(f"{'kernel':44s} {'grid':>9s} {'n':>3s} {'us':>8s} {'vgpr':>5s} {'scr':>5s} {'MFMA%':>6s} | {'wait%':>6s} {'stall%':>6s} {'issue%':>6s} |"
           f" {'mfma/wv':>8s} {'valu/wv':>8s} {'lds/wv':>7s} {'vmrd/wv':>7s} {'vmwr/wv':>7s} | {'v:m':>5s} {'ldsCf%':>6s}")
     order = sorted(agg.items(), key=lambda kv: -mean(kv[1], "us") * len(kv[1]))

@@ -41,11 +41,20 @@ def main():
         p = os.path.join(src, a)
         if os.path.exists(p):
             shutil.copy(p, dst + b)
+    stamp = ""
+    for c in (os.path.join(src, "commit.txt"), ".commit_stamp"):
+        if os.path.exists(c):
+            stamp = " ".join(open(c).read().split())
+            break
+    if stamp:   # every summary of this visit carries the commit its snapshot was cut from (tools/gpu.sh)
+        open(dst + "_tree.txt", "w").write(f"profiles {os.path.basename(dst)}_*: measured on a snapshot of tree {stamp}\n")
     fe = os.path.join(src, "pmc_fetch", "pf_counter_collection.csv")
     wr = os.path.join(src, "pmc_write", "pw_counter_collection.csv")
     if os.path.exists(fe) and os.path.exists(wr):
         F, W = per_kernel(fe, "FETCH_SIZE"), per_kernel(wr, "WRITE_SIZE")
         with open(dst + "_hbm_traffic.csv", "w") as out:
+            if stamp:
+                out.write(f"# tree {stamp}\n")
             out.write("kernel,launches,mean_us_under_pmc,fetch_MB_raw,fetch_MB_x2_gfx950,write_MB_raw,total_MB_corrected\n")
             tot = 0.0
             for k in sorted(F, key=lambda k: -F[k][1]):
