@@ -391,8 +391,7 @@ static hipError_t launch_blk_one(const ConvArgs& a, hipStream_t stream) {
     }
     dim3 grid((unsigned)(a.B * a.tiles_per_item), (unsigned)(a.M / (256 / WN)));
     if (a.row_groups > 0) grid = dim3((unsigned)(a.B * a.tiles_per_item * a.row_groups), 1u);
-    if (WN == 1) note_kernel("conv_blk_kernel", KT, NI, HALO, CM, RING);
-    else note_kernel("conv_blk_kernel", KT, NI, HALO, CM, RING, WN);
+    note_kernel("conv_blk_kernel", KT, NI, HALO, CM, RING, WN);
     note_conv_work(a, KT, grid);
     hipLaunchKernelGGL((conv_blk_kernel<KT, NI, HALO, CM, RING, WN>), grid, dim3(256), lds, stream, a);
     return hipGetLastError();

@@ -1,4 +1,5 @@
-// Activation1d with both 12-tap FIRs on the matrix pipe (round 5) -- the in-register form used by ampb_f16x3.hip.
+// NEGATIVE RESULT (round 5, profiles/r5_b_fir_mfma.txt): correct, 45 % slower than the fp32 VALU chains it was to replace.  Not built into the library.
+// Activation1d with both 12-tap FIRs on the matrix pipe -- an in-register form for ampb_f16x3.hip.
 //
 // Activation1d = 2x up-sampling FIR -> Snake -> 2x down-sampling FIR (modules/anti_aliasing/act.py:31-36, resample.py:36-65,
 // filter.py:92-99) and its filters are the SAME for every channel.  In the kernel's P layout a lane owns 64 consecutive columns of

@@ -1,8 +1,8 @@
-// Probe for amphion_amd/csrc/act1d_mfma.h (round 5): Activation1d with both FIRs as split-f16 Toeplitz products on the matrix pipe.
+// Probe for profiles/negative_kernels/act1d_mfma.h (round 5; result: profiles/r5_b_fir_mfma.txt): Activation1d with both FIRs as split-f16 Toeplitz products on the matrix pipe.
 //   1. f16 MFMA operands below 2^-14 (subnormal halves of a split) are NOT flushed
 //   2. act_run_mfma on P-layout runs == fp64 Activation1d of the same signal (interior columns; halos given)
 //   3. time per run and wave at two waves per SIMD, against the fp32 VALU chains of round 4's act_run
-// hipcc --offload-arch=gfx950 -O3 -std=c++17 -I amphion_amd/csrc -I include tests/experiments/fir_mfma_probe.hip -o tests/experiments/fir_mfma_probe
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -I profiles/negative_kernels -I amphion_amd/csrc -I include tests/experiments/fir_mfma_probe.hip -o tests/experiments/fir_mfma_probe
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>

@@ -43,16 +43,20 @@ def main():
         for ax in "XYZ":
             wg *= max(1, int(r["Grid_Size_" + ax]) // max(1, int(r["Workgroup_Size_" + ax])))
         disp.append((short(r["Kernel_Name"]), wg, int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
-    # overlap marks: sweep in start order
+    # overlap marks: a dispatch that shares more than 5 % of its duration with other dispatches (concurrent streams)
     order = sorted(range(len(disp)), key=lambda i: disp[i][2])
-    ovl = [False] * len(disp)
-    latest_end, latest_i = -1, -1
+    shared = [0] * len(disp)
+    active = []                                   # indices still running, by end time
     for i in order:
-        if disp[i][2] < latest_end:
-            ovl[i] = True
-            ovl[latest_i] = True
-        if disp[i][3] > latest_end:
-            latest_end, latest_i = disp[i][3], i
+        s0, e0 = disp[i][2], disp[i][3]
+        active = [j for j in active if disp[j][3] > s0]
+        for j in active:
+            o = min(e0, disp[j][3]) - s0
+            if o > 0:
+                shared[i] += o
+                shared[j] += o
+        active.append(i)
+    ovl = [shared[i] > 0.05 * max(1, disp[i][3] - disp[i][2]) for i in range(len(disp))]
     agg = collections.OrderedDict()
     for i, (n, wg, s, e) in enumerate(disp):
         a = agg.setdefault((n, wg), [0, 0.0, 0])
@@ -103,8 +107,10 @@ def main():
             gf = sum(k[0] * c for k, c in works.items()) / tw
             mb = sum(k[1] * c for k, c in works.items()) / tw
             what = max(works.items(), key=lambda kv: kv[1])[0][2]
-            if len(works) > 1:
-                what += "  [mean of %d different works on this key]" % len(works)
+            if len({k[0] for k in works}) > 1:
+                what += "  [mean of %d different works on this key]" % len({k[0] for k in works})
+            elif len(works) > 1:
+                what += "  [+ %d variants of it: dilation / residual / running sum]" % (len(works) - 1)
         tr = traffic.get((n, wg))
         pmc = (tr["FETCH_SIZE"][1] / max(1, tr["FETCH_SIZE"][0]) + tr["WRITE_SIZE"][1] / max(1, tr["WRITE_SIZE"][0])) if tr else None
 
