@@ -24,9 +24,9 @@
 // in place, with a sliding window of Snake pairs; only the 5 columns either side of a run come from elsewhere -- the other half
 // wave (5 more swaps) or the neighbouring wave (a 1.25-KB LDS exchange per wave).  No LDS traffic, no bank conflicts, no
 // redundant Snake evaluations beyond the 5 + 3 per 64 of the run's ends.  The activation's output then has to become the next
-// conv's operand tile [16-channel chunk][plane hi|lo][octet][column][8 x f16] (rb_f16x3.hip's layout): the eight lanes of a channel
-// octet transpose 8 x 8 blocks among themselves with three DPP butterfly stages (quad_perm / row_shl:4 / row_shr:4), after which a
-// lane holds the 8 channels of ONE column = one 16-B ds_write_b128 per plane, conflict-free.
+// conv's operand tile [16-channel chunk][plane hi|lo][octet][column][8 x f16] (rb_f16x3.hip's layout): the LDS does that transposition,
+// every value is written to its own 2-byte slot (see the step loop; the first version's DPP lane transposes are in
+// profiles/negative_kernels/ampb_transpose_write.hip.txt).
 //
 //   step s (6 per block):  [x or xt in registers, P layout] -> halo exchange -> Activation1d a_s -> x16, hi / lo -> LDS tile
 //                          -> conv s (K loop over the tile, all waves) -> un-scale (+ residual: odd steps) -> P layout
@@ -48,13 +48,7 @@
 #ifndef AMP_KT
 #error "compile with -DAMP_KT=<taps>"
 #endif
-#ifndef AMP_AMPB_SCATTER
-#define AMP_AMPB_SCATTER 1     // 0: the register-transpose form of the tile write (same bits; kept for the A/B, profiles/r4_u_*)
-#endif
 #include <type_traits>
-#ifndef AMP_AMPB_KO
-#define AMP_AMPB_KO 0          // timing-only knock-outs (wrong results): 1 no Activation1d, 2 no tile write, 4 no conv K loop, 8 no halo exchange, 16 no load of x, 32 no store of y
-#endif
 
 namespace amp {
 
@@ -81,41 +75,6 @@ __device__ __forceinline__ void lane_half_swap(float a, float b, float& na, floa
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     na = a;
     nb = b;
-}
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-
-// 8 x 8 transpose among the 8 lanes of an octet (lane e = lane & 7 holds R[j] = M[e][j]; afterwards M[j][e]): three butterfly
-// stages, partner e ^ 4 (row_shr:4 for the upper four lanes, row_shl:4 for the lower), e ^ 2 and e ^ 1 (quad_perm)
-__device__ __forceinline__ void transpose8(float (&R)[8], bool b4, bool b2, bool b1) {
-    // (the DPP moves are evaluated by EVERY lane, then selected: inside a conditional they would run under a partial EXEC mask and
-    //  read disabled lanes)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float lo = R[j], hi = R[j + 4];
-        const float from_below = dpp_mov<0x114>(hi), from_above = dpp_mov<0x104>(lo);
-        R[j] = b4 ? from_below : lo;
-        R[j + 4] = b4 ? hi : from_above;
-    }
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        const int j = (jj & 1) + 4 * (jj >> 1);
-        const float lo = R[j], hi = R[j + 2];
-        const float phi = dpp_mov<0x4E>(hi), plo = dpp_mov<0x4E>(lo);
-        R[j] = b2 ? phi : lo;
-        R[j + 2] = b2 ? hi : plo;
-    }
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        const int j = 2 * jj;
-        const float lo = R[j], hi = R[j + 1];
-        const float phi = dpp_mov<0xB1>(hi), plo = dpp_mov<0xB1>(lo);
-        R[j] = b1 ? phi : lo;
-        R[j + 1] = b1 ? hi : plo;
-    }
 }
 
 template <typename T>
@@ -289,11 +248,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void ampb_f16x3_kernel(const AmpbA
 
     f32x16 xv[4];                             // x (then x + pair_0(x), ...): the residual, P layout
     f32x16 acc[4];                            // accumulators / the activation's operand and result (P layout)
-#if AMP_AMPB_KO & 16
-    for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) xv[t][r] = 0.001f * (float)(lane + r);
-#else
     load_rows(a.x, qw, Tv, xv);
-#endif
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = xv[t];
 
@@ -315,19 +270,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void ampb_f16x3_kernel(const AmpbA
         const bool last = s + 1 == ns;
         // ---------------- halo exchange: 5 columns either side of every run ----------------
         float hl[5], hr[5];
-#if AMP_AMPB_KO & 8
-        for (int i = 0; i < 5; ++i) { hl[i] = acc[0][i]; hr[i] = acc[3][11 + i]; }
-        if (false)
-#endif
         {
             float* my = xch + ((wave * 2 + h) * 32 + m) * 5;      // side 0: my first five (h = 0), side 1: my last five (h = 1)
 #pragma unroll
             for (int i = 0; i < 5; ++i) my[i] = h ? acc[AMP_PT(59 + i)][AMP_PR(59 + i)] : acc[AMP_PT(i)][AMP_PR(i)];
         }
         __syncthreads();                          // ... and every wave is through the previous conv: the tile may be overwritten
-#if AMP_AMPB_KO & 8
-        if (false)
-#endif
         {
             const int wl = wn > 0 ? wave - 1 : wave, wr = wn + 1 < WN ? wave + 1 : wave;   // (tile edges: finite filler)
             const float* nb = h ? xch + ((wr * 2 + 0) * 32 + m) * 5 : xch + ((wl * 2 + 1) * 32 + m) * 5;
@@ -379,11 +327,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void ampb_f16x3_kernel(const AmpbA
         }
 
         // ---------------- Activation1d, in place ----------------
-#if !(AMP_AMPB_KO & 1)
         act_run(acc, hl, hr, aa, invb, fu2, fd);
-#else
-        acc[0][0] += hl[0] * aa + hr[4] * invb + fu2[3] + fd[2];
-#endif
 
         // the conv's first weight fragments: in flight under the transposes
         {
@@ -397,12 +341,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void ampb_f16x3_kernel(const AmpbA
         AMP_PIN_VMEM();
 
         // ---------------- x16, hi / lo, the conv's zero padding -> the operand tile ----------------
-#if AMP_AMPB_KO & 2
-        range_max = __builtin_fmaxf(range_max, acc[1][3]);
-#elif AMP_AMPB_SCATTER
         // A lane holds ONE channel of 64 columns; the tile wants 8 channels of one column per 16-B unit.  The transposition is left to
         // the LDS: every value goes to its own 2-byte slot (ds_write_b16 / _d16_hi of the packed conversions, 128 per step).  The kernel is
-        // VALU-bound with the LDS pipe ~10 % busy, and the register transposes of the first version (below) were 384 of its ~2 500 vector
+        // VALU-bound with the LDS pipe ~10 % busy, and the register transposes of the first version (profiles/negative_kernels/ampb_transpose_write.hip.txt) were 384 of its ~2 500 vector
         // instructions per step.  Rows of WL * 16 B with WL = 1 (mod 8): the four octets of a half-wave (two per chunk, chunks 4 WL apart) land on disjoint banks.
         {
             _Float16* const dst = reinterpret_cast<_Float16*>(smem4 + (2 * wm + (o4 >> 1)) * CHS + (o4 & 1) * WL + G + 128 * wn + 64 * h) + e8;
@@ -428,34 +369,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void ampb_f16x3_kernel(const AmpbA
             if (edge) scatter(std::true_type{});      // (workgroup-uniform: the selects only where an utterance ends)
             else scatter(std::false_type{});
         }
-#else
-        // the first version: lane = channel -> lane = column by 8 x 8 DPP transposes, one ds_write_b128 per column and plane
-        {
-            const int qws = opaque(qw);           // (not hoisted: eight loop-invariant k16 pairs cost 16 registers for the whole kernel)
-            const int colb = G + 128 * wn + 64 * h + e8;
-            uint4* dst = smem4 + (2 * wm + (o4 >> 1)) * CHS + (o4 & 1) * WL + colb;
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                float R[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) R[j] = acc[AMP_PT(8 * b + j)][AMP_PR(8 * b + j)];
-                transpose8(R, b4, b2, b1);        // R[j]: channel 8 * o4 + j of the octet at run column 8 * b + e8
-                const int q = qws + 8 * b + e8;
-                const float k16 = (!edge || (q >= 0 && q < Tv)) ? 16.f : 0.f;
-                const amp_f32x2 v01 = (amp_f32x2){R[0], R[1]} * k16, v23 = (amp_f32x2){R[2], R[3]} * k16;
-                const amp_f32x2 v45 = (amp_f32x2){R[4], R[5]} * k16, v67 = (amp_f32x2){R[6], R[7]} * k16;
-                range_max = __builtin_fmaxf(range_max, __builtin_fmaxf(__builtin_fabsf(v01.x), __builtin_fabsf(v01.y)));
-                range_max = __builtin_fmaxf(range_max, __builtin_fmaxf(__builtin_fabsf(v23.x), __builtin_fabsf(v23.y)));
-                range_max = __builtin_fmaxf(range_max, __builtin_fmaxf(__builtin_fabsf(v45.x), __builtin_fabsf(v45.y)));
-                range_max = __builtin_fmaxf(range_max, __builtin_fmaxf(__builtin_fabsf(v67.x), __builtin_fabsf(v67.y)));
-                uint2 ha, la, hb, lb;
-                split4_f16(v01, v23, ha, la);
-                split4_f16(v45, v67, hb, lb);
-                dst[8 * b] = make_uint4(ha.x, ha.y, hb.x, hb.y);
-                dst[8 * b + 2 * WL] = make_uint4(la.x, la.y, lb.x, lb.y);
-            }
-        }
-#endif
         if (edge) {
             __syncthreads();                      // the patched columns belong to other lanes' writes
             if (wn == 0 && (h ? has_hi : has_lo)) {
@@ -508,7 +421,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void ampb_f16x3_kernel(const AmpbA
             // run column 16 t + r of this lane
             const int rd = h * WL + G + 128 * wn + 64 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3) - H2 * d;
 #pragma unroll 1
-            for (int c = 0; c < ((AMP_AMPB_KO & 4) ? 0 : NCH); ++c) {
+            for (int c = 0; c < NCH; ++c) {
                 const uint4* wcur = wa + (size_t)c * (KT * 128);
                 const uint4* wan = (c + 1) < NCH ? wa + (size_t)(c + 1) * (KT * 128) : wa;   // (last chunk: a reload nobody uses)
                 const uint4* base = smem4 + c * CHS + rd;
@@ -569,7 +482,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void ampb_f16x3_kernel(const AmpbA
         for (int i = 0; i < 16; ++i) {
             const int col = colr + 4 * i;
             const int q = q0 + col;
-            if (col >= RH && col < W - RH && q < T && (!(AMP_AMPB_KO & 32) || xv[0][0] == 1234.5f))
+            if (col >= RH && col < W - RH && q < T)
                 *reinterpret_cast<float4*>(row + q) = make_float4(xv[AMP_PT(4 * i)][AMP_PR(4 * i)], xv[AMP_PT(4 * i)][AMP_PR(4 * i) + 1],
                                                                   xv[AMP_PT(4 * i)][AMP_PR(4 * i) + 2], xv[AMP_PT(4 * i)][AMP_PR(4 * i) + 3]);
         }
