@@ -1103,6 +1103,11 @@ struct amp_gen {
     // concurrent resblocks (small launches): n_kernels - 1 side streams, per stage one fork event and n_kernels - 1 join events
     std::vector<hipStream_t> side;
     std::vector<hipEvent_t> ev_side;
+    // One launch sequence of this handle at a time: the side streams, their fork / join events, the profiling ring and the
+    // range-guard word are per HANDLE, so two host threads (or two caller streams) enqueueing forwards of the same generator take turns
+    // on the HOST -- each sequence's event records and waits are then issued as a unit (a wait binds to the record that precedes it in
+    // issue order) and the device-side order per side stream is the issue order.  The forwards still overlap on the device.
+    std::mutex launch_mu;
     ~amp_gen() {
         guard_free(guard);
         for (auto s_ : side) (void)hipStreamDestroy(s_);
@@ -1914,6 +1919,7 @@ int amp_gen_forward_ragged(amp_gen* g, const float* mel_dev, const float* cond_d
     if (workspace_bytes < amp_gen_workspace_bytes(g, B, T)) { set_error("amp_gen_forward: workspace too small (%zu < %zu)", workspace_bytes, amp_gen_workspace_bytes(g, B, T)); return AMP_ERR_INVALID; }
     if (cond_dev && !g->cond) { set_error("amp_gen_forward: cond given but gin_channels == 0"); return AMP_ERR_INVALID; }
     hipStream_t st = (hipStream_t)stream_;
+    std::lock_guard<std::mutex> launch_lock(g->launch_mu);
     AMP_RC(range_poll(&g->guard, st)); // a previous forward of this handle left the f16 operand range: say so now
     struct FlagScope { FlagScope(unsigned* p) { tl_range_flag = p; } ~FlagScope() { tl_range_flag = nullptr; } } flag_scope(g->guard.dev);
     const amp_gen_desc& d = g->d;

@@ -924,6 +924,24 @@ static bool rel_attention_tiled() { return g_rel_attention_tiled.load() != 0; }
         if (e__ != hipSuccess) { set_error(name ": %s", hipGetErrorString(e__)); return AMP_ERR_HIP; } \
     } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to ONE device's copy of a kernel: set it once per (kernel, device), not once per process
+// (a process that ran the text side on cuda:0 and then on cuda:1 launched on the second device without it -> AMP_ERR_HIP).
+// Returns hipSuccess when the attribute is in place on the current device.
+template <auto Kernel>
+static hipError_t ensure_dynamic_lds(int bytes) {
+    static std::atomic<unsigned long long> done{0};       // one bit per device; the kernel is a template ARGUMENT: one mask per kernel
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if ((done.load(std::memory_order_acquire) >> dev) & 1ull) return hipSuccess;
+    std::lock_guard<std::mutex> lock(mu);
+    if ((done.load(std::memory_order_acquire) >> dev) & 1ull) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+    done.fetch_or(1ull << dev, std::memory_order_release);
+    return hipSuccess;
+}
+
 extern "C" {
 
 static int layer_norm_run(const char* who, const float* x_dev, const float* res_dev, const float* gamma_dev, const float* beta_dev,
@@ -999,12 +1017,11 @@ static int rel_attention_run(const char* who, const float* q_dev, const float* k
     const bool one = T <= RA_KT && lds_fixed + 2 * lds_kv <= 150 * 1024;          // keys and values staged together
     const size_t lds_tile = lds_fixed + (one ? 2 : 1) * lds_kv;
     if (rel_attention_tiled() && dk % 4 == 0 && dk <= 128 && 2 * window + 1 <= 16 && lds_tile <= 150 * 1024) {
-        static std::once_flag once;
-        std::call_once(once, [] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rel_attention_tile_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rel_attention_tile_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        });
         auto kern = one ? rel_attention_tile_kernel<true> : rel_attention_tile_kernel<false>;
+        {
+            const hipError_t e = one ? ensure_dynamic_lds<&rel_attention_tile_kernel<true>>(150 * 1024) : ensure_dynamic_lds<&rel_attention_tile_kernel<false>>(150 * 1024);
+            if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e)); return AMP_ERR_HIP; }
+        }
         hipLaunchKernelGGL(kern, dim3((T + RA_QB - 1) / RA_QB, H, B), dim3(256), lds_tile, (hipStream_t)stream, q_dev,
                            k_dev, v_dev, emb_k_dev, emb_v_dev, lens_dev, out_dev, bs, H, dk, T, window, Tp);
     } else {
@@ -1072,10 +1089,10 @@ int amp_spline_flow_proj(const float* z_dev, const float* hc_dev, const float* p
     }
     const int R = 3 * num_bins - 1;
     const size_t lds = (size_t)(C * (SPP_TT + 1) + R * (C + 1) + R * (SPP_TT + 1)) * sizeof(float);
-    static std::once_flag once;
-    std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spline_flow_proj_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    });
+    {
+        const hipError_t e = ensure_dynamic_lds<&spline_flow_proj_kernel>(100 * 1024);
+        if (e != hipSuccess) { set_error("amp_spline_flow_proj: hipFuncSetAttribute: %s", hipGetErrorString(e)); return AMP_ERR_HIP; }
+    }
     hipLaunchKernelGGL(spline_flow_proj_kernel, dim3((T + SPP_TT - 1) / SPP_TT, B), dim3(256), lds, (hipStream_t)stream, z_dev, hc_dev,
                        proj_w_dev, proj_b_dev, lens_dev, z_out_dev, C, T, num_bins, 1.0f / sqrtf((float)filter_channels), tail_bound, inverse,
                        flip_in, flip_out);

@@ -52,8 +52,8 @@ def _crops_to_host(model, out, lengths):
 
 def _ragged(model, batch, lens):
     """forward_ragged, through the generator's cached hipGraph when the batch is small enough for one to pay (same bits)"""
-    if hasattr(model, "forward_graphed"):
-        return model.forward_graphed(batch, lens, clone=False)     # copied to the host by the caller before the next forward
+    if hasattr(model, "_forward_graphed_view"):
+        return model._forward_graphed_view(batch, lens)     # copied to the host by the caller before the next forward
     return model.forward_ragged(batch, lens)
 
 
@@ -67,8 +67,8 @@ def vocoder_inference(cfg, model, mels, f0s=None, device=None, fast_inference=Fa
 
         def run():
             if f0s is None and not cfg.preprocess.extract_amplitude_phase:
-                if hasattr(model, "forward_graphed"):      # small batches of a repeated shape: a cached hipGraph (same bits)
-                    return model.forward_graphed(mels, clone=False)     # .cpu() below, before any other forward
+                if hasattr(model, "_forward_graphed_view"):      # small batches of a repeated shape: a cached hipGraph (same bits)
+                    return model._forward_graphed_view(mels)     # .cpu() below, before any other forward
                 return model.forward(mels)
             if cfg.preprocess.extract_amplitude_phase:
                 return model.forward(mels)[4]

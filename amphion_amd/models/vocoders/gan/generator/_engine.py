@@ -461,17 +461,24 @@ class HipGenerator(nn.Module):
     GRAPH_MAX_FRAMES = 1024         # larger batches run eagerly: the gain shrinks with the batch
     GRAPH_MAX_ENTRIES = 48          # graphs share ONE scratch (sized for GRAPH_MAX_FRAMES); each owns only its input / output tensors (~1.3 MB)
 
-    def forward_graphed(self, x, lengths=None, clone=True):
+    def forward_graphed(self, x, lengths=None):
+        """``forward`` / ``forward_ragged`` of a small batch through a cached hipGraph; returns a tensor of its own (see
+        ``_forward_graphed_view`` for what happens underneath)."""
+        return self._forward_graphed_view(x, lengths, clone=True)
+
+    def _forward_graphed_view(self, x, lengths=None, clone=False):
         """``forward`` / ``forward_ragged`` of a small batch through a cached hipGraph: the (B, T) shape is rounded up to a bucket of
         ``GRAPH_BUCKET_FRAMES`` frames, the bucket's graph -- captured the SECOND time the bucket is seen -- runs the ragged forward
         with the valid lengths in a device buffer, and ``out[b, 0, : lengths[b] * hop]`` (``lengths`` defaults to T for every item) is
         bit-identical to the eager forward of that utterance alone (the ragged contract: every layer pads at the utterance's own end;
         tests/test_gpu_inference_api.py).  What it buys: one ``hipGraphLaunch`` instead of ~85 launch / event calls, and the
         concurrent-resblock launch order without host gaps -- a 3-s utterance 0.95 -> 0.83 ms.  Falls back to the eager call for
-        batches beyond ``GRAPH_MAX_FRAMES`` frames, conditioned generators, profiling runs and inputs that require grad.  The graphs
+        batches beyond ``GRAPH_MAX_FRAMES`` frames, profiling runs and inputs that require grad (a generator called WITH a conditioning
+        input never comes here: this entry point takes none, callers with ``g`` use ``forward``).  The graphs
         die with the packed weights (``load_state_dict`` / ``.to()`` / precision switch: the cache is dropped and rebuilt).
-        ``clone=False`` returns a view of the graph's own output buffer -- valid until the next call for the same bucket -- for callers
-        that copy it away at once (``vocoder_inference`` / ``synthesis_audios``: straight to the host)."""
+        PRIVATE because of ``clone=False``: the result is then a VIEW of the graph's own output buffer, overwritten by the next call for the
+        same bucket -- only for callers that copy it away at once (``vocoder_inference`` / ``synthesis_audios``: straight to the host).
+        The public ``forward_graphed`` always clones."""
         x = _lib.require_device_tensor(x, "generator input")
         B, C, T = x.shape
         eager = lambda: self._amp_forward(x, lengths=lengths)
@@ -506,6 +513,11 @@ class HipGenerator(nn.Module):
                     ws = cache["ws"] = torch.empty(max(need, cap + cap // 8), dtype=torch.uint8, device=x.device)
                 if ws.numel() < need:                   # (a shape whose scratch outgrows the shared one: leave it eager)
                     return eager()
+                # capture()'s warm-up forwards and the capture itself run on the SHARED scratch: order them behind the previous replay
+                # if that went to another stream (capture() itself only orders them behind the current stream)
+                last = cache.get("last")
+                if last is not None and last[0] != torch.cuda.current_stream(x.device):
+                    torch.cuda.current_stream(x.device).wait_event(last[1])
                 ent = cache[key] = self.capture(B, Tb, ragged=True, workspace=ws)
             replay, static_in, static_out = ent
             # the graphs share one scratch: a replay on ANOTHER stream than the previous one first waits for that one to finish

@@ -81,8 +81,18 @@ def cpu_baseline(sd, hp, budget_s=20.0):
     # 128 thr x1.3, 256 thr x0.17); 16 threads is the best, so that is the baseline we report.
     cores = min(os.cpu_count() or 1, int(os.environ.get("AMP_CPU_BASELINE_THREADS", "16")))
     torch.set_num_threads(cores)
+    import statistics
     with torch.no_grad():
         vo.hifigan_forward(sd, hp, synthetic_mel(1, N_MEL, 32, seed=1))  # warm-up
+        # leg b1: B = 1, T = 256, median of 3
+        mel1 = synthetic_mel(1, N_MEL, T_FRAMES, seed=3)
+        t_b1 = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            vo.hifigan_forward(sd, hp, mel1)
+            t_b1.append(time.perf_counter() - t0)
+        b1_s = statistics.median(t_b1)
+        # leg b4: B = 4, T = 256, as many forwards as fit the budget (the figure the line's top-level fields carry)
         B, T = 4, T_FRAMES
         mel = synthetic_mel(B, N_MEL, T, seed=2)
         t0 = time.perf_counter()
@@ -91,9 +101,33 @@ def cpu_baseline(sd, hp, budget_s=20.0):
             vo.hifigan_forward(sd, hp, mel)
             reps += 1
             el = time.perf_counter() - t0
-            if el >= budget_s * 0.5 or reps >= 16:
+            if el >= budget_s * 0.35 or reps >= 16:
                 break
+        # leg c1_clips: the CPU twin of other_configs.c1_clips = bins/vocoder/inference.py over the 16 clips at inference.batch_size = 1
+        # (reference :97-111): wav -> mel front end -> HiFi-GAN V1 -> crop -> PCM16, one utterance per forward, once
+        c1 = None
+        try:
+            import numpy as np
+            from oracle import pcm16 as opcm
+            G = np.load(os.path.join(ROOT, "tests", "golden", "golden_c1.npz"))
+            clips = [torch.from_numpy(G[f"pcm_{i}"].astype(np.float32) / 32768.0) for i in range(16)]
+            pp = NS(sample_rate=SAMPLE_RATE, n_fft=1024, win_size=1024, hop_size=256, n_mel=N_MEL, fmin=0, fmax=8000)
+            t1 = time.perf_counter()
+            n_out = 0
+            for w in clips:
+                m = vo.extract_mel_features(w.unsqueeze(0), pp)
+                m = m if m.dim() == 3 else m.unsqueeze(0)
+                y = vo.hifigan_forward(sd, hp, m)
+                y = y.reshape(-1)[: m.shape[-1] * 256]
+                n_out += int(opcm.float_to_pcm16(y.numpy()).size) if hasattr(opcm, "float_to_pcm16") else int(y.numel())
+            c1_s = time.perf_counter() - t1
+            secs = sum(int(c.numel()) for c in clips) / float(SAMPLE_RATE)
+            c1 = {"s_total": c1_s, "audio_s": secs, "x_realtime": secs / c1_s, "samples_out": n_out,
+                  "sample": "the 16 clips of tests/golden/golden_c1.npz, one utterance per forward, oracle front end + generator + PCM16, once"}
+        except Exception as e:  # noqa: BLE001  (a reported baseline: its failure must not cost the line)
+            c1 = {"error": f"{type(e).__name__}: {e}"[:300]}
     samples = reps * B * T * 256
+    n1 = T_FRAMES * 256
     return {
         "value": samples / el,
         "unit": "samples/s",
@@ -107,6 +141,12 @@ def cpu_baseline(sd, hp, budget_s=20.0):
         "sample_note": "B=4 rather than the GPU line's B=64: one B=64 forward is ~30 s on this path (the same per-item "
                        "work 16 times; torch's CPU convs do not speed up with batch), i.e. the whole bounded sample; "
                        "threads = the measured optimum of tests/experiments/cpu_threads_sweep.py, not the host's core count",
+        "legs": {
+            "b1": {"value": n1 / b1_s, "unit": "samples/s", "x_realtime": n1 / b1_s / SAMPLE_RATE, "s_per_forward": b1_s,
+                   "sample": "B=1, T=256, median of 3 forwards"},
+            "b4": {"value": samples / el, "unit": "samples/s", "x_realtime": samples / el / SAMPLE_RATE, "sample": f"B=4, T=256, {reps} forwards in {el:.1f} s"},
+            "c1_clips": c1,
+        },
     }
 
 
@@ -239,6 +279,10 @@ def other_configs(reps=5):
     return out
 
 
+class AgreedFailure(RuntimeError):
+    """a failure every rank has been told about (multi_gpu_diagnostics): safe to report in the line, nobody is left inside a collective"""
+
+
 def multi_gpu_diagnostics(model, mel, total_items, device, per_rank_ms, reps=5):
     """N > 1 only, after the timed region (collective calls: every rank runs this).  What a first 8-GPU run needs to be read:
     per-rank step times, the generator alone (no gather), the fp32 gather alone (nothing to overlap with) and the same gather with
@@ -246,26 +290,55 @@ def multi_gpu_diagnostics(model, mel, total_items, device, per_rank_ms, reps=5):
     from amphion_amd.distributed import gather_audio
     from amphion_amd.utils.io import wav_to_pcm16
 
-    def timed_ms(fn):
+    def agree(err):
+        """collective: every rank learns whether ANY rank failed its local part of the phase; then all of them raise the same exception
+        (an exception swallowed on one rank left the others blocked in the next collective)"""
+        flag = torch.tensor([1.0 if err else 0.0], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if flag.item() > 0:
+            raise AgreedFailure(err or "another rank failed in this phase")
+
+    def local(fn):
+        """a rank-local step (allocations, kernels): its failure is agreed on before anybody enters the next collective"""
+        err, res = None, None
+        try:
+            res = fn()
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"[:300]
+        agree(err)
+        return res
+
+    def timed_ms(fn, collective):
         dist.barrier()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        err = None
         e0.record()
-        for _ in range(reps):
-            fn()
+        try:
+            for _ in range(reps):
+                fn()
+        except Exception as e:  # noqa: BLE001
+            if collective:
+                raise      # inside a collective nothing can be agreed any more: let it propagate, the process group's timeout ends every rank
+            err = f"{type(e).__name__}: {e}"[:300]
         e1.record()
         torch.cuda.synchronize()
+        if not collective:
+            agree(err)
         t = torch.tensor([e0.elapsed_time(e1) / reps], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     with torch.no_grad():
-        wav = model(mel).squeeze(1)
-        pcm = wav_to_pcm16(wav)
-        compute_ms = timed_ms(lambda: model(mel))
-        gather_ms = timed_ms(lambda: gather_audio(wav, total_items, dst=0))
-        gather_pcm_ms = timed_ms(lambda: gather_audio(pcm, total_items, dst=0))
-        pcm_convert_ms = timed_ms(lambda: wav_to_pcm16(wav))
+        wav = local(lambda: model(mel).squeeze(1))
+        pcm = local(lambda: wav_to_pcm16(wav))
+        compute_ms = timed_ms(lambda: model(mel), collective=False)
+        # the receive buffer of the gather is the one allocation inside the collective: try its size first, on every rank, and agree
+        local(lambda: torch.empty((total_items,) + tuple(wav.shape[1:]), dtype=wav.dtype, device=device) if dist.get_rank() == 0 else None)
+        gather_ms = timed_ms(lambda: gather_audio(wav, total_items, dst=0), collective=True)
+        gather_pcm_ms = timed_ms(lambda: gather_audio(pcm, total_items, dst=0), collective=True)
+        pcm_convert_ms = timed_ms(lambda: wav_to_pcm16(wav), collective=False)
     step_ms = max(per_rank_ms)
     nbytes = wav.numel() * 4
     return {"per_rank_ms": [round(v, 3) for v in per_rank_ms], "per_rank_ms_min": min(per_rank_ms), "per_rank_ms_max": step_ms,
@@ -402,7 +475,7 @@ def main():
         # so every rank makes them -- and a failure is reported in the line, it does not cost the line
         try:
             multi = multi_gpu_diagnostics(model, mel, total_items, device, per_rank_ms)
-        except Exception as e:  # noqa: BLE001
+        except AgreedFailure as e:     # raised on EVERY rank after an all-reduce of the error flag; anything else propagates
             multi = {"multi_gpu_diagnostics_error": f"{type(e).__name__}: {e}"[:400], "per_rank_ms": [round(v, 3) for v in per_rank_ms]}
 
     if rank == 0:
@@ -513,6 +586,17 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     result[key] = {"error": f"{type(e).__name__}: {e}"[:500]}
                     torch.cuda.empty_cache()
+        # a one-glance summary at the HEAD of the line (a record that keeps only the start or the end of stdout still has every leg's figure)
+        def _ms(path):
+            d = result
+            for k in path:
+                d = d.get(k) if isinstance(d, dict) else None
+            return round(d, 3) if isinstance(d, (int, float)) else None
+        summary = {"c2_f16x3_ms": round(result["ms_per_step"], 3), "c2_strict_fp32_ms": _ms(("strict_fp32", "ms_per_step")),
+                   "c3_bigvgan_ms": _ms(("other_configs", "c3_bigvgan", "ms_per_step")), "c5_vits_decode_ms": _ms(("other_configs", "c5_vits_decode", "ms_per_step")),
+                   "c1_clips_ms": _ms(("other_configs", "c1_clips", "ms_total")), "cpu_b4_x_realtime": _ms(("cpu_baseline", "x_realtime")),
+                   "miopen_ms": _ms(("library_baseline", "ms_per_step"))}
+        result = {"summary_ms": summary, **result}
         print(json.dumps(result))
     if world > 1:
         dist.barrier()
