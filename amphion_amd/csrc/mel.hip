@@ -121,6 +121,142 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ wav,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Any other n_fft the reference accepts (round 5): torch.stft takes every length (utils/mel.py:145-169) and the reference ships
+// n_fft = 1920 = 2^7 * 3 * 5 (egs/vocoder/vocos/emilia_singnet.json:15).  Mixed-radix Stockham autosort FFT in LDS, one workgroup per
+// frame, complex n_fft-point transform: pass with radix r over Ns (the product of the radices done),
+//     j in [0, N / r):  k = j mod Ns;  v_q = in[j + q N / r] * W_N^{q k N / (Ns r)};  u_p = sum_q v_q W_r^{p q};  out[(j - k) r + k + p Ns] = u_p
+// with the whole unit circle W_N^m in LDS (one sincospif per entry and frame), radices = the prime factors of n_fft (<= 13), twos last.
+// Window, reflect padding, |X|, mel projection, log: mel_kernel's.  A fallback, not a fast path: the frame-rate front end is 0.15 % of a
+// vocoder step, and every config the reference trains with is 1 024 (mel1024_kernel).
+// ------------------------------------------------------------------------------------------------
+struct MelRadices {
+    int n;          // passes
+    int r[16];      // radix of each pass
+};
+
+template <int R>
+__device__ __forceinline__ void mixed_pass(const float2* __restrict__ in, float2* __restrict__ out, const float2* __restrict__ tw, int N, int Ns, int tid) {
+    const int M = N / R;                 // butterflies
+    const int tstep = N / (Ns * R);      // twiddle index step of this pass
+    const int rstep = N / R;             // W_R = W_N^{N / R}
+    for (int j = tid; j < M; j += 256) {
+        const int k = j % Ns;
+        float2 v[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const float2 x = in[j + q * M];
+            const float2 w = tw[(q * k * tstep) % N];
+            v[q] = make_float2(x.x * w.x - x.y * w.y, x.x * w.y + x.y * w.x);
+        }
+        const int j0 = (j - k) * R + k;
+#pragma unroll
+        for (int pq = 0; pq < R; ++pq) {
+            float2 u = v[0];
+#pragma unroll
+            for (int q = 1; q < R; ++q) {
+                const float2 w = tw[((pq * q) % R) * rstep];
+                u.x += v[q].x * w.x - v[q].y * w.y;
+                u.y += v[q].x * w.y + v[q].y * w.x;
+            }
+            out[j0 + pq * Ns] = u;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void mel_mixed_kernel(const float* __restrict__ wav, const int* __restrict__ lens, int L, int F,
+                                                        int n_fft, const MelRadices rad, int hop, int pad, int n_mel, float mag_eps,
+                                                        float log_clip, const float* __restrict__ window,
+                                                        const float* __restrict__ melbasis, float* __restrict__ mel,
+                                                        float* __restrict__ mag, float* __restrict__ re_out, float* __restrict__ im_out,
+                                                        const MelRange rng) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    mel_range_begin(rng);
+    float2* buf0 = reinterpret_cast<float2*>(smem);   // [n_fft]
+    float2* buf1 = buf0 + n_fft;                      // [n_fft]
+    float2* tw = buf1 + n_fft;                        // [n_fft]  exp(-2 pi i m / n_fft), the whole circle
+    float* magl = reinterpret_cast<float*>(tw + n_fft);   // [n_fft / 2 + 1]
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / F;
+    const int f = blockIdx.x - b * F;
+    const int bins = (n_fft >> 1) + 1;
+    const float* wb = wav + (size_t)b * L;
+    int Li = L;
+    if (lens) { Li = lens[b] < L ? lens[b] : L; if (f > (Li + 2 * pad - n_fft) / hop || Li <= pad) return; }
+
+    float rlo = 0.f, rhi = 0.f;
+    for (int n = tid; n < n_fft; n += 256) {
+        const int s = reflect_index(f * hop + n - pad, Li);
+        const float xv = wb[s];
+        rlo = fminf(rlo, xv); rhi = fmaxf(rhi, xv);
+        buf0[n] = make_float2(xv * window[n], 0.f);
+        float sn, cs;
+        sincospif(-2.0f * (float)n / (float)n_fft, &sn, &cs);
+        tw[n] = make_float2(cs, sn);
+    }
+    mel_range_end(rng, rlo, rhi);
+    __syncthreads();
+
+    float2* in = buf0;
+    float2* out = buf1;
+    int Ns = 1;
+    for (int s = 0; s < rad.n; ++s) {
+        const int r = rad.r[s];
+        switch (r) {
+            case 2: mixed_pass<2>(in, out, tw, n_fft, Ns, tid); break;
+            case 3: mixed_pass<3>(in, out, tw, n_fft, Ns, tid); break;
+            case 5: mixed_pass<5>(in, out, tw, n_fft, Ns, tid); break;
+            case 7: mixed_pass<7>(in, out, tw, n_fft, Ns, tid); break;
+            case 11: mixed_pass<11>(in, out, tw, n_fft, Ns, tid); break;
+            default: mixed_pass<13>(in, out, tw, n_fft, Ns, tid); break;
+        }
+        Ns *= r;
+        __syncthreads();
+        float2* t = in; in = out; out = t;
+    }
+    for (int k = tid; k < bins; k += 256) {
+        const float2 v = in[k];
+        const float m = sqrtf(v.x * v.x + v.y * v.y + mag_eps);
+        magl[k] = m;
+        const size_t o = ((size_t)b * bins + k) * F + f;
+        if (mag) mag[o] = m;
+        if (re_out) re_out[o] = v.x;
+        if (im_out) im_out[o] = v.y;
+    }
+    if (!mel) return;
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int m = wave; m < n_mel; m += 4) {
+        const float* row = melbasis + (size_t)m * bins;
+        float acc = 0.f;
+        for (int k = lane; k < bins; k += 64) acc = fmaf(row[k], magl[k], acc);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if (lane == 0) {
+            float v = acc;
+            if (log_clip > 0.f) v = logf(fmaxf(v, log_clip));
+            mel[((size_t)b * n_mel + m) * F + f] = v;
+        }
+    }
+}
+
+// prime factors of n (each <= 13), the twos last; false when n has a larger prime factor
+static bool mel_radices(int n, MelRadices* out) {
+    out->n = 0;
+    const int primes[6] = {13, 11, 7, 5, 3, 2};
+    for (int p : primes)
+        while (n % p == 0) {
+            if (out->n >= 16) return false;
+            out->r[out->n++] = p;
+            n /= p;
+        }
+    return n == 1;
+}
+bool mel_nfft_supported(int n_fft) {
+    MelRadices r;
+    return n_fft >= 16 && n_fft <= 4096 && mel_radices(n_fft, &r);
+}
+
+// ------------------------------------------------------------------------------------------------
 // n_fft = 1024 (every 22.05 / 24 kHz config of the reference: config/fs2.json:25-31, config/vocoder.json:34-40,
 // config/vits.json): one WAVE per frame, radix-8, real-input FFT, nothing recomputed per frame.
 //
@@ -523,6 +659,26 @@ hipError_t launch_mel(const amp_mel_desc& d, const float* wav, const int* lens, 
             e = hipMemcpyAsync(d.range_host, d.range_dev, 3 * sizeof(int), hipMemcpyDeviceToHost, stream);
         return e;
     }
+    if ((d.n_fft & (d.n_fft - 1)) != 0) {
+        // any other length with prime factors <= 13: mixed-radix Stockham, one workgroup per frame
+        MelRadices rad;
+        if (!mel_radices(d.n_fft, &rad)) return hipErrorInvalidValue;
+        const size_t lds = (size_t)(3 * d.n_fft) * sizeof(float2) + (size_t)(d.n_fft / 2 + 1) * sizeof(float);
+        static std::atomic<unsigned long long> attr_done{0};      // per device (the attribute belongs to that device's copy of the function)
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        if (!((attr_done.load(std::memory_order_acquire) >> dev) & 1ull)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mel_mixed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+            if (e != hipSuccess) return e;
+            attr_done.fetch_or(1ull << dev, std::memory_order_release);
+        }
+        hipLaunchKernelGGL(mel_mixed_kernel, dim3((unsigned)((size_t)B * F)), dim3(256), lds, stream, wav, lens, L, F, d.n_fft, rad, d.hop_size, pad,
+                           n_mel, d.mag_eps, d.log_clip, window, melbasis, mel, mag, re, im, rng);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess && d.range_dev && d.range_host)
+            e = hipMemcpyAsync(d.range_host, d.range_dev, 3 * sizeof(int), hipMemcpyDeviceToHost, stream);
+        return e;
+    }
     // generic power-of-two n_fft: one workgroup per frame, radix-2
     int log2n = 0;
     while ((1 << log2n) < d.n_fft) ++log2n;
@@ -799,8 +955,9 @@ int amp_mel_forward_ragged(const amp_mel_desc* d_in, const float* wav_dev, const
     if (!mel_desc_in(d_in, &dn, "amp_mel_forward_ragged")) return AMP_ERR_INVALID;
     const amp_mel_desc* d = &dn;
     if (!d || !wav_dev || !window_dev) { set_error("amp_mel_forward: null argument"); return AMP_ERR_INVALID; }
-    if (d->n_fft < 64 || d->n_fft > 4096 || (d->n_fft & (d->n_fft - 1)) != 0) {
-        set_error("amp_mel_forward: n_fft=%d must be a power of two in [64, 4096]", d->n_fft);
+    if (d->n_fft < 64 || d->n_fft > 4096 || !mel_nfft_supported(d->n_fft)) {
+        set_error("amp_mel_forward: n_fft=%d must lie in [64, 4096] and have no prime factor above 13 (torch.stft semantics for every 2-3-5-7-11-13-smooth length; "
+                  "a length with a larger prime factor needs a chirp-z transform, not built)", d->n_fft);
         return AMP_ERR_UNSUPPORTED;
     }
     if (d->hop_size <= 0 || B <= 0 || L <= 0) { set_error("amp_mel_forward: hop=%d B=%d L=%d", d->hop_size, B, L); return AMP_ERR_INVALID; }

@@ -46,7 +46,9 @@ def librosa_mel_fn(sr, n_fft, n_mels=128, fmin=0.0, fmax=None):
     if fmax is None:
         fmax = sr / 2.0
     bins = n_fft // 2 + 1
-    nu = np.arange(bins, dtype=np.float64) * (float(sr) / n_fft)          # FFT bin centre frequencies
+    # FFT bin centre frequencies AS librosa 0.9.1 (the reference's pin, env.sh:13) lays them out: fft_frequencies() = linspace(0, sr / 2,
+    # 1 + n_fft // 2) -- k * sr / n_fft for even n_fft, a slightly stretched grid for odd ones (round 5: the odd lengths became reachable)
+    nu = np.linspace(0.0, float(sr) / 2.0, bins, endpoint=True)
     edges = _slaney_mel_to_hz(np.linspace(_slaney_hz_to_mel(fmin), _slaney_hz_to_mel(fmax), n_mels + 2))
     lo, ce, hi = edges[:-2, None], edges[1:-1, None], edges[2:, None]
     rising = (nu[None, :] - lo) / (ce - lo)

@@ -267,9 +267,11 @@ def other_configs(reps=5):
         torch.cuda.empty_cache()
         out["vits_text_to_wave"] = bc.vits(reps)[0]       # full SynthesizerTrn.infer at config/vits.json dimensions
         torch.cuda.empty_cache()
-        r = bc.mel(max(reps, 10))[0]
+        mels = bc.mel(max(reps, 10))
+        r = mels[0]
         r.update({"algorithmic_bytes": 64 * 65536 * 4 + 64 * 80 * 256 * 4, "frac_of_hbm_peak": r["algorithmic_GBps"] / PEAK_HBM_GBS})
         out["mel_front_end"] = r
+        out["mel_front_end_other_nfft"] = mels[1:]               # n_fft 2048 / 1920 / 512: the one-workgroup-per-frame kernels
         out["mel_front_end_large"] = bc.mel_large(reps)[0]     # 1 024 x 65 536 samples: the dataset-extraction regime
         torch.cuda.empty_cache()
         out["c1_clips"] = bc.c1(reps)[0]                        # BASELINE configs[0]: the 16 real clips end to end, batch_size = 1

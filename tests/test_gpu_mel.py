@@ -163,6 +163,44 @@ def test_mel_small_nfft_and_window_shorter_than_fft():
     _check_logmel(out.numpy(), ref.numpy(), "n_fft 512 / win 400 (generic radix-2 kernel) vs oracle")
 
 
+@pytest.mark.parametrize("sr,n_fft,win,hop,n_mel,L", [
+    (24000, 1920, 1920, 480, 128, 480 * 21),      # egs/vocoder/vocos/emilia_singnet.json:15 (2^7 * 3 * 5)
+    (44100, 2048, 2048, 512, 128, 512 * 9),       # power of two beyond the wave-per-frame kernel
+    (16000, 400, 400, 160, 80, 160 * 33),         # 2^4 * 5^2
+    (22050, 1000, 800, 250, 64, 250 * 12),        # 2^3 * 5^3, window shorter than the transform
+    (16000, 882, 882, 147, 40, 147 * 20),         # 2 * 3^2 * 7^2
+    (16000, 1001, 1001, 143, 40, 143 * 25),       # odd: 7 * 11 * 13
+])
+def test_mel_any_smooth_nfft(sr, n_fft, win, hop, n_mel, L):
+    """torch.stft accepts every n_fft (utils/mel.py:145-169); amp_mel_forward now does for every length without a prime factor above 13
+    (mixed-radix kernel): log-mel and the linear spectrum against the oracle."""
+    from types import SimpleNamespace as NS
+
+    from amphion_amd.utils import mel as M
+
+    pp = NS(sample_rate=sr, n_fft=n_fft, win_size=win, hop_size=hop, n_mel=n_mel, fmin=0, fmax=None)
+    g = torch.Generator().manual_seed(n_fft)
+    y = (torch.rand(2, L, generator=g) * 2 - 1) * 0.7
+    ref = vo.mel_spectrogram_torch(y, pp)
+    out = M.mel_spectrogram_torch(y.cuda(), pp).cpu()
+    _check_logmel(out.numpy(), ref.numpy(), f"n_fft {n_fft} (mixed radix) vs oracle")
+    lin_ref = vo.extract_linear_features(y[:1], pp)
+    lin = M.extract_linear_features(y[:1].cuda(), pp).cpu()
+    assert lin.shape == lin_ref.shape
+    assert (lin - lin_ref).abs().max().item() <= 2e-5 * max(1.0, lin_ref.abs().max().item())
+
+
+def test_mel_nfft_with_a_large_prime_factor_is_refused():
+    from types import SimpleNamespace as NS
+
+    from amphion_amd._lib import AmpError
+    from amphion_amd.utils import mel as M
+
+    pp = NS(sample_rate=16000, n_fft=1021, win_size=1021, hop_size=255, n_mel=40, fmin=0, fmax=None)     # prime
+    with pytest.raises(AmpError, match="prime factor"):
+        M.mel_spectrogram_torch(torch.zeros(1, 8000).cuda(), pp)
+
+
 def test_mel_errors():
     from amphion_amd._lib import AmpError
     from amphion_amd.utils import mel as M

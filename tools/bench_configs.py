@@ -120,8 +120,17 @@ def mel(reps):
     wav = (torch.rand(64, 65536, generator=torch.Generator().manual_seed(1)) * 2 - 1).to(DEV)
     ms = timed(lambda: mel_spectrogram_torch(wav, pp), reps)
     byts = 64 * 65536 * 4 + 64 * 80 * 256 * 4
-    return [{"config": "mel front end (reflect pad + STFT 1024/256 + mel 80 + log), B=64 x 65536 samples", "ms_per_step": ms,
-             "samples_per_s": 64 * 65536 / ms * 1e3, "algorithmic_GBps": byts / ms / 1e6}]
+    out = [{"config": "mel front end (reflect pad + STFT 1024/256 + mel 80 + log), B=64 x 65536 samples", "ms_per_step": ms,
+            "samples_per_s": 64 * 65536 / ms * 1e3, "algorithmic_GBps": byts / ms / 1e6}]
+    # the other transform lengths (one workgroup per frame: radix-2 for powers of two, mixed radix otherwise -- fallbacks, not fast paths)
+    for sr, n_fft, hop, n_mel in ((44100, 2048, 512, 128), (24000, 1920, 480, 128), (16000, 512, 128, 80)):
+        pq = NS(sample_rate=sr, n_fft=n_fft, win_size=n_fft, hop_size=hop, n_mel=n_mel, fmin=0, fmax=None)
+        w = wav[:, : (65536 // hop) * hop]
+        ms2 = timed(lambda: mel_spectrogram_torch(w, pq), max(2, reps // 2))
+        b2 = 64 * w.shape[1] * 4 + 64 * n_mel * (w.shape[1] // hop) * 4
+        out.append({"config": f"mel front end, n_fft {n_fft} / hop {hop} / {n_mel} mel, B=64 x {w.shape[1]} samples", "ms_per_step": ms2,
+                    "samples_per_s": 64 * w.shape[1] / ms2 * 1e3, "algorithmic_GBps": b2 / ms2 / 1e6})
+    return out
 
 
 def mel_large(reps):
