@@ -114,7 +114,6 @@ _SIGNATURES = {
     "amp_rel_attention_strided": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "amp_set_rel_attention_tiled": (c_int, [c_int]),
     "amp_set_resblock_streams": (c_int, [c_int]),
-    "amp_set_wn_layer_fusion": (c_int, [c_int]),
     "amp_gen_prepare_streams": (c_int, [c_void_p]),
     "amp_rel_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "amp_dwconv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -139,12 +138,10 @@ _SIGNATURES = {
     "amp_set_conv_blk": (c_int, [c_int]),
     "amp_set_conv_rg_fast": (c_int, [c_int]),
     "amp_set_pingpong": (c_int, [c_int]),
-    "amp_set_fuse_act": (c_int, [c_int]),
     "amp_set_conv_blk_narrow": (c_int, [c_int]),
     "amp_ampblock_forward": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                      c_void_p, c_int, c_int, c_void_p, c_int, c_float, c_void_p]),
     "amp_set_ampblock_fusion": (c_int, [c_int]),
-    "amp_conv_act_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "amp_conv_create_gated": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, POINTER(c_void_p)]),
     "amp_wn_forward": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_int, c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_int, c_int,
                                c_void_p, c_void_p, c_void_p]),

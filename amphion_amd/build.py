@@ -39,7 +39,7 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE,
 def _units():
     units = [("generator.hip", "generator.o", []), ("small_kernels.hip", "small_kernels.o", []),
              ("mel.hip", "mel.o", []), ("vits_text.hip", "vits_text.o", []), ("pair3_f16x3.hip", "pair3_f16x3.o", []),
-             ("conv_small3_f16x3.hip", "conv_small3_f16x3.o", []), ("wn_layer_f16x3.hip", "wn_layer_f16x3.o", [])]
+             ("conv_small3_f16x3.hip", "conv_small3_f16x3.o", [])]
     for kt in CONV_TAPS:
         units.append(("conv_mfma.hip", f"conv_mfma_kt{kt}.o", [f"-DAMP_KT={kt}"]))
         units.append(("conv_f16x3.hip", f"conv_f16x3_kt{kt}.o", [f"-DAMP_KT={kt}"]))

@@ -65,11 +65,6 @@ struct ConvArgs {
     float* wn_x;                // EPI_WNACC: x [B, H, T], updated in place: x = (x + rs[:H]) * mask
     float* wn_out;              //            output [B, H, T]: (+)= rs[H:] (last layer: (+)= rs)
     int wn_first, wn_last;      //            first layer starts `output` from zero; last layer has H rows only
-    // ---- conv_f16x3.hip, ACT variant: Activation1d applied to the conv's output in the epilogue (bigvgan.py:141-143) ----
-    const float* act_a;         // [Cout] alpha (exp'ed when logscale)
-    const float* act_invb;      // [Cout] 1 / (beta + 1e-9)
-    const float* act_fu;        // 12 up-sampling taps
-    const float* act_fd;        // 12 down-sampling taps
 };
 
 // Arguments of the fused ResBlock-pair kernel (pair_f16x3.hip):
@@ -96,15 +91,6 @@ struct PairArgs {
     int len_mul;
     unsigned* range_flag;      // see ConvArgs
 };
-
-// A whole WN layer in one launch (wn_layer_f16x3.hip): g = the gated in-layer conv's arguments (EPI_GATE fields; y unused), r = the res_skip
-// conv's (EPI_WNACC fields; wn_x = the x this layer READS, x unused), x_out = where x' = (x + rs[:H]) * mask goes (never wn_x itself)
-struct WnLayerArgs {
-    ConvArgs g;
-    ConvArgs r;
-    float* x_out;
-};
-hipError_t launch_wn_layer(int kt, int nw, const WnLayerArgs& p, hipStream_t stream);
 
 // Three whole-K convs in one grid (conv_small3_f16x3.hip): a[0] / a[1] / a[2] = the k = 11 / 7 / 3 conv (standard epilogue) of a stage's three
 // resblocks, nx[j] = B * tiles_per_item column tiles x ny[j] = ceil(M / 128) row groups each
@@ -187,8 +173,6 @@ struct ConvPlan {
 bool choose_plan(int ntaps, int M, int halo_total, int Tq, ConvPlan* plan);
 hipError_t launch_conv(const ConvPlan& plan, const ConvArgs& a, hipStream_t stream);        // exact f32 MFMA
 hipError_t launch_conv_f16x3(const ConvPlan& plan, const ConvArgs& a, hipStream_t stream);  // split-f16 MFMA
-// the same kernel with Activation1d fused behind it (a.act_*): tiles advance by NT - 16 columns; full-width tiles only
-hipError_t launch_conv_f16x3_act(const ConvPlan& plan, const ConvArgs& a, hipStream_t stream);
 // frame-rate convs (conv_small_f16x3.hip): whole-K staging; epi 0 standard, 1 gate, 2 WN accumulate; ni 2 | 4
 constexpr int kSmallConvMaxChunks = 16;
 hipError_t launch_conv_small(int KT, int ni, int epi, const ConvArgs& a, hipStream_t stream);

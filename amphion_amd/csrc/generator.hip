@@ -333,34 +333,26 @@ hipError_t launch_ampb(int k, const AmpbArgs& a, int wide, hipStream_t s) {
 
 // ---- launch-policy switches: ONE configuration, read from the environment once (first use) and changed afterwards only
 // through the amp_set_* entry points the tests use for their bitwise A/B comparisons.  Nothing on a launch path calls getenv.
+// Environment forms exist for the FOUR switches a deployment may want without code (round 5 dropped AMP_FUSE_PAIRS, AMP_PAIR_STRIP,
+// AMP_CONV_BLK, AMP_RB_SUM_FRAMES, AMP_RB_HORIZONTAL, AMP_RB_HORIZONTAL_FRAMES and AMP_GROUP_MB: amp_set_* or nothing):
 //   AMP_PRECISION     f32 | f16x3       arithmetic of the conv contractions (amp_set_precision), read in precision()
-//   AMP_FUSE_PAIRS    0                 every ResBlock pair as two conv launches
-//   AMP_PAIR_STRIP    0 | 1             per-tile pair kernel everywhere | four-wave strips wherever built (default: the policy)
 //   AMP_RB_FUSION     0 .. 3            whole-ResBlock kernel: off | policy (default) | wherever built | + four-wave tiles
-//   AMP_CONV_BLK      0 .. 3            row-blocked conv kernel forms (default 3)
 //   AMP_AMPB_FUSION   0 .. 3            whole-AMPBlock kernel (BigVGAN): off | policy (default) | wherever built | + four-wave tiles
-//   AMP_GROUP_MB      n                 depth-first batch groups of n MB (default 0 = off)
+//   AMP_RB_STREAMS    -1 .. 1           a stage's resblocks on concurrent streams: small launches only (default) | never | always
+// (+ AMP_LAUNCH_MANIFEST=<file>, the profiling manifest above, and AMP_GRAPH_CACHE=0 on the Python side.)
 constexpr int kConvBlkDefault = 3;
 struct Config {
-    int fuse_pairs = 1;
     int pair_strips = -1;      // -1 policy, 0 per-tile kernel, 1 four-wave strips
     int rb_fusion = 1;
     int ampb_fusion = 1;
     int conv_blk = kConvBlkDefault;
     size_t group_bytes = 0;
-    // no environment form: bit-identical A/B switches for the tests (amp_set_small_conv / _conv_rg_fast / _pingpong / _fuse_act)
+    // no environment form: bit-identical A/B switches for the tests (amp_set_small_conv / _conv_rg_fast / _pingpong)
     int small_conv = 1;
     int conv_rg_fast = 1;
     int pingpong = 1;
-    int fuse_act = 0;
     int narrow_blk = 1;        // row-blocked conv kernel for 128- / 64-row convs (amp_set_conv_blk_narrow)
     int rb_streams = -1;       // resblocks of a stage on concurrent streams: -1 small launches only, 0 never, 1 always (amp_set_resblock_streams)
-    int wn_layer = 0;          // one-launch WN layer (wn_layer_f16x3.hip): 0 = two launches per layer (default: the fused form measured EQUAL),
-                               // 4 / 8 / 12 = waves per workgroup (amp_set_wn_layer_fusion)
-    int rb_horizontal = 1;     // concurrent mode: a stage's three fused pairs in ONE grid (pair3_f16x3.hip) where they apply (AMP_RB_HORIZONTAL=0: streams only)
-    int rb_horizontal_frames = 0;  // ... while B * T <= this many frames (AMP_RB_HORIZONTAL_FRAMES; 0 = kRbHorizontalMaxFrames)
-    int rb_sum_frames = 1 << 20;   // concurrent mode: per-resblock results + one MRF-mean launch while B * T <= this many frames (AMP_RB_SUM_FRAMES, A/B switch;
-                                   // 0 = always chain).  Same-box sweep, profiles/r4_streams_sum_vs_chain.txt: the summed form wins at every batch size
     Config() {
         auto num = [](const char* name, int lo, int hi, int dflt) {
             const char* e = getenv(name);
@@ -368,21 +360,12 @@ struct Config {
             const int v = atoi(e);
             return (v < lo || v > hi) ? dflt : v;
         };
-        fuse_pairs = num("AMP_FUSE_PAIRS", 0, 1, 1);
-        pair_strips = num("AMP_PAIR_STRIP", 0, 1, -1);
         rb_fusion = num("AMP_RB_FUSION", 0, 3, 1);
         ampb_fusion = num("AMP_AMPB_FUSION", 0, 3, 1);
-        conv_blk = num("AMP_CONV_BLK", 0, 3, kConvBlkDefault);
         rb_streams = num("AMP_RB_STREAMS", -1, 1, -1);
-        rb_sum_frames = num("AMP_RB_SUM_FRAMES", 0, 1 << 20, 1 << 20);
-        rb_horizontal = num("AMP_RB_HORIZONTAL", 0, 1, 1);
-        rb_horizontal_frames = num("AMP_RB_HORIZONTAL_FRAMES", 0, 1 << 20, 0);
-        const char* e = getenv("AMP_GROUP_MB");
-        group_bytes = (e && atol(e) > 0) ? (size_t)atol(e) << 20 : 0;
     }
 };
 static Config& cfg() { static Config c; return c; }
-static bool fuse_pairs_enabled() { return cfg().fuse_pairs != 0; }
 
 // Which fused-pair kernel a (C, k) pair runs.  Results are bit-identical either way (tests/test_gpu_pair.py); the choice
 // is measured (profiles/r2_cd_strip_kernel.txt, r2_j_strip_policy.txt): the strip-mined kernel (pair_strip_f16x3.hip)
@@ -390,13 +373,11 @@ static bool fuse_pairs_enabled() { return cfg().fuse_pairs != 0; }
 // independent tiles: in its 4-wave form it wins 1.5 % on the k = 11, C = 128 pairs and loses everywhere else.  Its
 // 2 x 2-blocked form (a wave owns 64 rows x 96 columns, one workgroup per CU, 512 registers: half the LDS reads per
 // MFMA) wins 2-5 % for k >= 7 at C = 128 -- the policy at the end of strip_choice().
-//   amp_set_pair_strips(-1) / AMP_PAIR_STRIP unset: the measured policy below;  0: per-tile kernel everywhere
-//   (round 1);  1: strips wherever they are built (incl. C = 256, which has no per-tile form).
-struct StripChoice { bool use; int wide; int steps; };   // wide: 0 four-wave strips, 3 the A-ring form; steps = 0: the planner sizes the strips
+//   amp_set_pair_strips(-1): the measured policy below;  0: per-tile kernel everywhere (the bitwise cross-check of the strips).
+struct StripChoice { bool use; int wide; int steps; };   // wide: 3 the A-ring form (the only strip form left); steps = 0: the planner sizes the strips
 static StripChoice strip_choice(int C, int k) {
     const int mode = cfg().pair_strips;
     if (mode == 0) return {false, 0, 0};
-    if (mode == 1) return {true, 0, 0};
     // measured policy.  C = 128, k in {7, 11}: the 2 x 2-blocked strips with an A-fragment ring, 64 x 128-column wave tiles, one
     // 256-column step per strip (pair_strip_f16x3.hip; profiles/r2_aw_strip_ring.txt: k = 11 1.86 ms against 2.23 for the per-tile
     // kernel, k = 7 1.27 against 1.43; inside the forward 1.88 / 1.31 ms, profiles/r3_a_kernel_stats.csv).  Everything else: per-tile
@@ -432,20 +413,6 @@ static void strip_plan(int B, int T, int n1, int hb, int wg_per_cu, int* strip_l
 // One 3-s utterance 1.56 -> 1.24 ms, one 10-s utterance 2.80 -> 2.38 ms; the frame-rate convs of VITS (short
 // contractions) neither gain nor lose (profiles/r1_exp_small_tiles.txt).
 constexpr long long kSmallGridWorkgroups = 384;
-
-hipError_t launch_conv_h_act_kt3(const ConvPlan&, const ConvArgs&, hipStream_t);
-hipError_t launch_conv_h_act_kt5(const ConvPlan&, const ConvArgs&, hipStream_t);
-hipError_t launch_conv_h_act_kt7(const ConvPlan&, const ConvArgs&, hipStream_t);
-hipError_t launch_conv_h_act_kt11(const ConvPlan&, const ConvArgs&, hipStream_t);
-hipError_t launch_conv_f16x3_act(const ConvPlan& p, const ConvArgs& a, hipStream_t s) {
-    switch (p.KT) {
-        case 3: return launch_conv_h_act_kt3(p, a, s);
-        case 5: return launch_conv_h_act_kt5(p, a, s);
-        case 7: return launch_conv_h_act_kt7(p, a, s);
-        case 11: return launch_conv_h_act_kt11(p, a, s);
-    }
-    return hipErrorInvalidValue;
-}
 
 hipError_t launch_conv_small_kt1(int, int, const ConvArgs&, hipStream_t);
 hipError_t launch_conv_small_kt3(int, int, const ConvArgs&, hipStream_t);
@@ -749,54 +716,9 @@ static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope
     return AMP_OK;
 }
 
-// `a2(c1(x))` of an AMPBlock as ONE launch (the conv kernel's ACT variant, conv_f16x3.hip) instead of conv + act1d: same
-// bits (tests/test_gpu_bigvgan.py), one read and one write of the tensor less -- and SLOWER on MI355X (visit Y,
-// profiles/r2_y_conv_act_fused.txt: the conv launches grow by 110-145 us each, as much as the act1d launch they
-// replace, plus 14 % recomputed margin: C3 27.6 vs 26.8 ms).  The activation is VALU + LDS work that the stand-alone
-// kernel runs at 8 waves per SIMD under its own HBM stream; behind a conv it runs at 2 waves per SIMD and overlaps
-// nothing.  Off unless amp_set_fuse_act(1).
-static bool fuse_act_enabled() { return cfg().fuse_act != 0; }
-
-// conv + Activation1d in one launch is built for: f16x3, Conv1d with 'same' zero padding, k in {3, 5, 7, 11}, a bias,
-// rows a multiple of the kernel's row group; the launch must be large enough for full-width tiles
-static bool conv_act_supported(const amp_conv* c, int B, int T) {
-    if (c->precision != PREC_F16X3 || c->transposed || c->pad_reflect || c->tanh_out || c->gated_H || !c->bias_dev) return false;
-    if (c->KT != c->ntaps || (c->KT != 3 && c->KT != 5 && c->KT != 7 && c->KT != 11)) return false;
-    if (c->M % c->plan.Mgroup() != 0 || conv_out_len(c, T) != T) return false;
-    ConvPlan plan = c->plan;   // NI = 4
-    const long long wgs = (long long)B * ((T + plan.NT() - 1) / plan.NT()) * (c->M / plan.Mgroup());
-    return wgs >= kSmallGridWorkgroups;
-}
-
-// y = Activation1d(conv(x) + bias): a2(c1(xt)) of AMPBlock1 (bigvgan.py:141-143).  y must not alias x.
-static int conv_act_run(const amp_conv* c, const float* x, int B, int T, const float* act_a, const float* act_invb,
-                        const float* act_fu, const float* act_fd, float* y, hipStream_t stream, const int* lens = nullptr,
-                        int len_mul = 1) {
-    if (!conv_act_supported(c, B, T)) { set_error("conv_act_run: unsupported conv / launch shape"); return AMP_ERR_UNSUPPORTED; }
-    if (x == y) { set_error("conv_act_run: x and y must not alias"); return AMP_ERR_INVALID; }
-    ConvArgs a{};
-    a.x = x; a.wp = c->wp_dev; a.bias = c->bias_dev; a.res = nullptr; a.y = y;
-    a.B = B; a.Cin = c->cin; a.Tin = T; a.xbs = (long long)c->cin * T; a.nchunks = c->nchunks; a.M = c->M;
-    a.Tq = T;
-    const ConvPlan plan = c->plan;
-    const int AT = plan.NT() - 16;
-    a.tiles_per_item = (T + AT - 1) / AT;
-    a.off0 = c->off0; a.dstep = c->dstep; a.halo_left = c->halo_left;
-    a.wd = plan.NT() + c->halo_left + c->halo_right;
-    a.Cout = c->cout; a.Tout = T; a.up = 1; a.up_pad = 0;
-    a.slope_in = 1.f; a.slope_out = 1.f; a.mode = 0; a.div = 1.f;
-    a.lens = lens; a.len_mul = len_mul;
-    a.range_flag = range_flag_for_current_device();
-    a.acc_scale = 16.f * c->wscale; a.inv_scale = 1.f / a.acc_scale;
-    a.act_a = act_a; a.act_invb = act_invb; a.act_fu = act_fu; a.act_fd = act_fd;
-    AMP_HIP(launch_conv_f16x3_act(plan, a, stream));
-    return AMP_OK;
-}
-
 // Fused ResBlock1 pair (pair_f16x3.hip): y = x + c2(lrelu(c1(lrelu(x)))).  Returns false when this
 // (channels, kernel, dilation, precision) is not covered and the caller must run the two convs.
 static bool pair_supported(const amp_conv* c1, const amp_conv* c2) {
-    if (!fuse_pairs_enabled()) return false;
     if (c1->precision != PREC_F16X3 || c2->precision != PREC_F16X3) return false;
     if (c1->pad_reflect || c2->pad_reflect || c1->tanh_out || c2->tanh_out) return false;
     if (c1->transposed || c2->transposed || c1->cin != c1->cout || c2->cin != c2->cout || c1->cin != c2->cin) return false;
@@ -1177,8 +1099,10 @@ extern "C" {
 // _pingpong; 130 (round 3's ABI, numbered in round 4): amp_mel_desc grew four trailing fields, + amp_resblock_forward /
 // amp_set_resblock_fusion / amp_gen_kernel_name; 140: amp_mel_desc.struct_size, + amp_ampblock_forward / amp_set_ampblock_fusion / amp_mel_init;
 // 141 (additive): the ragged / fused entry points of the VITS text side (amp_conv_forward_ragged, amp_layer_norm_c_ragged, amp_dwconv_layer_norm_c,
-// amp_rel_attention_strided, amp_set_rel_attention_tiled, amp_expand_path_strided)
-int amp_version(void) { return 141; }
+// amp_rel_attention_strided, amp_set_rel_attention_tiled, amp_expand_path_strided); 142 (round 5, REMOVALS): amp_conv_act_forward, amp_set_fuse_act,
+// amp_set_wn_layer_fusion are gone with the kernels behind them (never chosen by the launch policy), amp_set_pair_strips(1) is refused; amp_mel_forward
+// accepts every n_fft without a prime factor above 13
+int amp_version(void) { return 142; }
 const char* amp_last_error(void) { return g_err; }
 
 int amp_set_precision(int precision) {
@@ -1494,7 +1418,7 @@ size_t amp_gen_workspace_bytes(const amp_gen* g, int B, int T) {
 }
 
 int amp_set_pair_strips(int on) {
-    if (on < -1 || on > 1) { set_error("amp_set_pair_strips: %d", on); return AMP_ERR_INVALID; }
+    if (on < -1 || on > 0) { set_error("amp_set_pair_strips: %d (-1 the policy, 0 the per-tile kernel everywhere; the four-wave strips of mode 1 left in ABI 142)", on); return AMP_ERR_INVALID; }
     cfg().pair_strips = on;
     return AMP_OK;
 }
@@ -1624,7 +1548,7 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
         // replay, but 1.08 instead of 0.90-0.95 ms eager, where the host issues the critical stream's launches last.)
         // Horizontal form (pair3_f16x3.hip): where the stage's three resblocks (k = 11 / 7 / 3) run as per-tile fused pairs, pair p of all
         // three shares ONE launch -- nd launches + the MRF mean instead of 3 nd launches on three streams with their fork / join events.
-        if (conc && cfg().rb_horizontal && (long long)B * T <= (cfg().rb_horizontal_frames > 0 ? cfg().rb_horizontal_frames : kRbHorizontalMaxFrames) && d.resblock_type == 1 && !big && nk == 3) {
+        if (conc && (long long)B * T <= kRbHorizontalMaxFrames && d.resblock_type == 1 && !big && nk == 3) {
             int slot_of[3] = {-1, -1, -1};                 // resblock index holding k = 11 / 7 / 3
             bool okh = true;
             for (int j = 0; j < 3; ++j) {
@@ -1666,7 +1590,7 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
         // The same for a stage of UNFUSED whole-K convs (the C = 256 stage of a single utterance): c1 of a dilation, then c2, of all
         // three resblocks in one launch each (conv_small3_f16x3.hip); only the three convs that accumulate into XS stay separate
         // launches, in resblock order with their `=` / `+=` / `(y + v) / n` modes (they add y BEFORE the products: no post-hoc mean).
-        if (conc && cfg().rb_horizontal && (long long)B * T <= (cfg().rb_horizontal_frames > 0 ? cfg().rb_horizontal_frames : kRbHorizontalMaxFrames) && d.resblock_type == 1 && !big && nk == 3) {
+        if (conc && (long long)B * T <= kRbHorizontalMaxFrames && d.resblock_type == 1 && !big && nk == 3) {
             int slot_of[3] = {-1, -1, -1};
             bool okh = true;
             for (int j = 0; j < 3; ++j) {
@@ -1735,7 +1659,7 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
         // A stage whose resblocks ALL end in a fused pair / whole-resblock kernel (HiFi-GAN, C <= 128) needs no chain: those kernels add
         // the accumulated y to their finished, rounded result, so each resblock stores its own result (mode 0) and one small launch forms
         // ((XS0 + XS1) + XS2) / n afterwards -- the same bits with one join instead of two chained cross-queue waits (~12 us each).
-        bool sum_stage = conc && d.resblock_type == 1 && !big && nk - 1 <= AMP_MRF_MAX_PARTS && (long long)B * T <= cfg().rb_sum_frames;
+        bool sum_stage = conc && d.resblock_type == 1 && !big && nk - 1 <= AMP_MRF_MAX_PARTS;
         for (int j = 0; sum_stage && j < nk; ++j) {
             const ResBlock& rb = g->rbs[(size_t)i * nk + j];
             const size_t last = rb.dil.size() - 1;
@@ -1811,15 +1735,9 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
                             AMP_HIP(hipMemcpyAsync(R_, TMP_, (size_t)B * C * t * sizeof(float), hipMemcpyDeviceToDevice, sj));
                             cur = R_;
                         }
+                        AMP_RC(conv_run(rb.c1[p].get(), ACT_, B, t, 1.f, nullptr, 1.f, TMP_, 0, 1.f, sj, 0, lens, lm));
+                        AMP_HIP(launch_act1d(TMP_, ACT_, B, C, t, a2.a_dev, a2.invb_dev, a2.fu_dev, a2.fd_dev, lens, lm, sj, next_rev(lens)));
                         const float* c2_in = ACT_;
-                        if (fuse_act_enabled() && conv_act_supported(rb.c1[p].get(), B, t)) {
-                            // a2(c1(.)) in one launch: the conv's output tile never leaves the CU un-activated
-                            AMP_RC(conv_act_run(rb.c1[p].get(), ACT_, B, t, a2.a_dev, a2.invb_dev, a2.fu_dev, a2.fd_dev, TMP_, sj, lens, lm));
-                            c2_in = TMP_;
-                        } else {
-                            AMP_RC(conv_run(rb.c1[p].get(), ACT_, B, t, 1.f, nullptr, 1.f, TMP_, 0, 1.f, sj, 0, lens, lm));
-                            AMP_HIP(launch_act1d(TMP_, ACT_, B, C, t, a2.a_dev, a2.invb_dev, a2.fu_dev, a2.fd_dev, lens, lm, sj, next_rev(lens)));
-                        }
                         if (!last) { AMP_RC(conv_run(rb.c2[p].get(), c2_in, B, t, 1.f, cur, 1.f, R_, 0, 1.f, sj, 0, lens, lm)); cur = R_; }
                         else { AMP_RC(before_last()); AMP_RC(conv_run(rb.c2[p].get(), c2_in, B, t, 1.f, cur, 1.f, XSJ, mode_last, (float)nk, sj, 0, lens, lm)); }
                     }
@@ -2081,29 +1999,9 @@ int amp_wn_forward(const amp_conv* const* in_layers, const amp_conv* const* res_
             return AMP_ERR_INVALID;
         }
     }
-    // one launch per layer (wn_layer_f16x3.hip) where the layers qualify: x ping-pongs between x_dev and acts_ws_dev (acts itself never
-    // leaves the CU); else two launches per layer with acts through acts_ws_dev
-    bool one_launch = cfg().wn_layer != 0;
-    for (int i = 0; one_launch && i < n_layers; ++i)
-        one_launch = small_conv_ni(in_layers[i]) == 1 && small_conv_ni(res_skip_layers[i]) == 1 && (in_layers[i]->KT == 1 || in_layers[i]->KT == 3 || in_layers[i]->KT == 5);
-    float* xc = x_dev;            // the x the next layer reads
-    float* xn = acts_ws_dev;
     for (int i = 0; i < n_layers; ++i) {
         ConvArgs a;
         const int ni_in = small_conv_ni(in_layers[i]), ni_rs = small_conv_ni(res_skip_layers[i]);
-        if (one_launch) {
-            WnLayerArgs p{};
-            small_args(in_layers[i], xc, B, T, lens_dev, 1, &p.g);
-            p.g.wn_H = H;
-            p.g.gate_cond = cond_dev ? cond_dev + (size_t)i * 2 * H : nullptr;
-            p.g.gate_cond_bs = cond_batch_stride;
-            small_args(res_skip_layers[i], xc, B, T, lens_dev, 1, &p.r);
-            p.r.wn_H = H; p.r.wn_x = xc; p.r.wn_out = out_dev; p.r.wn_first = i == 0; p.r.wn_last = i == n_layers - 1;
-            p.x_out = xn;
-            AMP_HIP(launch_wn_layer(in_layers[i]->KT, cfg().wn_layer, p, stream));
-            if (i < n_layers - 1) { float* t_ = xc; xc = xn; xn = t_; }
-            continue;
-        }
         small_args(in_layers[i], x_dev, B, T, lens_dev, ni_in, &a);       // in_layers[i](x * mask) + g_l -> tanh * sigmoid (round 4: the mask is the kernel's
                                                                           // select at staging, so the caller's x need not be masked; tiles beyond an end are skipped)
         a.y = acts_ws_dev; a.wn_H = H;
@@ -2116,33 +2014,6 @@ int amp_wn_forward(const amp_conv* const* in_layers, const amp_conv* const* res_
         AMP_HIP(launch_conv_small(1, ni_rs, 2, a, stream));
     }
     return AMP_OK;
-}
-
-int amp_set_wn_layer_fusion(int mode) {
-    if (mode != -1 && mode != 0 && mode != 4 && mode != 8 && mode != 12) { set_error("amp_set_wn_layer_fusion: mode=%d (0 off, 4 / 8 / 12 waves, -1 default)", mode); return AMP_ERR_INVALID; }
-    cfg().wn_layer = mode < 0 ? 0 : mode;
-    return AMP_OK;
-}
-
-int amp_set_fuse_act(int on) {
-    cfg().fuse_act = on ? 1 : 0;
-    return AMP_OK;
-}
-
-int amp_conv_act_forward(const amp_conv* c, const float* x_dev, int B, int T, const float* alpha_dev, const float* beta_dev,
-                         int logscale, const float* filt_up_host, const float* filt_down_host, float* y_dev, void* stream) {
-    if (!c || !x_dev || !y_dev || !alpha_dev || !filt_up_host || !filt_down_host) { set_error("amp_conv_act_forward: null argument"); return AMP_ERR_INVALID; }
-    if (B <= 0 || T <= 0) { set_error("amp_conv_act_forward: B=%d T=%d", B, T); return AMP_ERR_INVALID; }
-    if (!conv_act_supported(c, B, T)) { set_error("amp_conv_act_forward: conv / launch shape outside the fused kernel (run amp_conv_forward + amp_antialias_snake)"); return AMP_ERR_UNSUPPORTED; }
-    float* scratch = nullptr;
-    const int C = c->cout;
-    int rc = act_params_upload(alpha_dev, beta_dev, C, logscale, filt_up_host, filt_down_host, &scratch);
-    if (rc != AMP_OK) return rc;
-    rc = conv_act_run(c, x_dev, B, T, scratch, scratch + C, scratch + 2 * C, scratch + 2 * C + 12, y_dev, (hipStream_t)stream);
-    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
-    (void)hipFree(scratch);
-    if (rc == AMP_OK && e != hipSuccess) { set_error("amp_conv_act_forward: %s", hipGetErrorString(e)); return AMP_ERR_HIP; }
-    return rc;
 }
 
 int amp_conv_out_len(const amp_conv* c, int T) { return c ? conv_out_len(c, T) : 0; }

@@ -439,37 +439,23 @@ static hipError_t launch_strip_one(const PairArgs& a, hipStream_t stream) {
 
 // Step width (xt columns = output columns per step) for C channels, or 0 when (C, KT, dilation) is not covered;
 // *wg_per_cu = resident workgroups per CU (LDS / register bound), used by the host to size the strips.
-// wide = 3: the 2 x 2-blocked form with an A-fragment ring -- C = 128, k >= 7: 4 waves x (64 rows x 128 columns), 256-column steps.
-// wide = 0: four waves x (32 rows x NI x 32 columns), two workgroups per CU; C = 256: eight waves, one workgroup per CU.
-// (Round 2's 8-wave double-width tiles and the whole-chunk 2 x 2 form were measured neutral or slower and are gone; so is the
-// C = 64 ring form -- a wave owning all 64 rows x 96 columns, 384-column steps: -5 % at k = 11, then overtaken by rb_f16x3.hip.)
+// ONE form is left (round 5): wide = 3, the 2 x 2-blocked strips with an A-fragment ring -- C = 128, k >= 7: 4 waves x (64 rows x 128 columns),
+// 256-column steps, one workgroup per CU -- the form the launch policy picks.  The four-wave strips (C = 32 / 64 / 128, two workgroups per CU:
+// +1.5 % at C = 128, k = 11, slower elsewhere) and the eight-wave C = 256 strips (overtaken by the row-blocked conv kernel) were reachable
+// only through amp_set_pair_strips(1) and are gone, like round 2's double-width tiles, the whole-chunk 2 x 2 form and the C = 64 ring form.
 int AMP_CAT(strip_step_kt, AMP_KT)(int C, int dil, int wide, int* wg_per_cu) {
     constexpr int KT = AMP_KT;
     const int span = (KT - 1) * dil;   // staged halo = 2 * h1
-    int n1 = 0, wg = 2;
-    if (C == 256) { n1 = (96 + span <= 256) ? 96 : 0; wg = 1; }
-    else if (wide == 3 && C == 128) { n1 = (KT >= 7 && 256 + span <= 320) ? 256 : 0; wg = 1; }
-    else if (wide == 3) { n1 = 0; wg = 1; }
-    else if (C == 128) n1 = (96 + span <= 192) ? 96 : 0;
-    else if (C == 64) n1 = (128 + span <= 192) ? 128 : 0;
-    else if (C == 32) n1 = (256 + span <= 320) ? 256 : 0;
-    if (wg_per_cu) *wg_per_cu = wg;
-    return n1;
+    if (wg_per_cu) *wg_per_cu = 1;
+    if (wide == 3 && C == 128) return (KT >= 7 && 256 + span <= 320) ? 256 : 0;
+    return 0;
 }
 
 hipError_t AMP_CAT(launch_strip_kt, AMP_KT)(const PairArgs& a, hipStream_t stream) {
     constexpr int KT = AMP_KT;
-    const int span = (KT - 1) * a.dil;
-    if (a.C == 256) return launch_strip_one<KT, 8, 1, 3, 256>(a, stream);
-    if (a.wide == 3) {
-        if constexpr (KT >= 7) {
-            if (a.C == 128) return launch_strip_one<KT, 2, 2, 4, 320, 2, 4, 1>(a, stream);
-        }
-        return hipErrorInvalidValue;
+    if constexpr (KT >= 7) {
+        if (a.wide == 3 && a.C == 128) return launch_strip_one<KT, 2, 2, 4, 320, 2, 4, 1>(a, stream);
     }
-    if (a.C == 128) return span <= 32 ? launch_strip_one<KT, 4, 1, 3, 128>(a, stream) : launch_strip_one<KT, 4, 1, 3, 192>(a, stream);
-    if (a.C == 64) return launch_strip_one<KT, 2, 2, 2, 192>(a, stream);
-    if (a.C == 32) return launch_strip_one<KT, 1, 4, 2, 320>(a, stream);
     return hipErrorInvalidValue;
 }
 

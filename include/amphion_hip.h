@@ -88,7 +88,9 @@ typedef struct amp_gen amp_gen;
  * added amp_resblock_forward / amp_set_resblock_fusion / amp_gen_kernel_name; 140 (round 4): amp_mel_desc starts with struct_size
  * (an ABI break for every earlier consumer of that struct -- re-compile against this header), + amp_mel_init,
  * amp_ampblock_forward, amp_set_ampblock_fusion; 141 (additive): amp_conv_forward_ragged, amp_layer_norm_c_ragged,
- * amp_dwconv_layer_norm_c, amp_rel_attention_strided, amp_set_rel_attention_tiled, amp_expand_path_strided. */
+ * amp_dwconv_layer_norm_c, amp_rel_attention_strided, amp_set_rel_attention_tiled, amp_expand_path_strided; 142 (round 5) REMOVES
+ * amp_conv_act_forward, amp_set_fuse_act and amp_set_wn_layer_fusion together with the kernels behind them (bit-identical forms the launch
+ * policy never chose), refuses amp_set_pair_strips(1), and lets amp_mel_forward take any n_fft whose prime factors are <= 13. */
 int amp_version(void);
 const char* amp_last_error(void);
 /* Number of HIP devices visible (0 when there is no GPU); never fails. */
@@ -123,7 +125,7 @@ size_t amp_gen_workspace_bytes(const amp_gen* g, int B, int T);
 
 /* amp_gen_forward can run the batch depth-first in groups of items (each group through the whole
  * generator) to bound the workspace: target working set in MiB, 0 = whole batch per layer (default; the
- * faster setting on MI355X).  Also settable with the environment variable AMP_GROUP_MB.
+ * faster setting on MI355X).
  * Results do not depend on it. */
 int amp_set_group_mb(int megabytes);
 
@@ -142,8 +144,8 @@ int amp_gen_range_check(amp_gen* g, void* stream);
 
 /* Fused ResBlock pairs (hifigan.py:93-100) have two kernels with bit-identical results (tests/test_gpu_pair.py): the
  * per-tile kernel and the strip-mined kernel (a workgroup walks a strip of one utterance and carries conv2's halo in
- * LDS; also covers C = 256).  -1 (default; AMP_PAIR_STRIP unset): the measured per-shape policy; 0: per-tile
- * everywhere; 1: strips wherever they exist.  A tuning / cross-check switch. */
+ * LDS; C = 128, k >= 7, launches that fill the chip).  -1 (default): the measured per-shape policy; 0: per-tile
+ * everywhere (the cross-check).  Mode 1 (four-wave / C = 256 strips) left with amp_version 142. */
 int amp_set_pair_strips(int on);
 
 /* Replaces HiFiGAN.forward (hifigan.py:203-219), BigVGAN.forward (bigvgan.py:313-331) and
@@ -429,12 +431,6 @@ int amp_wn_forward(const amp_conv* const* in_layers, const amp_conv* const* res_
                    const float* cond_dev, long long cond_batch_stride, const int32_t* lens_dev, int B, int T,
                    float* acts_ws_dev, float* out_dev, void* stream);
 
-/* 4 / 8 / 12: every layer of amp_wn_forward is ONE launch (csrc/wn_layer_f16x3.hip: gated conv -> acts in LDS -> res_skip conv ->
- * residual / skip update, that many waves per workgroup; x then ping-pongs between x_dev and acts_ws_dev, and which of the two holds
- * the final x is unspecified); 0 (default; also -1): two launches per layer.  Same bits in every mode; measured equal in time
- * (DESIGN.md 3.1b), so the default stays with the older path. */
-int amp_set_wn_layer_fusion(int mode);
-
 /* ---- VITS posterior encoder + flow (config 5): element-wise pieces between the convs ---- */
 
 /* fused_add_tanh_sigmoid_multiply (utils/util.py:602-609) as called by WN.forward
@@ -468,17 +464,6 @@ int amp_posterior_sample(const float* stats_dev, const float* eps_dev, const int
 int amp_antialias_snake(const float* x_dev, int B, int C, int T, const float* alpha_dev, const float* beta_dev,
                         int logscale, const float* filt_up_host, const float* filt_down_host, float* y_dev,
                         void* stream);
-
-/* a2(c1(xt)) of an AMPBlock (bigvgan.py:141-143) in one launch: y = Activation1d(conv(x) + bias), the conv's output tile
- * activated in LDS before it is stored (csrc/conv_f16x3.hip, ACT variant) -- bit-identical to amp_conv_forward followed by
- * amp_antialias_snake, one read and one write of the tensor less.  Covered: f16x3 arithmetic, Conv1d with 'same' zero
- * padding and a bias, k in {3, 5, 7, 11}, cout a multiple of 32, and a launch of at least 384 full-width tiles; anything
- * else returns AMP_ERR_UNSUPPORTED (run the two ops).  Parameters as in amp_antialias_snake (op-level convenience:
- * synchronises).  Measured slower than the two launches on MI355X, so amp_gen_forward uses it only after
- * amp_set_fuse_act(1) (A/B and cross-check switch; round 4's whole-AMPBlock kernel, amp_ampblock_forward, is the form that pays). */
-int amp_conv_act_forward(const amp_conv* c, const float* x_dev, int B, int T, const float* alpha_dev, const float* beta_dev,
-                         int logscale, const float* filt_up_host, const float* filt_down_host, float* y_dev, void* stream);
-int amp_set_fuse_act(int on);
 
 /* Mel / STFT front end descriptor: cfg.preprocess.{sample_rate,n_fft,win_size,hop_size,n_mel,fmin,fmax}. */
 typedef struct amp_mel_desc {

@@ -109,37 +109,6 @@ def act1d_forward(x, alpha, beta, logscale, fu, fd):
     return y.cpu()
 
 
-def conv_act_forward(w, b, x, alpha, beta, logscale, fu, fd, *, dilation=1, fused=True):
-    """y = Activation1d(conv(x) + bias) on cuda:0: ``amp_conv_act_forward`` (one launch) when ``fused``, else
-    ``amp_conv_forward`` followed by ``amp_antialias_snake`` (the two launches it replaces).  CPU tensors in and out."""
-    L = _lib.lib()
-    h = ctypes.c_void_p()
-    w = w.contiguous().float()
-    b = b.contiguous().float()
-    cout, cin, k = w.shape
-    _lib.check(L.amp_conv_create(0, cin, cout, k, 1, dilation, (k * dilation - dilation) // 2, ctypes.c_void_p(w.data_ptr()),
-                                 ctypes.c_void_p(b.data_ptr()), ctypes.byref(h)))
-    try:
-        xd = x.contiguous().float().cuda()
-        B, _, T = xd.shape
-        ad = alpha.contiguous().float().cuda()
-        bd = beta.contiguous().float().cuda() if beta is not None else None
-        fu, fd = fu.contiguous().float(), fd.contiguous().float()
-        y = torch.full((B, cout, T), float("nan"), device="cuda")
-        st = _lib.current_stream_ptr(xd.device)
-        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
-        if fused:
-            _lib.check(L.amp_conv_act_forward(h, p(xd), B, T, p(ad), p(bd), int(logscale), p(fu), p(fd), p(y), st))
-        else:
-            tmp = torch.full((B, cout, T), float("nan"), device="cuda")
-            _lib.check(L.amp_conv_forward(h, p(xd), B, T, 1.0, None, 1.0, p(tmp), st))
-            _lib.check(L.amp_antialias_snake(p(tmp), B, cout, T, p(ad), p(bd), int(logscale), p(fu), p(fd), p(y), st))
-        torch.cuda.synchronize()
-        return y.cpu()
-    finally:
-        L.amp_conv_destroy(h)
-
-
 def ampblock_forward(ws1, bs1, ws2, bs2, alphas, betas, logscale, fu, fd, x, *, dilations, fused=True, mode=0, div=1.0, y0=None):
     """AMPBlock1 (bigvgan.py:137-146) on cuda:0 from per-pair weights and per-activation parameters (``alphas`` / ``betas``
     [2 * n, C]; ``betas`` None -> Snake).  fused=True -> ``amp_ampblock_forward`` (ONE launch, csrc/ampb_f16x3.hip);

@@ -132,34 +132,3 @@ def test_bigvgan_bad_activation():
     hp = dict(vo.bigvgan_base_hp(), activation="gelu")
     with pytest.raises(NotImplementedError):
         BigVGAN(NS(preprocess=NS(n_mel=100), model=NS(bigvgan=NS(**hp))))
-
-
-def test_bigvgan_fused_activation_ragged_batch_is_bitwise_unfused():
-    """Generator level, ragged lengths: every utterance's own end goes through the fused epilogue's replicate padding
-    (lens * hop-so-far), and the forward equals the one with the fusion switched off."""
-    from amphion_amd import _lib
-    from amphion_amd.models.vocoders.gan.generator.bigvgan import BigVGAN
-
-    _lib.set_precision("f16x3")
-    hp = vo.bigvgan_base_hp()
-    cfg = NS(preprocess=NS(n_mel=100, hop_size=256), model=NS(bigvgan=NS(**hp)))
-    sd = synth.synth_state_dict(synth.bigvgan_param_shapes(100, hp), 1234, g_gain=0.75)
-    m = BigVGAN(cfg)
-    m.load_state_dict(sd)
-    m = m.cuda().eval()
-    gen = torch.Generator().manual_seed(3)
-    lens = torch.tensor([300, 211, 97, 300, 5, 160, 299, 64], dtype=torch.int32)
-    mel = torch.randn(8, 100, 300, generator=gen)
-    for i, l in enumerate(lens):
-        mel[i, :, l:] = 0
-    L = _lib.lib()
-    outs = []
-    try:
-        for on in (1, 0):
-            _lib.check(L.amp_set_fuse_act(on))
-            with torch.no_grad():
-                outs.append(m.forward_ragged(mel.cuda(), lens.cuda()).cpu())
-    finally:
-        _lib.check(L.amp_set_fuse_act(1))
-    for i, l in enumerate(lens):
-        assert torch.equal(outs[0][i, :, : l * 256], outs[1][i, :, : l * 256]), i

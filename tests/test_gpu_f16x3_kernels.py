@@ -1,6 +1,5 @@
 """GPU parity of the kernels that exist for the f16x3 arithmetic only (run once, under f16x3): the whole-K frame-rate conv
-kernel (csrc/conv_small_f16x3.hip) against the pipelined one bit for bit, and conv + Activation1d in one launch
-(csrc/conv_f16x3.hip, ACT variant) against the two launches bit for bit, and the row-blocked kernel of the transposed /
+kernel (csrc/conv_small_f16x3.hip) against the pipelined one bit for bit, and the row-blocked kernel of the transposed /
 k = 3 convs (csrc/conv_blk_f16x3.hip) against the pipelined one bit for bit."""
 import pytest
 import torch
@@ -211,38 +210,3 @@ def test_blocked_conv_switch_rejects_bad_mode():
     assert _lib.lib().amp_set_conv_blk(-1) == 0
 
 
-# ---- a2(c1(.)) of an AMPBlock in one launch (csrc/conv_f16x3.hip, ACT variant) ----------------------------------
-FUSED_ACT_CASES = [
-    # C, k, dilation, B, T     (launches of >= 384 full-width tiles; T chosen so that the last tile is ragged / exact /
-    #                           one sample long, rows 16-B aligned and not; the switch counts tiles of NT columns)
-    (128, 7, 3, 4, 12400),     # 128 x 128 tiles (WM = 4), 112 outputs per tile
-    (128, 11, 5, 4, 112 * 111 + 1),   # last tile holds ONE sample; 128-column staged halo
-    (256, 3, 1, 2, 112 * 111),        # two row groups; T an exact number of tiles
-    (64, 7, 1, 4, 24803),      # 64 x 256 tiles (2 x 2 waves), 240 outputs per tile, unaligned rows
-    (32, 11, 3, 4, 50000),     # 32 x 512 tiles (1 x 4 waves): a row spans two waves
-    (32, 3, 5, 8, 30000),
-]
-
-
-@pytest.mark.parametrize("C,k,d,B,T", FUSED_ACT_CASES)
-def test_conv_act_fused_is_bitwise_the_two_launches(C, k, d, B, T):
-    """The fused epilogue runs act1d_kernel's operation sequence on the conv's fp32 output tile: the result is the two
-    launches' bit for bit -- interior tiles, both utterance ends (replicate padding of the up-sampler's input and of the
-    Snake output), large Snake arguments (libm path) -- and within the activation's tolerance of the oracle."""
-    from hip_helpers import conv_act_forward
-
-    g = torch.Generator().manual_seed(C + k + T)
-    w = torch.randn(C, C, k, generator=g) * (C * k) ** -0.5
-    b = torch.randn(C, generator=g) * 0.1
-    x = torch.randn(B, C, T, generator=g) * 1.5
-    al = torch.randn(C, generator=g) * 0.3
-    be = torch.randn(C, generator=g) * 0.3
-    al[1] = 12.5                                            # exp(12.5) * |u| > 1e5: the libm sine path of that channel
-    f = vo.kaiser_sinc_filter1d(0.25, 0.3, 12)
-    y_f = conv_act_forward(w, b, x, al, be, True, f, f, dilation=d, fused=True)
-    y_u = conv_act_forward(w, b, x, al, be, True, f, f, dilation=d, fused=False)
-    assert torch.isfinite(y_f).all()
-    assert torch.equal(y_f, y_u)
-    keep = [c for c in range(C) if c != 1]
-    ref = vo.activation1d(torch.nn.functional.conv1d(x[:1], w, b, dilation=d, padding=(k * d - d) // 2), al, be, True)
-    assert (y_f[:1, keep] - ref[:, keep]).abs().max().item() <= 2e-5

@@ -90,6 +90,27 @@ def test_forward_is_deterministic_and_batch_independent():
     assert torch.equal(a, c)
 
 
+def test_batch_groups_bound_the_workspace_and_keep_the_bits():
+    """amp_set_group_mb(n): the batch walks the generator in depth-first groups of about n MB of stage tensors (a bound on the workspace; off by
+    default).  Items are independent, so any grouping gives the bits of the one-group forward -- here groups of 1-2 items of a batch of 5."""
+    from amphion_amd import _lib
+
+    hp = vo.hifigan_v1_hp()
+    m, _ = _hifigan(hp, 80, 1234)
+    mel = synth.synth_mel(5, 80, 40, seed=9).cuda()
+    L = _lib.lib()
+    with torch.no_grad():
+        whole = m(mel).clone()
+        try:
+            _lib.check(L.amp_set_group_mb(2))
+            grouped = m(mel).clone()
+        finally:
+            _lib.check(L.amp_set_group_mb(0))
+    assert torch.equal(whole, grouped)
+    with pytest.raises(_lib.AmpError):
+        _lib.check(L.amp_set_group_mb(-1))
+
+
 @pytest.mark.parametrize("gin", [0, 256])
 def test_hifigan_vits_golden(golden, gin):
     from amphion_amd.models.vocoders.gan.generator.hifigan import HiFiGAN_vits

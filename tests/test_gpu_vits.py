@@ -109,36 +109,3 @@ def test_wn_fused_vs_unfused_and_oracle(gin, n_layers, k, rate, conv_precision):
     assert (y_u.cpu() - ref).abs().max().item() <= TOL
     assert (y_f.cpu() - ref).abs().max().item() <= TOL
     assert (y_f - y_u).abs().max().item() <= 2e-5
-
-
-@pytest.mark.parametrize("H,gin,n_layers,k,rate", [(192, 0, 4, 5, 1), (192, 256, 16, 5, 1), (128, 0, 3, 3, 2), (256, 64, 2, 1, 1), (192, 0, 1, 5, 1), (96, 8, 2, 5, 3)])
-def test_wn_layer_kernel_bitwise(H, gin, n_layers, k, rate):
-    """The one-launch WN layer (wn_layer_f16x3.hip: gated conv -> acts in LDS -> res_skip conv -> residual / skip update; 4, 8 or 12 waves per
-    workgroup; off by default: same speed) == the two launches per layer it replaces, bit for bit -- ragged lengths (tiles beyond an end, a 1-frame item), with
-    and without the speaker condition, one layer (first == last), dilated layers."""
-    from collections import OrderedDict
-
-    from amphion_amd import _lib
-    from amphion_amd.modules.flow.modules import WN
-
-    B, T = 3, 83
-    wn = WN(H, k, rate, n_layers, gin_channels=gin)
-    sd_p = synth.synth_state_dict(synth.wn_param_shapes(OrderedDict(), "enc", H, k, n_layers, gin), 99, g_gain=0.5)
-    wn.load_state_dict({n[len("enc."):]: v for n, v in sd_p.items()})
-    wn = wn.cuda().eval()
-    gen = torch.Generator().manual_seed(5)
-    lens = torch.tensor([83, 40, 1])
-    x = torch.randn(B, H, T, generator=gen).cuda()          # NOT masked: the kernels take the lengths
-    g = torch.randn(B, gin, 1, generator=gen).cuda() if gin else None
-    L = _lib.lib()
-    outs = {}
-    try:
-        for mode in (0, 8, 4, 12):
-            _lib.check(L.amp_set_wn_layer_fusion(mode))
-            with torch.no_grad():
-                outs[mode] = wn(x, lens, g=g).clone()
-    finally:
-        _lib.check(L.amp_set_wn_layer_fusion(-1))
-    assert torch.isfinite(outs[0]).all()
-    assert torch.equal(outs[8], outs[0]) and torch.equal(outs[4], outs[0]) and torch.equal(outs[12], outs[0])
-    assert L.amp_set_wn_layer_fusion(3) < 0

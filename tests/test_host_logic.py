@@ -119,9 +119,15 @@ def test_round4_switches_validate_without_device():
     """amp_version 141; the concurrent-resblock and attention switches are plain host state with range checks; a handle-less
     amp_gen_prepare_streams is refused with a message instead of touching a device."""
     L = _lib.lib()
-    assert L.amp_version() >= 141
+    assert L.amp_version() >= 142
     for mode in (0, 1, -1):
         assert L.amp_set_resblock_streams(mode) == 0
+    assert L.amp_set_pair_strips(0) == 0 and L.amp_set_pair_strips(-1) == 0
+    with pytest.raises(_lib.AmpError) as ei:           # the four-wave strips left with ABI 142
+        _lib.check(L.amp_set_pair_strips(1))
+    assert "amp_set_pair_strips" in str(ei.value)
+    for gone in ("amp_conv_act_forward", "amp_set_fuse_act", "amp_set_wn_layer_fusion"):     # removed with their kernels
+        assert not hasattr(L, gone)
     with pytest.raises(_lib.AmpError) as ei:
         _lib.check(L.amp_set_resblock_streams(2))
     assert "amp_set_resblock_streams" in str(ei.value)

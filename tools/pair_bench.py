@@ -18,7 +18,7 @@ def main():
     ap.add_argument("--C", type=int, nargs="+", default=[256, 128, 64, 32])
     ap.add_argument("--k", type=int, nargs="+", default=[3, 7, 11])
     ap.add_argument("--d", type=int, nargs="+", default=[1, 5])
-    ap.add_argument("--modes", type=int, nargs="+", default=[1, 0], help="1 strips, 0 tiles")
+    ap.add_argument("--modes", type=int, nargs="+", default=[-1, 0], help="-1 the launch policy (A-ring strips where it picks them), 0 per-tile kernel")
     a = ap.parse_args()
     _lib.set_precision("f16x3")
     L = _lib.lib()
@@ -43,7 +43,7 @@ def main():
                     def go():
                         return L.amp_pair_forward(hs[0], hs[1], ctypes.c_void_p(x.data_ptr()), a.batch, T, 0.1, ctypes.c_void_p(y.data_ptr()), st)
                     if go() != 0:
-                        print(f"{C},{k},{d},{T},{'strip' if mode else 'tile'},unsupported,"); continue
+                        print(f"{C},{k},{d},{T},{'policy' if mode else 'tile'},unsupported,"); continue
                     torch.cuda.synchronize()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
@@ -51,7 +51,7 @@ def main():
                         go()
                     e1.record(); torch.cuda.synchronize()
                     ms = e0.elapsed_time(e1) / a.reps
-                    print(f"{C},{k},{d},{T},{'strip' if mode else 'tile'},{ms:.3f},{2 * 2.0 * C * C * k * a.batch * T / ms / 1e9:.1f}", flush=True)
+                    print(f"{C},{k},{d},{T},{'policy' if mode else 'tile'},{ms:.3f},{2 * 2.0 * C * C * k * a.batch * T / ms / 1e9:.1f}", flush=True)
                 for h in hs:
                     L.amp_conv_destroy(h)
         del x, y
