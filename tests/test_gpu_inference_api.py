@@ -231,3 +231,40 @@ def test_list_api_skips_dead_padding_without_changing_a_bit(arch):
         # the margin is not generous by accident: with 4 frames the kept samples DO change
         short = m.forward_ragged(batch.cuda(), [min(150, T + 4) for T in Ts]).squeeze(1).cpu()
         assert any(not torch.equal(short[i, : T * 256], full[i, : T * 256]) for i, T in enumerate(Ts) if T + 4 < 150)
+
+
+def test_launch_manifest_states_every_launch_of_a_forward(tmp_path):
+    """AMP_LAUNCH_MANIFEST=<file> (read once per process, so a child process): every launch of a forward appends
+    kernel<template arguments> \\t workgroups \\t algorithmic GFLOP \\t MB \\t what -- the names are the ones amp_gen_kernel_name reports, the conv
+    FLOPs of one HiFi-GAN V1 forward add up to SURVEY.md's 2 398 848 FLOP per output sample (conv_pre .. conv_post, weights aside)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    man = tmp_path / "manifest.tsv"
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "from types import SimpleNamespace as NS\n"
+        "from amphion_amd.models.vocoders.gan.generator.hifigan import HiFiGAN\n"
+        "from amphion_amd.utils.synthetic import randomize_, synthetic_mel\n"
+        "hp = dict(resblock='1', upsample_rates=[8, 8, 2, 2], upsample_kernel_sizes=[16, 16, 4, 4], upsample_initial_channel=512,\n"
+        "          resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5]] * 3)\n"
+        "m = randomize_(HiFiGAN(NS(preprocess=NS(n_mel=80, hop_size=256, sample_rate=22050), model=NS(hifigan=NS(**hp)))), 1234).cuda().eval()\n"
+        "mel = synthetic_mel(16, 80, 64, seed=0).cuda()\n"
+        "m.set_profiling(1)\n"
+        "with torch.no_grad(): m(mel)\n"
+        "torch.cuda.synchronize()\n"
+        "print('|'.join(sorted({n for i in range(4) for j in range(3) for n in m.kernel_names(100 + 16 * i + j, 0)})))\n" % root)
+    env = dict(os.environ, AMP_LAUNCH_MANIFEST=str(man))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    reported = set(r.stdout.strip().splitlines()[-1].split("|"))
+    rows = [l.rstrip("\n").split("\t") for l in open(man)]
+    assert rows and all(len(p) == 5 for p in rows)
+    names = {p[0] for p in rows}
+    assert reported <= names, (reported - names)                       # every resblock kernel the handle reports is in the manifest
+    gflop = sum(float(p[2]) for p in rows)
+    samples = 16 * 64 * 256
+    assert abs(gflop * 1e9 / samples - 2398848) <= 0.002 * 2398848, gflop * 1e9 / samples
+    assert all(int(p[1]) > 0 and float(p[3]) >= 0.0 for p in rows)
