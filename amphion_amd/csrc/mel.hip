@@ -759,6 +759,101 @@ __global__ __launch_bounds__(256) void istft_frames_kernel(const float* __restri
     for (int n = tid; n < n_fft; n += 256) fr[n] = in[n].x * sc * window[n];
 }
 
+// The same for any n_fft whose prime factors are <= 13 (round 5: the inverse of mel_mixed_kernel's transform): mixed-radix Stockham passes over
+// the Hermitian extension; an odd n_fft has no Nyquist bin (bins = (n_fft - 1) / 2 + 1, every k >= 1 has a partner n_fft - k).
+__global__ __launch_bounds__(256) void istft_frames_mixed_kernel(const float* __restrict__ mag, const float* __restrict__ phase,
+                                                                 int polar, int F, int n_fft, const MelRadices rad, float inv_scale,
+                                                                 const float* __restrict__ window, float* __restrict__ frames) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float2* buf0 = reinterpret_cast<float2*>(smem);   // [n_fft]
+    float2* buf1 = buf0 + n_fft;                      // [n_fft]
+    float2* tw = buf1 + n_fft;                        // [n_fft]
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / F;
+    const int f = blockIdx.x - b * F;
+    const int half = n_fft >> 1;
+    const int bins = half + 1;
+    const int nyq = (n_fft & 1) ? -1 : half;
+    for (int k = tid; k < bins; k += 256) {
+        const size_t o = ((size_t)b * bins + k) * F + f;
+        float re, im;
+        if (polar) {
+            const float m = mag[o];
+            float sn, cs;
+            sincosf(phase[o], &sn, &cs);
+            re = m * cs;
+            im = m * sn;
+        } else {
+            re = mag[o];
+            im = phase[o];
+        }
+        if (k == 0 || k == nyq) im = 0.f;
+        buf0[k] = make_float2(re, -im);
+        if (k > 0 && k != nyq) buf0[n_fft - k] = make_float2(re, im);
+    }
+    for (int n = tid; n < n_fft; n += 256) {
+        float sn, cs;
+        sincospif(-2.0f * (float)n / (float)n_fft, &sn, &cs);
+        tw[n] = make_float2(cs, sn);
+    }
+    __syncthreads();
+    float2* in = buf0;
+    float2* out = buf1;
+    int Ns = 1;
+    for (int s = 0; s < rad.n; ++s) {
+        const int r = rad.r[s];
+        switch (r) {
+            case 2: mixed_pass<2>(in, out, tw, n_fft, Ns, tid); break;
+            case 3: mixed_pass<3>(in, out, tw, n_fft, Ns, tid); break;
+            case 5: mixed_pass<5>(in, out, tw, n_fft, Ns, tid); break;
+            case 7: mixed_pass<7>(in, out, tw, n_fft, Ns, tid); break;
+            case 11: mixed_pass<11>(in, out, tw, n_fft, Ns, tid); break;
+            default: mixed_pass<13>(in, out, tw, n_fft, Ns, tid); break;
+        }
+        Ns *= r;
+        __syncthreads();
+        float2* t = in; in = out; out = t;
+    }
+    const float sc = inv_scale / (float)n_fft;
+    float* fr = frames + ((size_t)b * F + f) * n_fft;
+    for (int n = tid; n < n_fft; n += 256) fr[n] = in[n].x * sc * window[n];
+}
+
+// irfft(spectrum) * window * inv_scale / n_fft per frame: the radix-2 kernel for powers of two, the mixed-radix one otherwise
+static hipError_t launch_istft_frames(int n_fft, const float* a, const float* b, int polar, int B, int F, float inv_scale, const float* window,
+                                      float* frames, hipStream_t stream) {
+    if ((n_fft & (n_fft - 1)) == 0) {
+        int log2n = 0;
+        while ((1 << log2n) < n_fft) ++log2n;
+        const size_t lds = (size_t)(2 * n_fft + n_fft / 2) * sizeof(float2);
+        if (lds > 64 * 1024) {
+            static std::atomic<unsigned long long> done2{0};
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+            if (!((done2.load(std::memory_order_acquire) >> dev) & 1ull)) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&istft_frames_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                if (e != hipSuccess) return e;
+                done2.fetch_or(1ull << dev, std::memory_order_release);
+            }
+        }
+        hipLaunchKernelGGL(istft_frames_kernel, dim3((unsigned)((size_t)B * F)), dim3(256), lds, stream, a, b, polar, F, n_fft, log2n, inv_scale, window, frames);
+        return hipGetLastError();
+    }
+    MelRadices rad;
+    if (!mel_radices(n_fft, &rad)) return hipErrorInvalidValue;
+    const size_t lds = (size_t)(3 * n_fft) * sizeof(float2);
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!((done.load(std::memory_order_acquire) >> dev) & 1ull)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&istft_frames_mixed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+        if (e != hipSuccess) return e;
+        done.fetch_or(1ull << dev, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(istft_frames_mixed_kernel, dim3((unsigned)((size_t)B * F)), dim3(256), lds, stream, a, b, polar, F, n_fft, rad, inv_scale, window, frames);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict__ frames, const float* __restrict__ wss,
                                                         int F, int n_fft, int hop, int crop, int Lout, float scale,
                                                         float tiny, float* __restrict__ wav) {
@@ -782,16 +877,11 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
 // mode 1: APNet ISTFT "same" (apnet.py:46-101): re/im input, crop (win - hop)/2, out = sum / envelope, L = F * hop
 hipError_t launch_istft(const amp_mel_desc& d, int mode, const float* a, const float* b, int B, int F, const float* window,
                         const float* wss, float* frames, float* wav, hipStream_t stream) {
-    int log2n = 0;
-    while ((1 << log2n) < d.n_fft) ++log2n;
-    const size_t lds = (size_t)(2 * d.n_fft + d.n_fft / 2) * sizeof(float2);
     const float scale = mode == 0 ? (float)d.n_fft / (float)d.hop_size : 1.0f;
-    hipLaunchKernelGGL(istft_frames_kernel, dim3((unsigned)((size_t)B * F)), dim3(256), lds, stream, a, b, mode == 0 ? 1 : 0, F,
-                       d.n_fft, log2n, 1.0f / scale, window, frames);
-    hipError_t e = hipGetLastError();
+    hipError_t e = launch_istft_frames(d.n_fft, a, b, mode == 0 ? 1 : 0, B, F, 1.0f / scale, window, frames, stream);
     if (e != hipSuccess) return e;
     const int crop = mode == 0 ? d.n_fft / 2 : (d.win_size - d.hop_size) / 2;
-    const int Lout = mode == 0 ? d.hop_size * (F - 1) : d.hop_size * (F - 1) + d.win_size - 2 * crop;
+    const int Lout = mode == 0 ? d.hop_size * (F - 1) + (d.n_fft & 1) : d.hop_size * (F - 1) + d.win_size - 2 * crop;   // (odd n_fft: crop = floor(n_fft / 2) twice)
     if (Lout <= 0) return hipSuccess;
     hipLaunchKernelGGL(istft_ola_kernel, dim3((unsigned)((Lout + 255) / 256), (unsigned)B), dim3(256), 0, stream, frames, wss, F,
                        d.n_fft, d.hop_size, crop, Lout, scale, mode == 0 ? 1.17549435e-38f : -1.0f, wav);
@@ -816,9 +906,9 @@ hipError_t launch_istft(const amp_mel_desc& d, int mode, const float* a, const f
 __global__ __launch_bounds__(256) void mel_grad_spec_kernel(const float* __restrict__ g_lm, const float* __restrict__ mel,
                                                             const float* __restrict__ mag, const float* __restrict__ re,
                                                             const float* __restrict__ im, const float* __restrict__ melbasis,
-                                                            int F, int bins, int n_mel, float log_clip,
+                                                            int F, int bins, int nyq, int n_mel, float log_clip,
                                                             float* __restrict__ h_re, float* __restrict__ h_im) {
-    extern __shared__ float gm[];                 // [n_mel][32]  g_mel of this tile
+    extern __shared__ float gm[];                 // [n_mel][32]  g_mel of this tile  (nyq = n_fft / 2 for an even n_fft, -1 for an odd one)
     const int fblocks = (F + 31) / 32;
     const int b = blockIdx.x / fblocks;
     const int f0 = (blockIdx.x - b * fblocks) * 32;
@@ -841,7 +931,7 @@ __global__ __launch_bounds__(256) void mel_grad_spec_kernel(const float* __restr
         for (int m = 0; m < n_mel; ++m) acc = fmaf(melbasis[(size_t)m * bins + k], gm[m * 32 + fl], acc);
         const size_t o = ((size_t)b * bins + k) * F + f;
         const float mg = mag[o];
-        const float wk = (k == 0 || k == bins - 1) ? 1.f : 0.5f;
+        const float wk = (k == 0 || k == nyq) ? 1.f : 0.5f;
         const float s = mg > 0.f ? wk * acc / mg : 0.f;
         h_re[o] = s * re[o];
         h_im[o] = s * im[o];
@@ -890,16 +980,11 @@ hipError_t launch_mel_backward(const amp_mel_desc& d, const int* lens, int B, in
     const int pad = d.pad_mode == 0 ? (d.n_fft - d.hop_size) / 2 : d.n_fft / 2;
     const int fblocks = (F + 31) / 32;
     hipLaunchKernelGGL(mel_grad_spec_kernel, dim3((unsigned)((size_t)B * fblocks)), dim3(256), (size_t)d.n_mel * 32 * sizeof(float), stream,
-                       g_lm, mel_lin, mag, re, im, melbasis, F, bins, d.n_mel, d.log_clip, h_re, h_im);
+                       g_lm, mel_lin, mag, re, im, melbasis, F, bins, (d.n_fft & 1) ? -1 : d.n_fft / 2, d.n_mel, d.log_clip, h_re, h_im);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    int log2n = 0;
-    while ((1 << log2n) < d.n_fft) ++log2n;
-    const size_t lds = (size_t)(2 * d.n_fft + d.n_fft / 2) * sizeof(float2);
-    // frames = irfft(H) * window * inv_scale / n_fft * n_fft ... istft_frames_kernel multiplies by inv_scale / n_fft: we want x n_fft
-    hipLaunchKernelGGL(istft_frames_kernel, dim3((unsigned)((size_t)B * F)), dim3(256), lds, stream, h_re, h_im, 0, F, d.n_fft, log2n,
-                       (float)d.n_fft, window, frames);
-    e = hipGetLastError();
+    // frames = irfft(H) * window * inv_scale / n_fft * n_fft ... the frames kernel multiplies by inv_scale / n_fft: we want x n_fft
+    e = launch_istft_frames(d.n_fft, h_re, h_im, 0, B, F, (float)d.n_fft, window, frames, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(mel_grad_ola_kernel, dim3((unsigned)((L + 255) / 256), (unsigned)B), dim3(256), 0, stream, frames, lens, L, F,
                        d.n_fft, d.hop_size, pad, g_wav);
@@ -978,8 +1063,8 @@ int amp_istft_forward(const amp_mel_desc* d_in, const float* mag_dev, const floa
     if (!mel_desc_in(d_in, &dn, "amp_istft_forward")) return AMP_ERR_INVALID;
     const amp_mel_desc* d = &dn;
     if (!d || !mag_dev || !phase_dev || !window_dev || !wss_dev || !frames_ws_dev || !wav_dev) { set_error("amp_istft_forward: null argument"); return AMP_ERR_INVALID; }
-    if (d->n_fft < 64 || d->n_fft > 4096 || (d->n_fft & (d->n_fft - 1)) != 0) {
-        set_error("amp_istft_forward: n_fft=%d must be a power of two in [64, 4096]", d->n_fft);
+    if (d->n_fft < 64 || d->n_fft > 4096 || !mel_nfft_supported(d->n_fft)) {
+        set_error("amp_istft_forward: n_fft=%d must lie in [64, 4096] and have no prime factor above 13", d->n_fft);
         return AMP_ERR_UNSUPPORTED;
     }
     if (d->hop_size <= 0 || d->hop_size > d->n_fft || B <= 0 || F <= 1) { set_error("amp_istft_forward: hop=%d B=%d F=%d", d->hop_size, B, F); return AMP_ERR_INVALID; }
@@ -994,8 +1079,8 @@ int amp_istft_same(const amp_mel_desc* d_in, const float* re_dev, const float* i
     if (!mel_desc_in(d_in, &dn, "amp_istft_same")) return AMP_ERR_INVALID;
     const amp_mel_desc* d = &dn;
     if (!d || !re_dev || !im_dev || !window_dev || !envelope_dev || !frames_ws_dev || !wav_dev) { set_error("amp_istft_same: null argument"); return AMP_ERR_INVALID; }
-    if (d->n_fft < 64 || d->n_fft > 4096 || (d->n_fft & (d->n_fft - 1)) != 0 || d->win_size != d->n_fft) {
-        set_error("amp_istft_same: n_fft=%d must be a power of two in [64, 4096] and equal win_size=%d", d->n_fft, d->win_size);
+    if (d->n_fft < 64 || d->n_fft > 4096 || !mel_nfft_supported(d->n_fft) || d->win_size != d->n_fft) {
+        set_error("amp_istft_same: n_fft=%d must lie in [64, 4096], have no prime factor above 13 and equal win_size=%d", d->n_fft, d->win_size);
         return AMP_ERR_UNSUPPORTED;
     }
     if (d->hop_size <= 0 || d->hop_size > d->n_fft || ((d->win_size - d->hop_size) & 1) || B <= 0 || F <= 0) { set_error("amp_istft_same: hop=%d B=%d F=%d", d->hop_size, B, F); return AMP_ERR_INVALID; }
@@ -1013,8 +1098,8 @@ int amp_mel_backward(const amp_mel_desc* d_in, const int32_t* lens_dev, int B, i
     const amp_mel_desc* d = &dn;
     if (!d || !window_dev || !melbasis_dev || !mel_linear_dev || !mag_dev || !re_dev || !im_dev || !grad_logmel_dev || !spec_ws_dev ||
         !frames_ws_dev || !grad_wav_dev) { set_error("amp_mel_backward: null argument"); return AMP_ERR_INVALID; }
-    if (d->n_fft < 64 || d->n_fft > 4096 || (d->n_fft & (d->n_fft - 1)) != 0) {
-        set_error("amp_mel_backward: n_fft=%d must be a power of two in [64, 4096]", d->n_fft);
+    if (d->n_fft < 64 || d->n_fft > 4096 || !mel_nfft_supported(d->n_fft)) {
+        set_error("amp_mel_backward: n_fft=%d must lie in [64, 4096] and have no prime factor above 13", d->n_fft);
         return AMP_ERR_UNSUPPORTED;
     }
     if (d->hop_size <= 0 || d->n_mel <= 0 || B <= 0 || L <= 0) { set_error("amp_mel_backward: hop=%d n_mel=%d B=%d L=%d", d->hop_size, d->n_mel, B, L); return AMP_ERR_INVALID; }

@@ -86,7 +86,7 @@ class STFT(torch.nn.Module):
         return out["mag"], phase
 
     def inverse(self, magnitude, phase):
-        """stft.py:183-222: (magnitude, phase) [B, n_fft/2+1, F] -> waveform [B, 1, hop * (F - 1)]."""
+        """stft.py:183-222: (magnitude, phase) [B, n_fft/2+1, F] -> waveform [B, 1, hop * (F - 1)] (+ 1 sample for an odd filter_length)."""
         magnitude = _lib.require_device_tensor(magnitude, "magnitude")
         phase = _lib.require_device_tensor(phase, "phase")
         if magnitude.shape != phase.shape or magnitude.dim() != 3 or magnitude.shape[1] != self.filter_length // 2 + 1:
@@ -102,7 +102,8 @@ class STFT(torch.nn.Module):
         wss = self._wss[key]
         window = _mel._window(self._cfg, dev)
         frames = torch.empty((B, F, self.filter_length), device=dev)
-        out = torch.empty((B, 1, self.hop_length * (F - 1)), device=dev)
+        # the reference crops int(filter_length / 2) samples either side of n_fft + hop * (F - 1): one more sample survives for an odd length
+        out = torch.empty((B, 1, self.hop_length * (F - 1) + (self.filter_length & 1)), device=dev)
         d = _lib.amp_mel_desc(self.filter_length, self.win_length, self.hop_length, 0, 1, 0.0, 0.0)
         p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
         with torch.cuda.device(dev):

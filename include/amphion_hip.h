@@ -90,7 +90,8 @@ typedef struct amp_gen amp_gen;
  * amp_ampblock_forward, amp_set_ampblock_fusion; 141 (additive): amp_conv_forward_ragged, amp_layer_norm_c_ragged,
  * amp_dwconv_layer_norm_c, amp_rel_attention_strided, amp_set_rel_attention_tiled, amp_expand_path_strided; 142 (round 5) REMOVES
  * amp_conv_act_forward, amp_set_fuse_act and amp_set_wn_layer_fusion together with the kernels behind them (bit-identical forms the launch
- * policy never chose), refuses amp_set_pair_strips(1), and lets amp_mel_forward take any n_fft whose prime factors are <= 13. */
+ * policy never chose), refuses amp_set_pair_strips(1), and lets amp_mel_forward / amp_mel_backward / amp_istft_forward / amp_istft_same take
+ * any n_fft in [64, 4096] whose prime factors are <= 13 (mixed-radix kernels; powers of two keep theirs). */
 int amp_version(void);
 const char* amp_last_error(void);
 /* Number of HIP devices visible (0 when there is no GPU); never fails. */
@@ -531,8 +532,8 @@ int amp_mel_backward(const amp_mel_desc* d, const int32_t* lens_dev, int B, int 
                      float* grad_wav_dev, void* stream);
 
 /* Replaces STFT.inverse (utils/stft.py:183-222; used by STFT.forward and griffin_lim :78-95): magnitude and
- * phase [B, n_fft/2+1, F] -> waveform [B, hop*(F-1)] (overlap-add of the windowed inverse FFTs, divided by the
- * window-sum-square envelope where it exceeds float32 tiny, times n_fft/hop, n_fft/2 cropped per side).
+ * phase [B, n_fft/2+1, F] -> waveform [B, hop*(F-1) + (n_fft & 1)] (overlap-add of the windowed inverse FFTs, divided by the
+ * window-sum-square envelope where it exceeds float32 tiny, times n_fft/hop, floor(n_fft/2) cropped per side).
  * window_dev [n_fft]; wss_dev [n_fft + hop*(F-1)] = window_sumsquare (stft.py:19-75) as float32;
  * frames_ws_dev: scratch of B*F*n_fft floats. */
 int amp_istft_forward(const amp_mel_desc* d, const float* mag_dev, const float* phase_dev, int B, int F,

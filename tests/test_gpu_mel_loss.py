@@ -50,6 +50,25 @@ def test_mel_loss_value_and_gradient(B, L):
     assert (got - ref_grad).abs().mean().item() <= 2e-5 * scale
 
 
+@pytest.mark.parametrize("sr,n_fft,hop,n_mel", [(24000, 1920, 480, 100), (16000, 400, 160, 80), (16000, 1001, 143, 40)])
+def test_mel_gradient_any_smooth_nfft(sr, n_fft, hop, n_mel):
+    """The mel-loss gradient for transform lengths that are not powers of two (round 5; the odd one has no Nyquist bin, so every bin
+    above 0 counts twice in the one-sided sum)."""
+    from amphion_amd.utils.mel import extract_mel_features
+
+    pp = NS(sample_rate=sr, n_fft=n_fft, win_size=n_fft, hop_size=hop, n_mel=n_mel, fmin=0, fmax=None)
+    g = torch.Generator().manual_seed(n_fft)
+    y = (torch.rand(2, hop * 20, generator=g) * 2 - 1) * 0.7
+    y64 = y.double().clone().requires_grad_(True)
+    _mel64(y64, pp).sum().backward()
+    yd = y.cuda().requires_grad_(True)
+    extract_mel_features(yd, pp).sum().backward()
+    got, ref = yd.grad.cpu().double(), y64.grad
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= 2e-3 * scale
+    assert (got - ref).abs().mean().item() <= 2e-5 * scale
+
+
 def test_mel_gradient_of_a_plain_sum():
     """d sum(logmel) / d y against autograd, without the L1's sign pattern (smooth upstream gradient)."""
     from amphion_amd.utils.mel import extract_mel_features
