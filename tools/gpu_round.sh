@@ -34,7 +34,7 @@ for STEP in $STEPS; do
     prof)
       rm -f $REPO/$OUT/manifest.tsv     # the library's launch manifest of the same run (amp_internal.h), joined by tools/roofline_table.py
       ( cd /tmp && AMP_LAUNCH_MANIFEST=$REPO/$OUT/manifest.tsv timeout 600 $PROF --stats -d $REPO/$OUT/prof -o kt -- $PROFCMD > $REPO/$OUT/prof_bench.json 2> $REPO/$OUT/prof.err )
-      python tools/roofline_table.py $OUT --title "$PROFCMD" > $OUT/roofline_table.txt 2> $OUT/roofline_table.err ;;
+      ;;
     pmc)
       ( cd /tmp && timeout 600 $PROF --pmc FETCH_SIZE -d $REPO/$OUT/pmc_fetch -o pf -- $PMCCMD > /dev/null 2> $REPO/$OUT/pmc_fetch.err )
       ( cd /tmp && timeout 600 $PROF --pmc WRITE_SIZE -d $REPO/$OUT/pmc_write -o pw -- $PMCCMD > /dev/null 2> $REPO/$OUT/pmc_write.err ) ;;
@@ -60,6 +60,8 @@ for STEP in $STEPS; do
     *) echo "unknown step $STEP" ;;
   esac
 done
+# the per-kernel roofline table of this visit, AFTER every step (it joins the prof step's trace + manifest with the pmc step's counters)
+[ -f $OUT/prof/kt_kernel_trace.csv ] && python tools/roofline_table.py $OUT --title "${ROOFTITLE:-$PROFCMD}" > $OUT/roofline_table.txt 2> $OUT/roofline_table.err
 find $OUT -name "*.db" -delete 2>/dev/null
 find $OUT -name "*agent_info*" -delete 2>/dev/null
 find $OUT -path "*sq_*" -name "*kernel_trace.csv" -delete 2>/dev/null
