@@ -437,7 +437,7 @@ static bool small_conv_enabled() { return cfg().small_conv != 0; }
 
 // Row-blocked conv kernel (conv_blk_f16x3.hip: 64 rows per wave, 256 per workgroup) for the short tap loops -- the
 // transposed convs (2 taps per chunk) and k = 3 convs -- whose GEMM rows are a multiple of 256; same bits as
-// conv_f16x3.hip.  AMP_CONV_BLK / amp_set_conv_blk: 0 off, 1 one 16-channel chunk per staging round, 2 two chunks per
+// conv_f16x3.hip.  amp_set_conv_blk: 0 off, 1 one 16-channel chunk per staging round, 2 two chunks per
 // round where the kernel has that variant (transposed convs), 3 (default) = 2 + the A-fragment-ring form for k = 7 / 11.
 int conv_blk_nt_kt2(int, int);
 int conv_blk_nt_kt3(int, int);
@@ -1394,7 +1394,7 @@ static bool gen_streams_wanted(const amp_gen* g, int B, int T) {
 
 // Optional depth-first batch grouping: a group of items runs through the WHOLE generator before the
 // next one starts, with a working set (the scratch tensors of its largest stage) bounded by
-// AMP_GROUP_MB / amp_set_group_mb().  It bounds the workspace (168 MB instead of 2.7 GB at config 2) but
+// amp_set_group_mb().  It bounds the workspace (168 MB instead of 2.7 GB at config 2) but
 // is OFF by default (0 = whole batch per layer): sized to the 256 MiB Infinity Cache it was measured
 // SLOWER on MI355X (36.2 ms ungrouped vs 45.6 / 49.9 / 62.4 ms at 200 / 144 / 104 MB groups,
 // profiles/r1_exp_group.txt) -- the small grids under-fill 256 CUs and the cache brings no bandwidth win.

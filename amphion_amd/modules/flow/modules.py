@@ -31,7 +31,7 @@ class WN(nn.Module):
         self.n_layers = n_layers
         self.gin_channels = gin_channels
         self.p_dropout = p_dropout
-        # False (or AMP_WN_FUSED=0): always the four unfused launches per layer -- cross-check / A-B switch
+        # False: always the four unfused launches per layer -- cross-check / A-B switch (tests set it)
         self.fused = True         # two launches per layer (amp_wn_forward); tests set False for the four unfused ops
         self.in_layers = nn.ModuleList()
         self.res_skip_layers = nn.ModuleList()

@@ -59,3 +59,30 @@ def test_multi_gpu_diagnostics_on_a_one_rank_group():
         assert k in d, k
     assert d["per_rank_ms"] == [1.5] and d["compute_only_ms"] > 0 and d["gather_ms"] > 0 and d["gather_ms_pcm16"] > 0
     json.dumps(d)
+
+
+def test_bench_under_the_drivers_own_launcher_line():
+    """The driver starts N > 1 runs as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus N ...`; with the one GPU of these boxes the same line at N = 1 must come back with ONE well-formed JSON line (the head-of-line
+    summary, the contract's keys, the roofline object)."""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert list(d)[0] == "summary_ms" and d["summary_ms"]["c2_f16x3_ms"] > 0
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["vs_baseline"] is None and d["config"]["workload"].startswith("HiFi-GAN V1 22.05 kHz")
+    assert 0.0 < d["roofline"]["frac"] <= 1.0 and d["roofline"]["bound"] == "mfma"
