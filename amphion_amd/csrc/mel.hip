@@ -683,6 +683,16 @@ hipError_t launch_mel(const amp_mel_desc& d, const float* wav, const int* lens, 
     int log2n = 0;
     while ((1 << log2n) < d.n_fft) ++log2n;
     const size_t lds = (size_t)(2 * d.n_fft + d.n_fft / 2) * sizeof(float2) + (size_t)(d.n_fft / 2 + 1) * sizeof(float);
+    if (lds > 64 * 1024) {                 // n_fft = 4096: 90 KB (round 5: the launch used to fail for want of the attribute)
+        static std::atomic<unsigned long long> attr_done{0};      // per device
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        if (!((attr_done.load(std::memory_order_acquire) >> dev) & 1ull)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            if (e != hipSuccess) return e;
+            attr_done.fetch_or(1ull << dev, std::memory_order_release);
+        }
+    }
     dim3 grid((unsigned)((size_t)B * F));
     hipLaunchKernelGGL(mel_kernel, grid, dim3(256), lds, stream, wav, lens, L, F, d.n_fft, log2n, d.hop_size, pad,
                        n_mel, d.mag_eps, d.log_clip, window, melbasis, mel, mag, re, im, rng);

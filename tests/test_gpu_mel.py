@@ -166,6 +166,7 @@ def test_mel_small_nfft_and_window_shorter_than_fft():
 @pytest.mark.parametrize("sr,n_fft,win,hop,n_mel,L", [
     (24000, 1920, 1920, 480, 128, 480 * 21),      # egs/vocoder/vocos/emilia_singnet.json:15 (2^7 * 3 * 5)
     (44100, 2048, 2048, 512, 128, 512 * 9),       # power of two beyond the wave-per-frame kernel
+    (48000, 4096, 4096, 1024, 128, 1024 * 7),     # the largest length: 90 KB of LDS per frame (needs the dynamic-LDS attribute)
     (16000, 400, 400, 160, 80, 160 * 33),         # 2^4 * 5^2
     (22050, 1000, 800, 250, 64, 250 * 12),        # 2^3 * 5^3, window shorter than the transform
     (16000, 882, 882, 147, 40, 147 * 20),         # 2 * 3^2 * 7^2
@@ -228,7 +229,7 @@ def test_stft_inverse_golden(tag):
     assert np.abs(wav - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("nfft,hop,win", [(1920, 480, 1920), (400, 100, 400), (1000, 250, 800), (1001, 143, 1001)])
+@pytest.mark.parametrize("nfft,hop,win", [(1920, 480, 1920), (400, 100, 400), (1000, 250, 800), (1001, 143, 1001), (4096, 1024, 4096)])
 def test_stft_inverse_any_smooth_nfft(nfft, hop, win):
     """STFT.transform / STFT.inverse (utils/stft.py:152-222) for lengths that are not powers of two (round 5: mixed-radix kernels in both
     directions; an odd length has no Nyquist bin): against the oracle's restatement of the conv-basis formulation."""
