@@ -407,10 +407,31 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void ampb_f16x3_kernel(const AmpbA
 #pragma unroll
                 for (int t = 0; t < 4; ++t) acc[t] = xv[t] + bv;
                 if (last && a.mode != 0) {
-                    f32x16 yv[4];
-                    load_rows(a.y, opaque(qw), T, yv);
+                    // the running MRF sum, 16 columns (four float4) at a time with ALL FOUR loads issued before the first is consumed.
+                    // (Round 5: as `load_rows` into a temporary f32x16[4] hipcc -- at 250 registers -- fused every load with its add and
+                    // put s_waitcnt vmcnt(0) behind each: sixteen serial round trips per tile, 0.09-0.17 ms of the k = 7 / 11 launches with
+                    // every other phase knocked out.)  Columns beyond the row read as zero; same sums in the same order.
+                    const float* yrow = a.y + rowoff;
+                    const int qrun = opaque(qw);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[t] += yv[t];
+                    for (int t = 0; t < 4; ++t) {
+                        float4 f[4];
+                        bool inb[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int qg = qrun + 16 * t + 4 * i;
+                            inb[i] = qg >= 0 && qg < T;
+                            f[i] = *reinterpret_cast<const float4*>(yrow + (inb[i] ? qg : 0));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);      // nothing crosses: four loads in flight, then their uses
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            acc[t][4 * i + 0] += inb[i] ? f[i].x : 0.f;
+                            acc[t][4 * i + 1] += inb[i] ? f[i].y : 0.f;
+                            acc[t][4 * i + 2] += inb[i] ? f[i].z : 0.f;
+                            acc[t][4 * i + 3] += inb[i] ? f[i].w : 0.f;
+                        }
+                    }
                 }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) acc[t] *= sc;

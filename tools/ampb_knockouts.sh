@@ -1,7 +1,7 @@
 #!/bin/bash
 # Timing-only knock-out builds of ampb_f16x3.hip (-DAMP_AMPB_KO=<bits>: 1 no Activation1d, 2 no tile write, 4 no conv K loop, 8 no halo
 # exchange): libamphion_hip_ko<bits>.so = the regular objects + the three ampb units rebuilt with the flag.  Run HERE (no GPU needed), then
-# needs profiles/negative_kernels/r5_ampb_knockouts.patch applied.  On the box:  for k in 0 1 2 4 8 15; do AMP_LIB_PATH=$PWD/amphion_amd/lib/libamphion_hip_ko$k.so python tools/ampb_inforward.py --modes 1 --rounds 1; done
+# needs the -DAMP_AMPB_KO hooks (profiles/negative_kernels/r5_ampb_knockouts.patch shows them).  On the box:  for k in 0 1 2 4 8 15; do AMP_LIB_PATH=$PWD/amphion_amd/lib/libamphion_hip_ko$k.so python tools/ampb_inforward.py --modes 1 --rounds 1; done
 cd "$(dirname "$0")/.."
 python -m amphion_amd.build || exit 1
 B=amphion_amd/csrc/_build
