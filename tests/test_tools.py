@@ -61,6 +61,7 @@ def test_isa_mix_counts_instruction_classes(tmp_path):
          "\tv_mfma_f32_32x32x16_f16 v[0:15], v[16:19], v[20:23], 0\n\tds_read_b128 v[0:3], v4\n\tglobal_load_dword v0, v[1:2], off\n\ts_nop 1\n.Lfunc_end0:\n")
     p = tmp_path / "k.s"
     p.write_text(s)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_mix.py"), str(p)], capture_output=True, text=True)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_mix.py"), str(p), "--serial"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+    assert "ONE AT A TIME: 0 of 1" in r.stdout                         # the one load is never waited for with vmcnt(0)
     assert "'pk_f32': 1" in r.stdout and "'mfma': 1" in r.stdout and "'trans': 1" in r.stdout and "'lds': 1" in r.stdout and "'vmem': 1" in r.stdout

@@ -2,7 +2,9 @@
 """Instruction mix of the kernels in a gfx950 assembly file (hipcc --cuda-device-only -S): VALU / packed / transcendental / MFMA /
 LDS / VMEM counts per function (whole function, or the body of the longest loop with --loop) and the VALU issue slots they cost on
 this chip (v_pk_*_f32 = 2, v_sin / v_cos / v_exp / v_log / v_rcp / v_rsq / v_sqrt = 4, everything else 1: DESIGN 3.2e).
-    python tools/isa_mix.py file.s [--loop] [name-substring]"""
+    python tools/isa_mix.py file.s [--loop] [--serial] [name-substring]
+--serial also counts the loads that are followed by `s_waitcnt vmcnt(0)` before the next load is issued: one memory round trip each (how round 5
+found sixteen serial reads of the MFMA running sum in ampb_f16x3)."""
 import re, sys
 from collections import Counter
 
@@ -45,7 +47,18 @@ for m in re.finditer(r"^(\w+):\s*;\s*@\1\n(.*?)^\.Lfunc_end\d+:", txt, re.S | re
         elif op.startswith("s_waitcnt"): c["waitcnt"] += 1
         elif op.startswith("s_nop"): c["nop"] += 1
         elif op.startswith("s_"): c["salu"] += 1
+    serial = ""
+    if "--serial" in sys.argv:
+        n, last = 0, None
+        for i, l in enumerate(lines):
+            t = l.strip()
+            if t.startswith(("global_load", "buffer_load", "flat_load")):
+                last = i
+            elif t.startswith("s_waitcnt") and "vmcnt(0)" in t and last is not None:
+                n += 1
+                last = None
+        serial = f"  loads waited for ONE AT A TIME: {n} of {c['vmem']} VMEM instructions"
     slots = c["valu"] + c["accvgpr"] + 2 * c["pk_f32"] + 4 * c["trans"]
     import subprocess
     short = subprocess.run(["/usr/bin/c++filt", name], capture_output=True, text=True).stdout.strip()[:90]
-    print(f"{short}\n   {'loop body' if loop else 'function'}: {dict(c)}  VALU issue slots ~{slots}, MFMA pipe cycles (8-pass) ~{32 * c['mfma']}")
+    print(f"{short}\n   {'loop body' if loop else 'function'}: {dict(c)}  VALU issue slots ~{slots}, MFMA pipe cycles (8-pass) ~{32 * c['mfma']}{serial}")
