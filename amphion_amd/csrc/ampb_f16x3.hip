@@ -234,24 +234,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void ampb_f16x3_kernel(const AmpbA
     // not be; the running MRF sum: the row length (its columns only ever meet the same columns of the output)
     auto load_rows = [&](const float* base, const int qrun, const int lim, f32x16 (&dst)[4]) __attribute__((always_inline)) {
         const float* row = base + rowoff;
-        // all sixteen loads in flight before the first select (round 5: the compiler kept 4-5 in flight -- four round trips per tile that
-        // nothing hides in the one-workgroup-per-CU forms; at kernel entry the registers for sixteen float4 are free)
-        float4 f[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int qg = qrun + 4 * i;
             const bool inb = qg >= 0 && qg < T;                  // whole float4 inside the row or outside (T, q0 multiples of 4)
-            f[i] = *reinterpret_cast<const float4*>(row + (inb ? qg : 0));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int qg = qrun + 4 * i;
-            const bool inb = qg >= 0 && qg < T;
-            dst[AMP_PT(4 * i)][AMP_PR(4 * i) + 0] = (inb && qg + 0 < lim) ? f[i].x : 0.f;
-            dst[AMP_PT(4 * i)][AMP_PR(4 * i) + 1] = (inb && qg + 1 < lim) ? f[i].y : 0.f;
-            dst[AMP_PT(4 * i)][AMP_PR(4 * i) + 2] = (inb && qg + 2 < lim) ? f[i].z : 0.f;
-            dst[AMP_PT(4 * i)][AMP_PR(4 * i) + 3] = (inb && qg + 3 < lim) ? f[i].w : 0.f;
+            const float4 f = *reinterpret_cast<const float4*>(row + (inb ? qg : 0));
+            dst[AMP_PT(4 * i)][AMP_PR(4 * i) + 0] = (inb && qg + 0 < lim) ? f.x : 0.f;
+            dst[AMP_PT(4 * i)][AMP_PR(4 * i) + 1] = (inb && qg + 1 < lim) ? f.y : 0.f;
+            dst[AMP_PT(4 * i)][AMP_PR(4 * i) + 2] = (inb && qg + 2 < lim) ? f.z : 0.f;
+            dst[AMP_PT(4 * i)][AMP_PR(4 * i) + 3] = (inb && qg + 3 < lim) ? f.w : 0.f;
         }
     };
 
@@ -557,7 +548,7 @@ int AMP_CAT(ampb_tile_kt, AMP_KT)(int C, int max_dil, int wide) {
 
 hipError_t AMP_CAT(launch_ampb_kt, AMP_KT)(const AmpbArgs& a, int wide, hipStream_t stream) {
     constexpr int KT = AMP_KT;
-    constexpr int RING = KT >= 7 ? 4 : 0;
+    constexpr int RING = KT >= 7 ? 4 : (KT == 5 ? 3 : 0);   // (k = 5: a ring of three taps instead of five resident ones leaves every form without spills)
     if (a.C == 32) return wide ? launch_ampb_one<KT, 1, 8, RING, 32>(a, stream) : launch_ampb_one<KT, 1, 4, RING, 32>(a, stream);
     if (a.C == 64 && wide) return launch_ampb_one<KT, 2, 4, RING, 32>(a, stream);
     return hipErrorInvalidValue;
