@@ -322,6 +322,10 @@ typedef _Float16 amp_f16x2 __attribute__((ext_vector_type(2)));
 // per operand pair instead of 5 (v_cvt_pk_f16_f32, 2 x v_cvt_f32_f16, v_pk_add_f32, v_cvt_pk_f16_f32).  hipcc does not select
 // the mix form for a subtraction (it vectorises it); tests/experiments/split_mix.hip compares both forms on the hardware over
 // 2^25 operand pairs covering every sign / exponent / upper-mantissa pattern.
+// CAUTION (round 5, profiles/r5_b_fir_mfma.txt): send the results to LDS (as every caller does: the store interlocks), never straight into an
+// MFMA -- on gfx950 an MFMA that reads a VGPR needs two wait states after the VALU instruction that wrote it, hipcc inserts them only for
+// instructions it can see, and these are inline asm: fragments fed directly came out with a stale half in ~3 % of the waves.  An MFMA consumer
+// needs an `s_nop 1` at the end of the asm (profiles/negative_kernels/act1d_mfma.h: act_split4).
 __device__ __forceinline__ void split4_f16(amp_f32x2 v01, amp_f32x2 v23, uint2& h, uint2& l) {
     asm("" : "+v"(v01));      // opaque, as in split_f16: no folding of the producing multiply into ONE of the conversions
     asm("" : "+v"(v23));
