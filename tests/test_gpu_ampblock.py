@@ -99,6 +99,41 @@ def test_ampblock_bitwise_equals_the_launches_it_replaces(fusion, C, k, dils, B,
                              f"max |d| {(y - ref).abs().max().item():.3e}; columns {sorted(set(bad[:, 2].tolist()))[:24]}")
 
 
+_FUZZ_OFF = int(__import__("os").environ.get("AMP_FUZZ_OFFSET", "0"))      # other seeds for a soak run (tests/test_gpu_fuzz.py)
+
+
+@pytest.mark.parametrize("seed", range(_FUZZ_OFF, _FUZZ_OFF + 10))
+def test_ampblock_random_shapes_bitwise(fusion, seed):
+    """Seeded random (C, k, dilations, B, T, MRF mode, tile form): the one-launch block == the launches it replaces, bit for bit -- every tap count
+    the kernel is built for (k = 5 runs on a ring of three taps since round 5), every MRF mode (the running sum is read four float4 at a time), one
+    to three pairs, T from one quad to several tiles."""
+    import random
+
+    from hip_helpers import ampblock_forward
+
+    rng = random.Random(7000 + seed)
+    C = rng.choice([32, 32, 64])
+    k = rng.choice([3, 5, 7, 11])
+    n = rng.choice([1, 2, 3, 3])
+    dils = tuple(rng.choice([1, 2, 3, 5]) for _ in range(n))
+    if (k - 1) // 2 * max(dils) > 32:
+        dils = tuple(min(d, 3) for d in dils)
+    B = rng.choice([1, 2, 3, 7])
+    T = 4 * rng.choice([1, 2, 3, 9, 64, 117, 234, 235, 400, 999])
+    mode = rng.choice([2, 3]) if C == 32 else 2
+    mrf = rng.choice([0, 1, 2])
+    fusion(mode)
+    ws1, bs1, ws2, bs2, al, be = _params(C, k, n)
+    x = _rand(B, C, T, seed=seed, scale=1.5)
+    y0 = _rand(B, C, T, seed=seed + 1, scale=0.7) if mrf else None
+    f = vo.kaiser_sinc_filter1d(0.25, 0.3, 12)
+    kw = dict(dilations=dils, mode=mrf, div=3.0, y0=y0)
+    ref = ampblock_forward(ws1, bs1, ws2, bs2, al, be, True, f, f, x, fused=False, **kw)
+    y = ampblock_forward(ws1, bs1, ws2, bs2, al, be, True, f, f, x, fused=True, **kw)
+    assert torch.isfinite(y).all()
+    assert torch.equal(y, ref), f"C={C} k={k} dils={dils} B={B} T={T} tile mode {mode} MRF mode {mrf}: max |d| {(y - ref).abs().max().item():.3e}"
+
+
 @pytest.mark.parametrize("C,k,dils,B,T", [(32, 3, (1, 3, 5), 2, 2000), (32, 11, (1, 3, 5), 1, 1200), (64, 7, (1, 3, 5), 2, 700),
                                            (32, 7, (1, 3, 5), 1, 8)])
 def test_ampblock_vs_fp64_reference(fusion, C, k, dils, B, T):

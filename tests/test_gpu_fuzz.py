@@ -1,6 +1,7 @@
 """GPU parity, randomized: seeded random conv / transposed-conv / fused-pair shapes and random small generator
 architectures against the fp64 oracle ops.  Complements the hand-picked cases of test_gpu_conv / _pair /
 _generator (odd channel counts, ragged tiles, every tap count and both kernel families)."""
+import os
 import random
 from types import SimpleNamespace as NS
 
@@ -12,13 +13,15 @@ from oracle import synth
 from oracle import vocoder_oracle as vo
 
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("conv_precision")]
+# AMP_FUZZ_OFFSET=<n>: the same tests on other seeds (a soak run: `for o in 100 200 300; do AMP_FUZZ_OFFSET=$o pytest tests/test_gpu_fuzz.py; done`)
+_OFF = int(os.environ.get("AMP_FUZZ_OFFSET", "0"))
 
 
 def _rand(*shape, gen, scale=1.0):
     return torch.randn(*shape, generator=gen) * scale
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(_OFF, _OFF + 12))
 def test_random_conv1d(seed):
     from hip_helpers import conv_forward
 
@@ -49,7 +52,7 @@ def test_random_conv1d(seed):
     assert (y.double() - ref).abs().max().item() <= 2e-5, (cin, cout, k, d, B, T, pad)   # fp32 chains up to K = 2200
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(_OFF, _OFF + 8))
 def test_random_conv_transpose1d(seed):
     from hip_helpers import conv_forward
 
@@ -71,7 +74,7 @@ def test_random_conv_transpose1d(seed):
     assert (y.double() - ref).abs().max().item() <= 2e-5, (cin, cout, k, u, B, T)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(_OFF, _OFF + 6))
 def test_random_generator_architecture(seed):
     """Random small HiFi-GAN configs (rates, kernel sizes, resblock type, dilations) vs the fp64 oracle."""
     from amphion_amd.models.vocoders.gan.generator.hifigan import HiFiGAN
