@@ -191,6 +191,37 @@ def test_mel_any_smooth_nfft(sr, n_fft, win, hop, n_mel, L):
     assert (lin - lin_ref).abs().max().item() <= 2e-5 * max(1.0, lin_ref.abs().max().item())
 
 
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("AMP_FUZZ_OFFSET", "0")), int(__import__("os").environ.get("AMP_FUZZ_OFFSET", "0")) + 10))
+def test_mel_random_smooth_nfft(seed):
+    """Seeded random transform lengths built from the primes 2 .. 13 (every radix pass and their orders), random hop and window: the linear
+    spectrum against the oracle (torch.stft semantics)."""
+    import random
+
+    from types import SimpleNamespace as NS
+
+    from amphion_amd.utils import mel as M
+
+    rng = random.Random(9000 + seed)
+    while True:
+        n = 1
+        for p in (2, 3, 5, 7, 11, 13):
+            n *= p ** rng.choice([0, 0, 1, 1, 2, 3] if p == 2 else [0, 0, 1, 1, 2] if p <= 5 else [0, 0, 0, 1])
+        n *= rng.choice([1, 2, 4, 8])
+        if 64 <= n <= 4096:
+            break
+    hop = max(1, n // rng.choice([2, 3, 4, 5, 8]))
+    win = n if rng.random() < 0.7 else max(8, n - 2 * rng.randrange(1, n // 4))
+    pp = NS(sample_rate=16000, n_fft=n, win_size=win, hop_size=hop, n_mel=20, fmin=0, fmax=None)
+    g = torch.Generator().manual_seed(seed)
+    L = n + hop * rng.choice([3, 8, 17])
+    y = (torch.rand(2, L, generator=g) * 2 - 1) * 0.7
+    ref = vo.extract_linear_features(y[:1], pp)
+    out = M.extract_linear_features(y[:1].cuda(), pp).cpu()
+    assert out.shape == ref.shape, (n, hop, win)
+    err = (out - ref).abs().max().item()
+    assert err <= 3e-5 * max(1.0, ref.abs().max().item()), f"n_fft={n} hop={hop} win={win}: {err:.2e}"
+
+
 def test_mel_nfft_with_a_large_prime_factor_is_refused():
     from types import SimpleNamespace as NS
 
