@@ -408,6 +408,21 @@ static void strip_plan(int B, int T, int n1, int hb, int wg_per_cu, int* strip_l
     *strip_len = (T + best_spi - 1) / best_spi;
 }
 
+// The strips a launch gets: the planner's, or `steps` fixed steps per strip where the launch policy names them (steps = 1: the measured
+// choice of rounds 2-4 -- with long strips every CU walks its own 16-KB-spaced region in lockstep and a step takes 15 % longer, round 5
+// re-measured it: profiles/r5_j_pair_strip_stamps.txt table 5).  Round 5: FOUR steps per strip where the grid still fills the chip four
+// times over -- the k - 1 columns a strip computes and throws away and the pipeline fill are paid once per 1 014 outputs instead of
+// once per 246: -1 % per launch at B = 64, T = 16 384 (k = 11: 1.928 -> 1.892 ms), same bits (every output's operation order is that of
+// any other cut, tests/test_gpu_pair.py).  Ragged batches keep the one-step strips they were measured with.
+static void strip_geometry(int B, int T, int n1, int hb, int wg_per_cu, int steps, bool ragged, int* strip_len, int* spi) {
+    strip_plan(B, T, n1, hb, wg_per_cu, strip_len, spi);
+    if (steps > 0 && steps * n1 - hb < T) { *strip_len = steps * n1 - hb; *spi = (T + *strip_len - 1) / *strip_len; }
+    if (steps == 1 && !ragged && 4 * n1 - hb < T) {
+        const int len4 = 4 * n1 - hb, spi4 = (T + len4 - 1) / len4;
+        if ((long long)B * spi4 >= 1024) { *strip_len = len4; *spi = spi4; }
+    }
+}
+
 // Half-width conv tiles (NI = 2) for launches that would leave most CUs idle (a single utterance): conv_run()
 // picks them when the full-width grid has fewer workgroups than kSmallGridWorkgroups (the chip holds 2 per CU).
 // One 3-s utterance 1.56 -> 1.24 ms, one 10-s utterance 2.80 -> 2.38 ms; the frame-rate convs of VITS (short
@@ -751,9 +766,7 @@ static int pair_run(const amp_conv* c1, const amp_conv* c2, const float* x, int 
     const int n1 = sc.use ? strip_step(c1->k, c1->cin, c1->dilation, sc.wide, &wg) : 0;
     if (n1 > 0) {
         a.wide = sc.wide;
-        strip_plan(B, T, n1, c1->k - 1, wg, &a.strip_len, &a.strips_per_item);
-        const int steps = sc.steps;
-        if (steps > 0 && steps * n1 - (c1->k - 1) < T) { a.strip_len = steps * n1 - (c1->k - 1); a.strips_per_item = (T + a.strip_len - 1) / a.strip_len; }
+        strip_geometry(B, T, n1, c1->k - 1, wg, sc.steps, lens != nullptr, &a.strip_len, &a.strips_per_item);
         // one workgroup per CU: a grid that cannot fill the chip twice over (a single utterance) is better served by the
         // 4x as many independent tiles of the per-tile kernel (same bits)
         if (cfg().pair_strips == -1 && sc.wide >= 2 && (long long)B * a.strips_per_item < 512 && pair_tile(c1->k, c1->cin, c1->dilation) > 0) {
@@ -793,8 +806,7 @@ static bool pair_tile_args(const amp_conv* c1, const amp_conv* c2, const float* 
     const int n1 = sc.use ? strip_step(c1->k, c1->cin, c1->dilation, sc.wide, &wg) : 0;
     if (n1 > 0) {       // pair_run's rule: the strips unless the grid cannot fill the chip twice over
         int strip_len = 0, strips_per_item = 0;
-        strip_plan(B, T, n1, c1->k - 1, wg, &strip_len, &strips_per_item);
-        if (sc.steps > 0 && sc.steps * n1 - (c1->k - 1) < T) { strip_len = sc.steps * n1 - (c1->k - 1); strips_per_item = (T + strip_len - 1) / strip_len; }
+        strip_geometry(B, T, n1, c1->k - 1, wg, sc.steps, lens != nullptr, &strip_len, &strips_per_item);
         if (!(cfg().pair_strips == -1 && sc.wide >= 2 && (long long)B * strips_per_item < 512)) return false;
     }
     const int NT = pair_tile(c1->k, c1->cin, c1->dilation);

@@ -21,6 +21,13 @@
 // operations (bias, chunks, taps, the three MFMAs of a term) is that of the per-tile kernel and of
 // conv_f16x3.hip, so the result has the same bits however the time axis is cut (tests/test_gpu_pair.py).
 //
+// Round 5 (clock stamps of every wave, profiles/r5_j_pair_strip_stamps.txt): with one wave per SIMD nothing hides an LDS round trip, and
+// the B fragments of a half-tap were read 1-2 MFMAs before their first use -- the matrix pipe waited ~100 cycles 22 times per chunk.  They
+// are now read one half-tap (12 MFMAs) ahead into a second register set (BPIPE; 468 of 512 registers, no spill) and the next chunk's
+// staging loads go out behind the first half-tap instead of in front of it: the MFMA loops issue at the rate of a register-resident
+// MFMA loop (35.8 cycles per MFMA), a wave's life fell from 203.5 k to 190.1 k cycles -- and the launch by 1.8 %: the package sits at
+// its power cap and gave the rest back as clock (1 809 -> 1 746 MHz).  Same bits (only load timing moved).
+//
 // WM x WN waves x MI row blocks per wave: C = 32 * WM * MI channels (C = 256 runs 8 waves, one workgroup per CU: the xt tile
 // of all 256 channels is 108 KB); compiled once per tap count:  -DAMP_KT=<3|5|7|11>.
 #include "amp_internal.h"
@@ -43,6 +50,9 @@ union FragS {
 };
 
 #define AMP_PIN_VMEM() __builtin_amdgcn_sched_barrier(0x386)
+// LDS reads stay above, MFMAs below (VALU / SALU / VMEM / LDS writes may cross)
+#define AMP_PIN_DSREAD() __builtin_amdgcn_sched_barrier(0x276)
+
 
 // RING = D > 0 (round 2, third session; `wide` = 3): the A fragments as a ring of D taps per row block instead of a whole chunk's set
 // (conv_blk_f16x3.hip: tap g in slot g % D, re-loaded right after its use with tap g + D of this chunk or tap g % D of the next
@@ -65,6 +75,15 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
     constexpr int XBUF = 4 * SX;              // uint4 per x staging buffer [plane][octet][SX]
     constexpr int XTCH = 4 * XT;              // uint4 per xt chunk       [plane][octet][XT]
     constexpr int NST = (4 * SX) / NTHR;      // staging items (column x channel quad) per thread
+    // the tap's B fragments in BH halves (ring form with an even NI: 16 registers instead of 32); every accumulator still sees hh, hl, lh
+    // of the tap in this order
+    constexpr int BH = (RING > 0 && NI % 2 == 0) ? 2 : 1;
+    constexpr int NB = NI / BH;
+#ifdef AMP_PS_NO_BPIPE
+    constexpr bool BPIPE = false;
+#else
+    constexpr bool BPIPE = RING > 0 && BH == 2;
+#endif
     static_assert(SX % 64 == 0, "staging items must have a wave-uniform channel quad");
     static_assert((4 * SX) % NTHR == 0, "staging items must divide over the threads");
     static_assert(HB <= 32, "the carried columns must belong to the last n-tile");
@@ -237,19 +256,59 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
 #pragma unroll 1
         for (int c = 0; c < NCH; ++c) {
             const bool more = (c + 1) < NCH;
-            stage_load(more ? c + 1 : c, tbase);
-            AMP_PIN_VMEM();
             const uint4* wcur = wa1 + (size_t)c * (KT * 128);
             const uint4* wan = more ? wa1 + (size_t)(c + 1) * (KT * 128) : wa2;
             const uint4* base = smem4 + (SBUF == 2 ? (c & 1) : 0) * XBUF + rd1;
+            if constexpr (BPIPE) {
+                // the B fragments of half-tap h + 1 are read while the MFMAs of half-tap h run (two register sets); the staging loads of the
+                // next chunk are issued behind the first half-tap's MFMAs instead of in front of them (round 5: clock stamps showed the
+                // matrix pipe waiting ~100 cycles for LDS at every half-tap and ~700 for the address arithmetic at every chunk)
+                FragS bh[2][NB], bl[2][NB];
+#pragma unroll
+                for (int t = 0; t < NB; ++t) {
+                    bh[0][t].u = base[32 * t];
+                    bl[0][t].u = base[2 * SX + 32 * t];
+                }
+#pragma unroll
+                for (int h = 0; h < KT * BH; ++h) {
+                    const int g = h / BH, th = h % BH, cur = h & 1;
+                    const int v = g % NA;
+                    if (h + 1 < KT * BH) {
+                        const uint4* bn = base + ((h + 1) / BH) * dil;
+                        const int tn = (h + 1) % BH;
+#pragma unroll
+                        for (int t = 0; t < NB; ++t) {
+                            bh[cur ^ 1][t].u = bn[32 * (tn * NB + t)];
+                            bl[cur ^ 1][t].u = bn[2 * SX + 32 * (tn * NB + t)];
+                        }
+                    }
+                    AMP_PIN_DSREAD();
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+                        for (int t = 0; t < NB; ++t)
+                            acc[mi][th * NB + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[mi][v].h, bh[cur][t].h, acc[mi][th * NB + t], 0, 0, 0);
+#pragma unroll
+                        for (int t = 0; t < NB; ++t)
+                            acc[mi][th * NB + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[mi][v].h, bl[cur][t].h, acc[mi][th * NB + t], 0, 0, 0);
+#pragma unroll
+                        for (int t = 0; t < NB; ++t)
+                            acc[mi][th * NB + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l[mi][v].h, bh[cur][t].h, acc[mi][th * NB + t], 0, 0, 0);
+                        if (th == BH - 1) reload(mi, g, wcur, wan);
+                    }
+                    if (h == 0) {
+                        AMP_PIN_VMEM();
+                        stage_load(more ? c + 1 : c, tbase);
+                    }
+                    if (th == BH - 1 || h == 0) AMP_PIN_VMEM();
+                }
+            } else {
+            stage_load(more ? c + 1 : c, tbase);
+            AMP_PIN_VMEM();
 #pragma unroll
             for (int g = 0; g < KT; ++g) {
                 const int v = RING > 0 ? g % NA : g;
                 const uint4* bg = base + g * dil;
-                // the tap's B fragments in BH halves (ring form with an even NI: 16 registers instead of 32); every accumulator still
-                // sees hh, hl, lh of the tap in this order
-                constexpr int BH = (RING > 0 && NI % 2 == 0) ? 2 : 1;
-                constexpr int NB = NI / BH;
 #pragma unroll
                 for (int th = 0; th < BH; ++th) {
                     FragS bh[NB], bl[NB];
@@ -273,6 +332,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
                     }
                 }
                 AMP_PIN_VMEM();
+            }
             }
             if (SBUF == 1) __syncthreads();   // every wave has read the one staging buffer
             if (more) stage_store(SBUF == 2 ? (c + 1) & 1 : 0, tbase);
@@ -331,6 +391,55 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
         __syncthreads();
 
         // ---------------- conv2 over the xt tile ----------------
+        if constexpr (BPIPE) {
+            // as in conv1; there is no barrier between the chunks, so the last half-tap of a chunk reads the first of the next one
+            FragS bh[2][NB], bl[2][NB];
+            {
+                const uint4* b0 = xt4 + rd2;
+#pragma unroll
+                for (int t = 0; t < NB; ++t) {
+                    bh[0][t].u = b0[32 * t];
+                    bl[0][t].u = b0[2 * XT + 32 * t];
+                }
+            }
+#pragma unroll 1
+            for (int c = 0; c < NCH; ++c) {
+                const uint4* wcur = wa2 + (size_t)c * (KT * 128);
+                const uint4* wan = (c + 1) < NCH ? wa2 + (size_t)(c + 1) * (KT * 128) : wa1;
+                const uint4* base = xt4 + c * XTCH + rd2;
+                const uint4* basen = xt4 + ((c + 1) < NCH ? c + 1 : c) * XTCH + rd2;      // last chunk: a read nobody uses
+#pragma unroll
+                for (int h = 0; h < KT * BH; ++h) {
+                    const int g = h / BH, th = h % BH, cur = h & 1;
+                    const int v = g % NA;
+                    {
+                        const bool wrap = h + 1 == KT * BH;
+                        const uint4* bn = wrap ? basen : base + (h + 1) / BH;
+                        const int tn = wrap ? 0 : (h + 1) % BH;
+#pragma unroll
+                        for (int t = 0; t < NB; ++t) {
+                            bh[cur ^ 1][t].u = bn[32 * (tn * NB + t)];
+                            bl[cur ^ 1][t].u = bn[2 * XT + 32 * (tn * NB + t)];
+                        }
+                    }
+                    AMP_PIN_DSREAD();
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+                        for (int t = 0; t < NB; ++t)
+                            acc[mi][th * NB + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[mi][v].h, bh[cur][t].h, acc[mi][th * NB + t], 0, 0, 0);
+#pragma unroll
+                        for (int t = 0; t < NB; ++t)
+                            acc[mi][th * NB + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[mi][v].h, bl[cur][t].h, acc[mi][th * NB + t], 0, 0, 0);
+#pragma unroll
+                        for (int t = 0; t < NB; ++t)
+                            acc[mi][th * NB + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l[mi][v].h, bh[cur][t].h, acc[mi][th * NB + t], 0, 0, 0);
+                        if (th == BH - 1) reload(mi, g, wcur, wan);
+                    }
+                    if (th == BH - 1) AMP_PIN_VMEM();
+                }
+            }
+        } else {
 #pragma unroll 1
         for (int c = 0; c < NCH; ++c) {
             const uint4* wcur = wa2 + (size_t)c * (KT * 128);
@@ -340,8 +449,6 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
             for (int g = 0; g < KT; ++g) {
                 const int v = RING > 0 ? g % NA : g;
                 const uint4* bg = base + g;
-                constexpr int BH = (RING > 0 && NI % 2 == 0) ? 2 : 1;
-                constexpr int NB = NI / BH;
 #pragma unroll
                 for (int th = 0; th < BH; ++th) {
                     FragS bh[NB], bl[NB];
@@ -366,6 +473,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
                 }
                 AMP_PIN_VMEM();
             }
+        }
         }
 
         // ---------------- epilogue: + residual, MRF accumulate, store ----------------
@@ -411,6 +519,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
     }
     if (a.range_flag && __any(range_max > 65504.f) && lane == 0) atomicOr(a.range_flag, 1u);
 }
+
 
 template <int KT, int WM, int WN, int NI, int SX, int MI = 1, int RING = 0, int SBUF = 2>
 static hipError_t launch_strip_one(const PairArgs& a, hipStream_t stream) {

@@ -47,12 +47,15 @@ STRIP_CASES = [
 
 
 # launches of 512+ strips at C = 128, k in {7, 11}: the policy's A-ring strips (pair_strip_f16x3.hip, wide = 3: 64 x 128-column wave
-# tiles, one 256-column step per strip); smaller launches of the same shapes fall back to the per-tile kernel
+# tiles, one 256-column step per strip, four where 1 024+ such strips remain); smaller launches of the same shapes fall back to the per-tile kernel
 RING_CASES = [
     # C, k, dilation, B, T
     (128, 11, 5, 64, 2100),
     (128, 7, 3, 64, 4100),
     (128, 11, 1, 48, 6000),
+    # 1 024+ four-step strips (round 5: generator.hip strip_geometry): the headline's stage shape, and one whose last strip is a ragged tail
+    (128, 11, 3, 64, 16384),
+    (128, 7, 1, 70, 15000),
 ]
 
 

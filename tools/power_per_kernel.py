@@ -68,6 +68,7 @@ def conv_handles(C, k, dils, seed=1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=3.5)
+    ap.add_argument("--jobs", type=str, default="", help="comma-separated indices into the job list (default: all), e.g. 0,1 = the two fused-pair jobs")
     a = ap.parse_args()
     _lib.set_precision("f16x3")
     L = _lib.lib()
@@ -136,6 +137,8 @@ def main():
     jobs.append(lambda: ampb_job(32, 11, 65536))
     jobs.append(lambda: ampb_job(32, 3, 65536))
 
+    if a.jobs:
+        jobs = [jobs[int(i)] for i in a.jobs.split(",")]
     stamp = ""
     if os.path.exists(os.path.join(ROOT, ".commit_stamp")):
         stamp = " ".join(open(os.path.join(ROOT, ".commit_stamp")).read().split())
