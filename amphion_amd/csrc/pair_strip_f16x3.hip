@@ -23,7 +23,7 @@
 //
 // Round 5 (clock stamps of every wave, profiles/r5_j_pair_strip_stamps.txt): with one wave per SIMD nothing hides an LDS round trip, and
 // the B fragments of a half-tap were read 1-2 MFMAs before their first use -- the matrix pipe waited ~100 cycles 22 times per chunk.  They
-// are now read one half-tap (12 MFMAs) ahead into a second register set (BPIPE; 468 of 512 registers, no spill) and the next chunk's
+// are now read one half-tap (12 MFMAs) ahead into a second register set (468 of 512 registers, no spill) and the next chunk's
 // staging loads go out behind the first half-tap instead of in front of it: the MFMA loops issue at the rate of a register-resident
 // MFMA loop (35.8 cycles per MFMA), a wave's life fell from 203.5 k to 190.1 k cycles -- and the launch by 1.8 %: the package sits at
 // its power cap and gave the rest back as clock (1 809 -> 1 746 MHz).  Same bits (only load timing moved).
@@ -79,11 +79,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
     // of the tap in this order
     constexpr int BH = (RING > 0 && NI % 2 == 0) ? 2 : 1;
     constexpr int NB = NI / BH;
-#ifdef AMP_PS_NO_BPIPE
-    constexpr bool BPIPE = false;
-#else
-    constexpr bool BPIPE = RING > 0 && BH == 2;
-#endif
+    static_assert(RING > 0 && BH == 2, "the one form left: A-fragment ring, B fragments in two halves, read one half-tap ahead");
     static_assert(SX % 64 == 0, "staging items must have a wave-uniform channel quad");
     static_assert((4 * SX) % NTHR == 0, "staging items must divide over the threads");
     static_assert(HB <= 32, "the carried columns must belong to the last n-tile");
@@ -259,7 +255,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
             const uint4* wcur = wa1 + (size_t)c * (KT * 128);
             const uint4* wan = more ? wa1 + (size_t)(c + 1) * (KT * 128) : wa2;
             const uint4* base = smem4 + (SBUF == 2 ? (c & 1) : 0) * XBUF + rd1;
-            if constexpr (BPIPE) {
+            {
                 // the B fragments of half-tap h + 1 are read while the MFMAs of half-tap h run (two register sets); the staging loads of the
                 // next chunk are issued behind the first half-tap's MFMAs instead of in front of them (round 5: clock stamps showed the
                 // matrix pipe waiting ~100 cycles for LDS at every half-tap and ~700 for the address arithmetic at every chunk)
@@ -302,37 +298,6 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
                     }
                     if (th == BH - 1 || h == 0) AMP_PIN_VMEM();
                 }
-            } else {
-            stage_load(more ? c + 1 : c, tbase);
-            AMP_PIN_VMEM();
-#pragma unroll
-            for (int g = 0; g < KT; ++g) {
-                const int v = RING > 0 ? g % NA : g;
-                const uint4* bg = base + g * dil;
-#pragma unroll
-                for (int th = 0; th < BH; ++th) {
-                    FragS bh[NB], bl[NB];
-#pragma unroll
-                    for (int t = 0; t < NB; ++t) {
-                        bh[t].u = bg[32 * (th * NB + t)];
-                        bl[t].u = bg[2 * SX + 32 * (th * NB + t)];
-                    }
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-                        for (int t = 0; t < NB; ++t)
-                            acc[mi][th * NB + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[mi][v].h, bh[t].h, acc[mi][th * NB + t], 0, 0, 0);
-#pragma unroll
-                        for (int t = 0; t < NB; ++t)
-                            acc[mi][th * NB + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[mi][v].h, bl[t].h, acc[mi][th * NB + t], 0, 0, 0);
-#pragma unroll
-                        for (int t = 0; t < NB; ++t)
-                            acc[mi][th * NB + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l[mi][v].h, bh[t].h, acc[mi][th * NB + t], 0, 0, 0);
-                        if (th == BH - 1) reload(mi, g, wcur, wan);
-                    }
-                }
-                AMP_PIN_VMEM();
-            }
             }
             if (SBUF == 1) __syncthreads();   // every wave has read the one staging buffer
             if (more) stage_store(SBUF == 2 ? (c + 1) & 1 : 0, tbase);
@@ -391,7 +356,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
         __syncthreads();
 
         // ---------------- conv2 over the xt tile ----------------
-        if constexpr (BPIPE) {
+        {
             // as in conv1; there is no barrier between the chunks, so the last half-tap of a chunk reads the first of the next one
             FragS bh[2][NB], bl[2][NB];
             {
@@ -439,41 +404,6 @@ __global__ __launch_bounds__(64 * WM * WN, (MI > 1 ? 1 : 2)) void pair_strip_ker
                     if (th == BH - 1) AMP_PIN_VMEM();
                 }
             }
-        } else {
-#pragma unroll 1
-        for (int c = 0; c < NCH; ++c) {
-            const uint4* wcur = wa2 + (size_t)c * (KT * 128);
-            const uint4* wan = (c + 1) < NCH ? wa2 + (size_t)(c + 1) * (KT * 128) : wa1;
-            const uint4* base = xt4 + c * XTCH + rd2;
-#pragma unroll
-            for (int g = 0; g < KT; ++g) {
-                const int v = RING > 0 ? g % NA : g;
-                const uint4* bg = base + g;
-#pragma unroll
-                for (int th = 0; th < BH; ++th) {
-                    FragS bh[NB], bl[NB];
-#pragma unroll
-                    for (int t = 0; t < NB; ++t) {
-                        bh[t].u = bg[32 * (th * NB + t)];
-                        bl[t].u = bg[2 * XT + 32 * (th * NB + t)];
-                    }
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-                        for (int t = 0; t < NB; ++t)
-                            acc[mi][th * NB + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[mi][v].h, bh[t].h, acc[mi][th * NB + t], 0, 0, 0);
-#pragma unroll
-                        for (int t = 0; t < NB; ++t)
-                            acc[mi][th * NB + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[mi][v].h, bl[t].h, acc[mi][th * NB + t], 0, 0, 0);
-#pragma unroll
-                        for (int t = 0; t < NB; ++t)
-                            acc[mi][th * NB + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l[mi][v].h, bh[t].h, acc[mi][th * NB + t], 0, 0, 0);
-                        if (th == BH - 1) reload(mi, g, wcur, wan);
-                    }
-                }
-                AMP_PIN_VMEM();
-            }
-        }
         }
 
         // ---------------- epilogue: + residual, MRF accumulate, store ----------------
