@@ -865,13 +865,38 @@ static bool rb_supported(const std::vector<std::unique_ptr<amp_conv>>& c1, const
     return true;
 }
 
-static int rb_run(const std::vector<std::unique_ptr<amp_conv>>& c1, const std::vector<std::unique_ptr<amp_conv>>& c2, const float* x,
-                  int B, int T, float slope, float* y, int mode, float div, hipStream_t stream, const int* lens = nullptr, int len_mul = 1) {
+// Round 5: a resblock whose tile keeps less than 80 % of its columns (every conv is evaluated on all W columns and 2 * RH are discarded:
+// C = 64, k = 11 keeps 392 of 512) runs as TWO launches, pairs [0, 2) and [2, 3): 452 of 512 columns kept in each, 13 % fewer MFMAs for one
+// more trip of x through HBM.  Under the package power cap removed MFMAs convert to time in full: B = 64 3.45 -> 3.19 ms,
+// B = 32 1.68 -> 1.58, B = 16 0.89 -> 0.78; B = 8 (672 workgroups) 0.431 -> 0.443, hence the 1 024-workgroup floor; k = 7 (86 % kept) and
+// C = 32 k = 11 (88 %) are 1-4 % slower split (profiles/r5_l_rb_split.txt).  Same bits: what leaves a launch is the fp32 x the next pair
+// would have read from registers.  Returns the number of pairs in the first launch, 0 = one launch.
+static int rb_split(const std::vector<std::unique_ptr<amp_conv>>& c1, int B, int T) {
+    const int np = (int)c1.size();
+    if (np != 3 || rb_fusion_mode() != 1) return 0;
+    int max_dil = 1, rh = 0;
+    for (int p = 0; p < np; ++p) {
+        max_dil = c1[p]->dilation > max_dil ? c1[p]->dilation : max_dil;
+        rh += (c1[p]->k - 1) / 2 * (c1[p]->dilation + 1);
+    }
+    const int W = rb_tile(c1[0]->k, c1[0]->cin, max_dil, rb_form(c1[0]->cin, c1[0]->k));
+    const int NT = W - 2 * rh;
+    if (W <= 0 || 5 * NT >= 4 * W) return 0;
+    if ((long long)B * ((T + NT - 1) / NT) < 1024) return 0;
+    return 2;
+}
+
+// pairs [first, first + count) of the resblock (count < 0: all of them): x -> y
+static int rb_run(const std::vector<std::unique_ptr<amp_conv>>& c1v, const std::vector<std::unique_ptr<amp_conv>>& c2v, const float* x,
+                  int B, int T, float slope, float* y, int mode, float div, hipStream_t stream, const int* lens = nullptr, int len_mul = 1,
+                  int first = 0, int count = -1) {
     if (x == y) { set_error("rb_run: x and y must not alias"); return AMP_ERR_INVALID; }
     if (slope > 1.f) { set_error("rb_run: leaky_relu slope %g > 1 is outside the fused kernels", (double)slope); return AMP_ERR_UNSUPPORTED; }
     RbArgs a{};
     a.x = x; a.y = y;
-    a.np = (int)c1.size();
+    a.np = count < 0 ? (int)c1v.size() - first : count;
+    const std::unique_ptr<amp_conv>* c1 = c1v.data() + first;
+    const std::unique_ptr<amp_conv>* c2 = c2v.data() + first;
     int max_dil = 1;
     for (int p = 0; p < a.np; ++p) {
         a.wp1[p] = c1[p]->wp_dev; a.bias1[p] = c1[p]->bias_dev; a.wp2[p] = c2[p]->wp_dev; a.bias2[p] = c2[p]->bias_dev;
@@ -1704,9 +1729,11 @@ static int gen_forward_group(amp_gen* g, const float* mel_dev, const float* cond
             const int mode_last = (nk == 1 || sum_stage) ? 0 : (j == 0 ? 0 : (j == nk - 1 ? 2 : 1));
             const float* cur = U;
             if (d.resblock_type == 1 && !big && rb_supported(rb.c1, rb.c2, B, t)) {
-                // the whole resblock in one launch: U -> XSJ (x and the residual never leave the CU in between)
+                // the whole resblock in one launch: U -> XSJ (x and the residual never leave the CU in between) -- or in two, rb_split()
+                const int sp = rb_split(rb.c1, B, t);
+                if (sp > 0) AMP_RC(rb_run(rb.c1, rb.c2, U, B, t, slope, R_, 0, 1.f, sj, lens, lm, 0, sp));
                 AMP_RC(before_last());
-                AMP_RC(rb_run(rb.c1, rb.c2, U, B, t, slope, XSJ, mode_last, (float)nk, sj, lens, lm));
+                AMP_RC(rb_run(rb.c1, rb.c2, sp > 0 ? R_ : U, B, t, slope, XSJ, mode_last, (float)nk, sj, lens, lm, sp, -1));
                 return AMP_OK;
             }
             if (d.resblock_type == 1 && big && nd <= AMP_AMPB_MAX_STEPS / 2) {
