@@ -97,6 +97,34 @@ def test_policy_kernel_equals_tile_kernel_bitwise(C, k, d, B, T, strips):
     assert torch.equal(y_pol, y_tile)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_four_step_strips_random_shapes_bitwise(seed, strips):
+    """Seeded random launches large enough for the four-step strips (B x ceil(T / (4 * 256 - (k - 1))) >= 1 024; AMP_FUZZ_OFFSET moves the
+    seeds): the policy's result == the per-tile kernel's, bit for bit, including strips that end in a ragged tail and T that is no
+    multiple of anything."""
+    import os
+    import random
+    from amphion_amd import _lib
+    from hip_helpers import pair_forward
+
+    rng = random.Random(4242 + seed + int(os.environ.get("AMP_FUZZ_OFFSET", "0")))
+    k = rng.choice([7, 11])
+    d = rng.choice([1, 3, 5])
+    len4 = 4 * 256 - (k - 1)
+    spi = rng.randint(9, 20)
+    T = (spi - 1) * len4 + rng.randint(1, len4)
+    B = (1024 + spi - 1) // spi + rng.randint(0, 6)
+    assert B * ((T + len4 - 1) // len4) >= 1024
+    _lib.set_precision("f16x3")
+    w1, b1, w2, b2, x = _pair_inputs(128, k, B, T)
+    strips(False)
+    y_tile = pair_forward(w1, b1, w2, b2, x, dilation=d)
+    _lib.check(_lib.lib().amp_set_pair_strips(-1))
+    y_pol = pair_forward(w1, b1, w2, b2, x, dilation=d)
+    assert not torch.isnan(y_pol).any()
+    assert torch.equal(y_pol, y_tile), (k, d, B, T)
+
+
 @pytest.mark.parametrize("C,k,d,B,T", STRIP_CASES + RING_CASES)
 def test_strip_partition_invariance_and_oracle(C, k, d, B, T, strips):
     """The launch plan depends on (B, T): a batch that fills the chip walks the A-ring strips (C = 128, k >= 7), a single item the per-tile
