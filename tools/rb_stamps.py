@@ -64,5 +64,11 @@ for C, k, T, waves, ni in ((64, 11, 32768, 8, 4), (64, 7, 32768, 8, 4), (32, 11,
               f"{mf * 32} nominal, {mf * 35.8:.0f} at the microbenchmark's issue rate; two waves share a SIMD at C = 64 / 128, four at the 2-per-CU forms);\n"
               f"   barriers {bar:.0f} ({bar / life:.0%}), seams + residual fma {seam:.0f} ({seam / life:.0%}), re-staging x + barrier {restage:.0f} ({restage / life:.0%}), "
               f"epilogue {d(last_c2, 28):.0f} + stores leaving {d(28, 29):.0f} ({d(last_c2, 29) / life:.0%})", flush=True)
+        # which waves are late?  K-loop duration of pair 0's c1 per wave index (wave = wm * WN + wn), and the spread inside a workgroup
+        k0 = (S[:, :, 4] - S[:, :, 3]).astype(np.float64)
+        arrive = (S[:, :, 4] - S[:, :, 4].min(axis=1, keepdims=True)).astype(np.float64)
+        print("   c1 of pair 0, per wave index: K-loop cycles " + " ".join(f"{np.median(k0[:, w]):.0f}" for w in range(waves))
+              + f"; arrival at the barrier after the first wave: " + " ".join(f"{np.median(arrive[:, w]):.0f}" for w in range(waves))
+              + f"; last - first arrival, median over workgroups {np.median(arrive.max(axis=1)):.0f}", flush=True)
     for h in h1 + h2:
         L.amp_conv_destroy(h)
