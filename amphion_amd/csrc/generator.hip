@@ -1138,7 +1138,7 @@ extern "C" {
 // 141 (additive): the ragged / fused entry points of the VITS text side (amp_conv_forward_ragged, amp_layer_norm_c_ragged, amp_dwconv_layer_norm_c,
 // amp_rel_attention_strided, amp_set_rel_attention_tiled, amp_expand_path_strided); 142 (round 5, REMOVALS): amp_conv_act_forward, amp_set_fuse_act,
 // amp_set_wn_layer_fusion are gone with the kernels behind them (never chosen by the launch policy), amp_set_pair_strips(1) is refused; amp_mel_forward
-// accepts every n_fft without a prime factor above 13
+// accepts every n_fft in [64, 4096]
 int amp_version(void) { return 142; }
 const char* amp_last_error(void) { return g_err; }
 

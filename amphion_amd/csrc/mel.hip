@@ -125,7 +125,8 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ wav,
 // n_fft = 1920 = 2^7 * 3 * 5 (egs/vocoder/vocos/emilia_singnet.json:15).  Mixed-radix Stockham autosort FFT in LDS, one workgroup per
 // frame, complex n_fft-point transform: pass with radix r over Ns (the product of the radices done),
 //     j in [0, N / r):  k = j mod Ns;  v_q = in[j + q N / r] * W_N^{q k N / (Ns r)};  u_p = sum_q v_q W_r^{p q};  out[(j - k) r + k + p Ns] = u_p
-// with the whole unit circle W_N^m in LDS (one sincospif per entry and frame), radices = the prime factors of n_fft (<= 13), twos last.
+// with the whole unit circle W_N^m in LDS (one sincospif per entry and frame), radices = the prime factors of n_fft, twos last (compile-time
+// butterflies for 2 .. 13, generic_pass below for larger primes).
 // Window, reflect padding, |X|, mel projection, log: mel_kernel's.  A fallback, not a fast path: the frame-rate front end is 0.15 % of a
 // vocoder step, and every config the reference trains with is 1 024 (mel1024_kernel).
 // ------------------------------------------------------------------------------------------------
@@ -160,6 +161,32 @@ __device__ __forceinline__ void mixed_pass(const float2* __restrict__ in, float2
             }
             out[j0 + pq * Ns] = u;
         }
+    }
+}
+
+// The same pass for a radix known only at run time (prime factors above 13; round 5): one OUTPUT per thread and step -- output p of butterfly j is
+// sum_q in[j + q M] W_N^{q k tstep + (p q mod R) rstep} -- R complex MACs each, N R per pass (a prime n_fft is one pass of N^2: a direct DFT).  Slow and
+// simple: it exists so that no n_fft in [64, 4096] is refused, as torch.stft refuses none.
+__device__ __forceinline__ void generic_pass(const float2* __restrict__ in, float2* __restrict__ out, const float2* __restrict__ tw, int N, int Ns, int R, int tid) {
+    const int M = N / R;
+    const int tstep = N / (Ns * R);
+    const int rstep = N / R;
+    for (int o = tid; o < N; o += 256) {
+        const int pq = o / M, j = o - pq * M;       // consecutive threads: consecutive butterflies
+        const int k = j % Ns;
+        const int kt = k * tstep;                    // q * kt < N for every q < R
+        float2 u = make_float2(0.f, 0.f);
+        int pm = 0;                                  // (pq * q) mod R, incrementally
+        for (int q = 0; q < R; ++q) {
+            int m = q * kt + pm * rstep;             // < 2 N
+            m = m >= N ? m - N : m;
+            const float2 x = in[j + q * M];
+            const float2 w = tw[m];
+            u.x += x.x * w.x - x.y * w.y;
+            u.y += x.x * w.y + x.y * w.x;
+            pm += pq; pm = pm >= R ? pm - R : pm;
+        }
+        out[(j - k) * R + k + pq * Ns] = u;
     }
 }
 
@@ -207,7 +234,8 @@ __global__ __launch_bounds__(256) void mel_mixed_kernel(const float* __restrict_
             case 5: mixed_pass<5>(in, out, tw, n_fft, Ns, tid); break;
             case 7: mixed_pass<7>(in, out, tw, n_fft, Ns, tid); break;
             case 11: mixed_pass<11>(in, out, tw, n_fft, Ns, tid); break;
-            default: mixed_pass<13>(in, out, tw, n_fft, Ns, tid); break;
+            case 13: mixed_pass<13>(in, out, tw, n_fft, Ns, tid); break;
+            default: generic_pass(in, out, tw, n_fft, Ns, r, tid); break;
         }
         Ns *= r;
         __syncthreads();
@@ -239,9 +267,21 @@ __global__ __launch_bounds__(256) void mel_mixed_kernel(const float* __restrict_
     }
 }
 
-// prime factors of n (each <= 13), the twos last; false when n has a larger prime factor
+// prime factors of n: those above 13 first (run-time radix passes), then 13 .. 3, the twos last
 static bool mel_radices(int n, MelRadices* out) {
     out->n = 0;
+    if (n < 1) return false;
+    int small = n;                              // strip the small primes to find what is left
+    for (int p : {2, 3, 5, 7, 11, 13}) while (small % p == 0) small /= p;
+    for (int p = 17; small > 1; p += 2) {
+        if ((long long)p * p > small) p = small;             // what is left is prime
+        while (small % p == 0) {
+            if (out->n >= 16) return false;
+            out->r[out->n++] = p;
+            small /= p;
+            n /= p;
+        }
+    }
     const int primes[6] = {13, 11, 7, 5, 3, 2};
     for (int p : primes)
         while (n % p == 0) {
@@ -660,7 +700,7 @@ hipError_t launch_mel(const amp_mel_desc& d, const float* wav, const int* lens, 
         return e;
     }
     if ((d.n_fft & (d.n_fft - 1)) != 0) {
-        // any other length with prime factors <= 13: mixed-radix Stockham, one workgroup per frame
+        // any other length: mixed-radix Stockham, one workgroup per frame
         MelRadices rad;
         if (!mel_radices(d.n_fft, &rad)) return hipErrorInvalidValue;
         const size_t lds = (size_t)(3 * d.n_fft) * sizeof(float2) + (size_t)(d.n_fft / 2 + 1) * sizeof(float);
@@ -769,7 +809,7 @@ __global__ __launch_bounds__(256) void istft_frames_kernel(const float* __restri
     for (int n = tid; n < n_fft; n += 256) fr[n] = in[n].x * sc * window[n];
 }
 
-// The same for any n_fft whose prime factors are <= 13 (round 5: the inverse of mel_mixed_kernel's transform): mixed-radix Stockham passes over
+// The same for any other n_fft (round 5: the inverse of mel_mixed_kernel's transform): mixed-radix Stockham passes over
 // the Hermitian extension; an odd n_fft has no Nyquist bin (bins = (n_fft - 1) / 2 + 1, every k >= 1 has a partner n_fft - k).
 __global__ __launch_bounds__(256) void istft_frames_mixed_kernel(const float* __restrict__ mag, const float* __restrict__ phase,
                                                                  int polar, int F, int n_fft, const MelRadices rad, float inv_scale,
@@ -818,7 +858,8 @@ __global__ __launch_bounds__(256) void istft_frames_mixed_kernel(const float* __
             case 5: mixed_pass<5>(in, out, tw, n_fft, Ns, tid); break;
             case 7: mixed_pass<7>(in, out, tw, n_fft, Ns, tid); break;
             case 11: mixed_pass<11>(in, out, tw, n_fft, Ns, tid); break;
-            default: mixed_pass<13>(in, out, tw, n_fft, Ns, tid); break;
+            case 13: mixed_pass<13>(in, out, tw, n_fft, Ns, tid); break;
+            default: generic_pass(in, out, tw, n_fft, Ns, r, tid); break;
         }
         Ns *= r;
         __syncthreads();
@@ -1051,8 +1092,7 @@ int amp_mel_forward_ragged(const amp_mel_desc* d_in, const float* wav_dev, const
     const amp_mel_desc* d = &dn;
     if (!d || !wav_dev || !window_dev) { set_error("amp_mel_forward: null argument"); return AMP_ERR_INVALID; }
     if (d->n_fft < 64 || d->n_fft > 4096 || !mel_nfft_supported(d->n_fft)) {
-        set_error("amp_mel_forward: n_fft=%d must lie in [64, 4096] and have no prime factor above 13 (torch.stft semantics for every 2-3-5-7-11-13-smooth length; "
-                  "a length with a larger prime factor needs a chirp-z transform, not built)", d->n_fft);
+        set_error("amp_mel_forward: n_fft=%d must lie in [64, 4096] (torch.stft semantics for every length in that range)", d->n_fft);
         return AMP_ERR_UNSUPPORTED;
     }
     if (d->hop_size <= 0 || B <= 0 || L <= 0) { set_error("amp_mel_forward: hop=%d B=%d L=%d", d->hop_size, B, L); return AMP_ERR_INVALID; }
@@ -1074,7 +1114,7 @@ int amp_istft_forward(const amp_mel_desc* d_in, const float* mag_dev, const floa
     const amp_mel_desc* d = &dn;
     if (!d || !mag_dev || !phase_dev || !window_dev || !wss_dev || !frames_ws_dev || !wav_dev) { set_error("amp_istft_forward: null argument"); return AMP_ERR_INVALID; }
     if (d->n_fft < 64 || d->n_fft > 4096 || !mel_nfft_supported(d->n_fft)) {
-        set_error("amp_istft_forward: n_fft=%d must lie in [64, 4096] and have no prime factor above 13", d->n_fft);
+        set_error("amp_istft_forward: n_fft=%d must lie in [64, 4096]", d->n_fft);
         return AMP_ERR_UNSUPPORTED;
     }
     if (d->hop_size <= 0 || d->hop_size > d->n_fft || B <= 0 || F <= 1) { set_error("amp_istft_forward: hop=%d B=%d F=%d", d->hop_size, B, F); return AMP_ERR_INVALID; }
@@ -1090,7 +1130,7 @@ int amp_istft_same(const amp_mel_desc* d_in, const float* re_dev, const float* i
     const amp_mel_desc* d = &dn;
     if (!d || !re_dev || !im_dev || !window_dev || !envelope_dev || !frames_ws_dev || !wav_dev) { set_error("amp_istft_same: null argument"); return AMP_ERR_INVALID; }
     if (d->n_fft < 64 || d->n_fft > 4096 || !mel_nfft_supported(d->n_fft) || d->win_size != d->n_fft) {
-        set_error("amp_istft_same: n_fft=%d must lie in [64, 4096], have no prime factor above 13 and equal win_size=%d", d->n_fft, d->win_size);
+        set_error("amp_istft_same: n_fft=%d must lie in [64, 4096] and equal win_size=%d", d->n_fft, d->win_size);
         return AMP_ERR_UNSUPPORTED;
     }
     if (d->hop_size <= 0 || d->hop_size > d->n_fft || ((d->win_size - d->hop_size) & 1) || B <= 0 || F <= 0) { set_error("amp_istft_same: hop=%d B=%d F=%d", d->hop_size, B, F); return AMP_ERR_INVALID; }

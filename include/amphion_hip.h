@@ -91,7 +91,8 @@ typedef struct amp_gen amp_gen;
  * amp_dwconv_layer_norm_c, amp_rel_attention_strided, amp_set_rel_attention_tiled, amp_expand_path_strided; 142 (round 5) REMOVES
  * amp_conv_act_forward, amp_set_fuse_act and amp_set_wn_layer_fusion together with the kernels behind them (bit-identical forms the launch
  * policy never chose), refuses amp_set_pair_strips(1), and lets amp_mel_forward / amp_mel_backward / amp_istft_forward / amp_istft_same take
- * any n_fft in [64, 4096] whose prime factors are <= 13 (mixed-radix kernels; powers of two keep theirs). */
+ * any n_fft in [64, 4096] (mixed-radix kernels: compile-time butterflies for the primes 2 .. 13, a run-time radix pass for larger prime factors;
+ * powers of two keep their kernels). */
 int amp_version(void);
 const char* amp_last_error(void);
 /* Number of HIP devices visible (0 when there is no GPU); never fails. */

@@ -171,10 +171,15 @@ def test_mel_small_nfft_and_window_shorter_than_fft():
     (22050, 1000, 800, 250, 64, 250 * 12),        # 2^3 * 5^3, window shorter than the transform
     (16000, 882, 882, 147, 40, 147 * 20),         # 2 * 3^2 * 7^2
     (16000, 1001, 1001, 143, 40, 143 * 25),       # odd: 7 * 11 * 13
+    (22050, 1102, 1102, 275, 64, 275 * 14),       # 2 * 19 * 29: two run-time radix passes (round 5, last session)
+    (16000, 646, 646, 160, 40, 160 * 20),         # 2 * 17 * 19
+    (16000, 1021, 1021, 255, 40, 255 * 12),       # prime: ONE pass, a direct DFT
+    (16000, 4093, 4093, 1023, 80, 1023 * 6),      # the largest prime below the limit
+    (16000, 68, 68, 17, 20, 17 * 90),             # 2^2 * 17 near the lower limit
 ])
 def test_mel_any_smooth_nfft(sr, n_fft, win, hop, n_mel, L):
-    """torch.stft accepts every n_fft (utils/mel.py:145-169); amp_mel_forward now does for every length without a prime factor above 13
-    (mixed-radix kernel): log-mel and the linear spectrum against the oracle."""
+    """torch.stft accepts every n_fft (utils/mel.py:145-169); amp_mel_forward does for every length in [64, 4096] (mixed-radix kernel: compile-time
+    butterflies for the primes 2 .. 13, a run-time radix pass for larger ones): log-mel and the linear spectrum against the oracle."""
     from types import SimpleNamespace as NS
 
     from amphion_amd.utils import mel as M
@@ -193,8 +198,8 @@ def test_mel_any_smooth_nfft(sr, n_fft, win, hop, n_mel, L):
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("AMP_FUZZ_OFFSET", "0")), int(__import__("os").environ.get("AMP_FUZZ_OFFSET", "0")) + 10))
 def test_mel_random_smooth_nfft(seed):
-    """Seeded random transform lengths built from the primes 2 .. 13 (every radix pass and their orders), random hop and window: the linear
-    spectrum against the oracle (torch.stft semantics)."""
+    """Seeded random transform lengths built from the primes 2 .. 13 and, in a third of the cases, one larger prime (every radix pass and their
+    orders), random hop and window: the linear spectrum against the oracle (torch.stft semantics)."""
     import random
 
     from types import SimpleNamespace as NS
@@ -207,6 +212,7 @@ def test_mel_random_smooth_nfft(seed):
         for p in (2, 3, 5, 7, 11, 13):
             n *= p ** rng.choice([0, 0, 1, 1, 2, 3] if p == 2 else [0, 0, 1, 1, 2] if p <= 5 else [0, 0, 0, 1])
         n *= rng.choice([1, 2, 4, 8])
+        n *= rng.choice([1, 1, 1, 17, 19, 23, 31, 37, 61, 127])      # a prime factor above 13: the run-time radix pass
         if 64 <= n <= 4096:
             break
     hop = max(1, n // rng.choice([2, 3, 4, 5, 8]))
@@ -222,15 +228,16 @@ def test_mel_random_smooth_nfft(seed):
     assert err <= 3e-5 * max(1.0, ref.abs().max().item()), f"n_fft={n} hop={hop} win={win}: {err:.2e}"
 
 
-def test_mel_nfft_with_a_large_prime_factor_is_refused():
+def test_mel_nfft_outside_the_range_is_refused():
     from types import SimpleNamespace as NS
 
     from amphion_amd._lib import AmpError
     from amphion_amd.utils import mel as M
 
-    pp = NS(sample_rate=16000, n_fft=1021, win_size=1021, hop_size=255, n_mel=40, fmin=0, fmax=None)     # prime
-    with pytest.raises(AmpError, match="prime factor"):
-        M.mel_spectrogram_torch(torch.zeros(1, 8000).cuda(), pp)
+    for n in (32, 4100):
+        pp = NS(sample_rate=16000, n_fft=n, win_size=n, hop_size=n // 4, n_mel=8, fmin=0, fmax=None)
+        with pytest.raises(AmpError, match=r"\[64, 4096\]"):
+            M.mel_spectrogram_torch(torch.zeros(1, 3 * 4100).cuda(), pp)
 
 
 def test_mel_errors():
@@ -260,7 +267,8 @@ def test_stft_inverse_golden(tag):
     assert np.abs(wav - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("nfft,hop,win", [(1920, 480, 1920), (400, 100, 400), (1000, 250, 800), (1001, 143, 1001), (4096, 1024, 4096)])
+@pytest.mark.parametrize("nfft,hop,win", [(1920, 480, 1920), (400, 100, 400), (1000, 250, 800), (1001, 143, 1001), (4096, 1024, 4096),
+                                          (1102, 275, 1102), (1021, 255, 1021), (646, 160, 600)])
 def test_stft_inverse_any_smooth_nfft(nfft, hop, win):
     """STFT.transform / STFT.inverse (utils/stft.py:152-222) for lengths that are not powers of two (round 5: mixed-radix kernels in both
     directions; an odd length has no Nyquist bin): against the oracle's restatement of the conv-basis formulation."""

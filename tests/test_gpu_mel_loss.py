@@ -50,7 +50,7 @@ def test_mel_loss_value_and_gradient(B, L):
     assert (got - ref_grad).abs().mean().item() <= 2e-5 * scale
 
 
-@pytest.mark.parametrize("sr,n_fft,hop,n_mel", [(24000, 1920, 480, 100), (16000, 400, 160, 80), (16000, 1001, 143, 40)])
+@pytest.mark.parametrize("sr,n_fft,hop,n_mel", [(24000, 1920, 480, 100), (16000, 400, 160, 80), (16000, 1001, 143, 40), (22050, 1102, 275, 64), (16000, 1021, 255, 40)])
 def test_mel_gradient_any_smooth_nfft(sr, n_fft, hop, n_mel):
     """The mel-loss gradient for transform lengths that are not powers of two (round 5; the odd one has no Nyquist bin, so every bin
     above 0 counts twice in the one-sided sum)."""
