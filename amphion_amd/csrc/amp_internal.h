@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -65,6 +67,9 @@ struct ConvArgs {
     float* wn_x;                // EPI_WNACC: x [B, H, T], updated in place: x = (x + rs[:H]) * mask
     float* wn_out;              //            output [B, H, T]: (+)= rs[H:] (last layer: (+)= rs)
     int wn_first, wn_last;      //            first layer starts `output` from zero; last layer has H rows only
+    // ---- conv_strip_f16x3.hip only (persistent strips of column tiles, one workgroup per CU) ----
+    int strip_steps;            // column tiles a workgroup walks (consecutive tiles of one item)
+    int strips_per_item;        // ceil(tiles_per_item / strip_steps)
 };
 
 // Arguments of the fused ResBlock-pair kernel (pair_f16x3.hip):
@@ -242,6 +247,26 @@ hipError_t launch_mel(const amp_mel_desc& d, const float* wav, const int* lens, 
                       const float* melbasis, float* mel, float* mag, float* re, float* im, hipStream_t stream);
 
 void set_error(const char* fmt, ...);
+
+// Kernels that ask for more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize, and the attribute belongs to
+// ONE device's copy of the function: set it once per (kernel, device), under a lock -- two handles may launch from two host threads
+// (the per-launcher copies of this bookkeeping had no lock and mapped devices >= 64 onto bit 0 without setting anything).
+// The kernel is a template ARGUMENT: one mask per kernel instantiation.  Devices beyond 63 set the attribute on every launch.
+template <auto Kernel>
+inline hipError_t ensure_dynamic_lds(size_t bytes) {
+    if (bytes <= 64 * 1024) return hipSuccess;
+    static std::atomic<unsigned long long> done{0};
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    if (dev < 64 && ((done.load(std::memory_order_acquire) >> dev) & 1ull)) return hipSuccess;
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev < 64 && ((done.load(std::memory_order_acquire) >> dev) & 1ull)) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    if (dev < 64) done.fetch_or(1ull << dev, std::memory_order_release);
+    return hipSuccess;
+}
 
 // Which kernels a stretch of launch_* calls issued, as rocprofv3 prints them ("pair_strip_kernel<11, 2, 2, 4, 320, 2, 4, 1>"):
 // while the calling thread points tl_kernel_log at a string (a profiled amp_gen_forward does, per resblock), every launch

@@ -380,15 +380,7 @@ template <int KT, int NI, int HALO, int CM, int RING = 0, int WN = 1>
 static hipError_t launch_blk_one(const ConvArgs& a, hipStream_t stream) {
     constexpr int S = 32 * NI * WN + HALO;
     const size_t lds = (size_t)2 * CM * 4 * S * sizeof(uint4);
-    static unsigned long long attr_set = 0;   // per device
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!((attr_set >> dev) & 1ull) && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_blk_kernel<KT, NI, HALO, CM, RING, WN>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set |= 1ull << dev;
-    }
+    if (hipError_t e = ensure_dynamic_lds<&conv_blk_kernel<KT, NI, HALO, CM, RING, WN>>(lds); e != hipSuccess) return e;
     dim3 grid((unsigned)(a.B * a.tiles_per_item), (unsigned)(a.M / (256 / WN)));
     if (a.row_groups > 0) grid = dim3((unsigned)(a.B * a.tiles_per_item * a.row_groups), 1u);
     note_kernel("conv_blk_kernel", KT, NI, HALO, CM, RING, WN);

@@ -381,15 +381,7 @@ static hipError_t launch_one_h(const ConvArgs& a, hipStream_t stream) {
     constexpr int NT = 32 * NI * WN;
     constexpr int S = NT + HALO;
     const size_t lds = (size_t)2 * 4 * S * sizeof(uint4);
-    static unsigned long long attr_set = 0;   // per device: the attribute belongs to that device's copy of the function
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!((attr_set >> dev) & 1ull) && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16x3_kernel<KT, WM, WN, NI, HALO>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set |= 1ull << dev;
-    }
+    if (hipError_t e = ensure_dynamic_lds<&conv_f16x3_kernel<KT, WM, WN, NI, HALO>>(lds); e != hipSuccess) return e;
     dim3 grid((unsigned)(a.B * a.tiles_per_item), (unsigned)((a.M + 32 * WM - 1) / (32 * WM)));
     if (a.row_groups > 0) grid = dim3((unsigned)(a.B * a.tiles_per_item * a.row_groups), 1u);   // conv_run: row_groups == grid.y
     note_kernel("conv_f16x3_kernel", KT, WM, WN, NI, HALO);

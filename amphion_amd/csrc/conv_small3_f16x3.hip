@@ -28,15 +28,7 @@ static hipError_t launch_small3_one(const ConvSmall3Args& p, hipStream_t stream)
         if (p.a[j].nchunks > kSmallMaxChunks || l > kSmallMaxLds || p.a[j].wd > S) return hipErrorInvalidValue;
         lds = l > lds ? l : lds;
     }
-    static unsigned long long attr_set = 0;   // per device
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!((attr_set >> dev) & 1ull)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small3_kernel<NI0, HALO0>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmallMaxLds);
-        if (e != hipSuccess) return e;
-        attr_set |= 1ull << dev;
-    }
+    if (hipError_t e = ensure_dynamic_lds<&conv_small3_kernel<NI0, HALO0>>(kSmallMaxLds); e != hipSuccess) return e;
     dim3 grid((unsigned)(p.nx[0] * p.ny[0] + p.nx[1] * p.ny[1] + p.nx[2] * p.ny[2]));
     note_kernel("conv_small3_kernel", NI0, HALO0);
     note_work(grid.x, 0.0, 0.0, "three frame-rate convs side by side (work not itemised)");

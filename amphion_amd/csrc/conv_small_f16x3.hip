@@ -49,15 +49,7 @@ static hipError_t launch_small_one(const ConvArgs& a, hipStream_t stream) {
     constexpr int AR = ARing<KT>::n;
     const size_t lds = (size_t)((a.nchunks + AR - 1) / AR * AR) * 4 * S * sizeof(uint4);
     if (a.nchunks > kSmallMaxChunks || lds > kSmallMaxLds || a.wd > S) return hipErrorInvalidValue;
-    static unsigned long long attr_set = 0;   // per device
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!((attr_set >> dev) & 1ull)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small_kernel<KT, NI, HALO, EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmallMaxLds);
-        if (e != hipSuccess) return e;
-        attr_set |= 1ull << dev;
-    }
+    if (hipError_t e = ensure_dynamic_lds<&conv_small_kernel<KT, NI, HALO, EPI>>(kSmallMaxLds); e != hipSuccess) return e;
     dim3 grid((unsigned)(a.B * a.tiles_per_item), (unsigned)((a.M + 127) / 128));
     note_kernel("conv_small_kernel", KT, NI, HALO, EPI);
     note_conv_work(a, KT, grid);

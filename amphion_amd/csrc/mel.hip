@@ -704,14 +704,7 @@ hipError_t launch_mel(const amp_mel_desc& d, const float* wav, const int* lens, 
         MelRadices rad;
         if (!mel_radices(d.n_fft, &rad)) return hipErrorInvalidValue;
         const size_t lds = (size_t)(3 * d.n_fft) * sizeof(float2) + (size_t)(d.n_fft / 2 + 1) * sizeof(float);
-        static std::atomic<unsigned long long> attr_done{0};      // per device (the attribute belongs to that device's copy of the function)
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-        if (!((attr_done.load(std::memory_order_acquire) >> dev) & 1ull)) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mel_mixed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
-            if (e != hipSuccess) return e;
-            attr_done.fetch_or(1ull << dev, std::memory_order_release);
-        }
+        if (hipError_t e = ensure_dynamic_lds<&mel_mixed_kernel>(112 * 1024); e != hipSuccess) return e;   // per device, amp_internal.h
         hipLaunchKernelGGL(mel_mixed_kernel, dim3((unsigned)((size_t)B * F)), dim3(256), lds, stream, wav, lens, L, F, d.n_fft, rad, d.hop_size, pad,
                            n_mel, d.mag_eps, d.log_clip, window, melbasis, mel, mag, re, im, rng);
         hipError_t e = hipGetLastError();
@@ -724,14 +717,7 @@ hipError_t launch_mel(const amp_mel_desc& d, const float* wav, const int* lens, 
     while ((1 << log2n) < d.n_fft) ++log2n;
     const size_t lds = (size_t)(2 * d.n_fft + d.n_fft / 2) * sizeof(float2) + (size_t)(d.n_fft / 2 + 1) * sizeof(float);
     if (lds > 64 * 1024) {                 // n_fft = 4096: 90 KB (round 5: the launch used to fail for want of the attribute)
-        static std::atomic<unsigned long long> attr_done{0};      // per device
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-        if (!((attr_done.load(std::memory_order_acquire) >> dev) & 1ull)) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-            if (e != hipSuccess) return e;
-            attr_done.fetch_or(1ull << dev, std::memory_order_release);
-        }
+        if (hipError_t e = ensure_dynamic_lds<&mel_kernel>(96 * 1024); e != hipSuccess) return e;
     }
     dim3 grid((unsigned)((size_t)B * F));
     hipLaunchKernelGGL(mel_kernel, grid, dim3(256), lds, stream, wav, lens, L, F, d.n_fft, log2n, d.hop_size, pad,
@@ -878,14 +864,7 @@ static hipError_t launch_istft_frames(int n_fft, const float* a, const float* b,
         while ((1 << log2n) < n_fft) ++log2n;
         const size_t lds = (size_t)(2 * n_fft + n_fft / 2) * sizeof(float2);
         if (lds > 64 * 1024) {
-            static std::atomic<unsigned long long> done2{0};
-            int dev = 0;
-            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-            if (!((done2.load(std::memory_order_acquire) >> dev) & 1ull)) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&istft_frames_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-                if (e != hipSuccess) return e;
-                done2.fetch_or(1ull << dev, std::memory_order_release);
-            }
+            if (hipError_t e = ensure_dynamic_lds<&istft_frames_kernel>(96 * 1024); e != hipSuccess) return e;
         }
         hipLaunchKernelGGL(istft_frames_kernel, dim3((unsigned)((size_t)B * F)), dim3(256), lds, stream, a, b, polar, F, n_fft, log2n, inv_scale, window, frames);
         return hipGetLastError();
@@ -893,14 +872,7 @@ static hipError_t launch_istft_frames(int n_fft, const float* a, const float* b,
     MelRadices rad;
     if (!mel_radices(n_fft, &rad)) return hipErrorInvalidValue;
     const size_t lds = (size_t)(3 * n_fft) * sizeof(float2);
-    static std::atomic<unsigned long long> done{0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!((done.load(std::memory_order_acquire) >> dev) & 1ull)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&istft_frames_mixed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
-        if (e != hipSuccess) return e;
-        done.fetch_or(1ull << dev, std::memory_order_release);
-    }
+    if (hipError_t e = ensure_dynamic_lds<&istft_frames_mixed_kernel>(112 * 1024); e != hipSuccess) return e;
     hipLaunchKernelGGL(istft_frames_mixed_kernel, dim3((unsigned)((size_t)B * F)), dim3(256), lds, stream, a, b, polar, F, n_fft, rad, inv_scale, window, frames);
     return hipGetLastError();
 }

@@ -24,15 +24,7 @@ static hipError_t launch_pair3_one(const Pair3Args& p, hipStream_t stream) {
     constexpr int N1 = 32 * NI * WN;
     constexpr int XT = N1 + 12;
     const size_t lds = ((size_t)2 * 4 * SX + (size_t)2 * WM * 4 * XT) * sizeof(uint4);     // independent of the tap count
-    static unsigned long long attr_set = 0;   // per device
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!((attr_set >> dev) & 1ull) && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair3_kernel<11, 7, 3, WM, WN, NI, SX>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set |= 1ull << dev;
-    }
+    if (hipError_t e = ensure_dynamic_lds<&pair3_kernel<11, 7, 3, WM, WN, NI, SX>>(lds); e != hipSuccess) return e;
     dim3 grid((unsigned)(p.n[0] + p.n[1] + p.n[2]));
     note_kernel("pair3_kernel", 11, 7, 3, WM, WN);
     note_work(grid.x, 0.0, 0.0, "three fused pairs side by side (work not itemised)");

@@ -37,15 +37,7 @@ static hipError_t launch_pair_one(const PairArgs& a, hipStream_t stream) {
     constexpr int N1 = 32 * NI * WN;
     constexpr int XT = N1 + 12;
     const size_t lds = ((size_t)2 * 4 * SX + (size_t)2 * WM * 4 * XT) * sizeof(uint4);
-    static unsigned long long attr_set = 0;   // per device: the attribute belongs to that device's copy of the function
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!((attr_set >> dev) & 1ull) && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_f16x3_kernel<KT, WM, WN, NI, SX>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set |= 1ull << dev;
-    }
+    if (hipError_t e = ensure_dynamic_lds<&pair_f16x3_kernel<KT, WM, WN, NI, SX>>(lds); e != hipSuccess) return e;
     dim3 grid((unsigned)(a.B * a.tiles_per_item));
     note_kernel("pair_f16x3_kernel", KT, WM, WN, NI, SX);
     note_work(grid.x, 2 * 2.0 * a.C * a.C * KT * (double)a.T * a.B / 1e9, 2 * 4.0 * a.B * (double)a.C * a.T * (1.0 + (a.mode ? 0.5 : 0.0)) / 1e6,

@@ -290,15 +290,7 @@ template <int KT, int WM, int WN, int NI, int RING = 0, int RB_G = 32>
 static hipError_t launch_rb_one(const RbArgs& a, hipStream_t stream) {
     constexpr int W = 32 * NI * WN;
     const size_t lds = (size_t)2 * WM * 4 * (W + 2 * RB_G) * sizeof(uint4);
-    static unsigned long long attr_set = 0;   // per device: the attribute belongs to that device's copy of the function
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!((attr_set >> dev) & 1ull) && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_f16x3_kernel<KT, WM, WN, NI, RING, RB_G>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set |= 1ull << dev;
-    }
+    if (hipError_t e = ensure_dynamic_lds<&rb_f16x3_kernel<KT, WM, WN, NI, RING, RB_G>>(lds); e != hipSuccess) return e;
     dim3 grid((unsigned)(a.B * a.tiles_per_item));
     note_kernel("rb_f16x3_kernel", KT, WM, WN, NI, RING, RB_G);
     note_work(grid.x, a.np * 2 * 2.0 * a.C * a.C * KT * (double)a.T * a.B / 1e9, 4.0 * a.B * (double)a.C * a.T * (2 + (a.mode ? 1 : 0)) / 1e6,

@@ -924,23 +924,7 @@ static bool rel_attention_tiled() { return g_rel_attention_tiled.load() != 0; }
         if (e__ != hipSuccess) { set_error(name ": %s", hipGetErrorString(e__)); return AMP_ERR_HIP; } \
     } while (0)
 
-// hipFuncAttributeMaxDynamicSharedMemorySize belongs to ONE device's copy of a kernel: set it once per (kernel, device), not once per process
-// (a process that ran the text side on cuda:0 and then on cuda:1 launched on the second device without it -> AMP_ERR_HIP).
-// Returns hipSuccess when the attribute is in place on the current device.
-template <auto Kernel>
-static hipError_t ensure_dynamic_lds(int bytes) {
-    static std::atomic<unsigned long long> done{0};       // one bit per device; the kernel is a template ARGUMENT: one mask per kernel
-    static std::mutex mu;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if ((done.load(std::memory_order_acquire) >> dev) & 1ull) return hipSuccess;
-    std::lock_guard<std::mutex> lock(mu);
-    if ((done.load(std::memory_order_acquire) >> dev) & 1ull) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e != hipSuccess) return e;
-    done.fetch_or(1ull << dev, std::memory_order_release);
-    return hipSuccess;
-}
+// (ensure_dynamic_lds<Kernel>(): amp_internal.h -- the attribute is per device, set once per (kernel, device) under a lock)
 
 extern "C" {
 
