@@ -25,7 +25,8 @@
 //     the end) carries an out-of-range offset, so that the hardware returns 0 / drops the store -- no selects while staging and no
 //     exec-mask branches between the MFMAs (a branch would make hipcc's counted s_waitcnt vmcnt conservative: every A-fragment
 //     wait would also wait for the HBM loads issued after it);
-//   * CM 16-channel chunks per staging round / barrier (k = 3: two, so that a round has 144 MFMAs per wave).
+//   * CM 16-channel chunks per staging round / barrier (two; k = 3: four -- 200+ MFMAs per wave between barriers), staged one chunk at a
+//     time between the MFMAs.
 //
 // Per output element the order of operations -- accumulator start (bias + residual [+ running sum]) * scale, chunks, taps, the
 // three MFMAs of a term, un-scale, leaky ReLU -- is that of conv_f16x3.hip: bit-identical results (tests/test_gpu_f16x3_kernels.py).
@@ -60,6 +61,12 @@ union FragC {
 constexpr int kStripOOB = (int)0x80000000u;   // a byte offset beyond every descriptor (num_records < 2^31, checked on the host)
 
 enum { RK_ST = 1, RK_LD = 2, RK_CV = 4, RK_LAST = 8 };
+#ifndef AMP_STRIP_ST_TAPS
+#define AMP_STRIP_ST_TAPS 99
+#endif
+#ifndef AMP_STRIP_LD_TAPS
+#define AMP_STRIP_LD_TAPS 99
+#endif
 
 // staged halo columns for a step of `ntw` columns: at least 64, and a staged width that is a multiple of 64
 constexpr int strip_halo(int ntw) { return (ntw + 64) % 64 == 0 ? 64 : 64 + (64 - (ntw + 64) % 64); }
@@ -78,7 +85,15 @@ __global__ __launch_bounds__(256, 1) void conv_strip_kernel(const ConvArgs a) {
     constexpr int NR = NCH / CM;               // staging rounds per step
     constexpr int VT = CM * KT;                // taps per round
     constexpr int NH = VT * BH;                // half-taps per round
-    constexpr int G = (32 + NH - 1) / NH;      // side work per half-tap: row groups (one (row block, register) = NI column tiles)
+    constexpr int G = (32 + NH - 1) / NH;      // conversions per half-tap: row groups (one (row block, register) = NI column tiles)
+    // The memory operations of the boundary are spread over ALL half-taps of their round (AMP_STRIP_ST_TAPS / _LD_TAPS = 99): a vector-memory
+    // instruction costs the issuing wave ~30 cycles when they come five to an MFMA (four waves share the CU's address unit, which the A
+    // fragments already keep a quarter busy) -- bursts of 32 stores / 96 loads in the first taps of a round cost 1 000-3 300 cycles per tap
+    // (profiles/r6_strip_conv.txt), one or two behind each MFMA 100-200
+    constexpr int ST_TAPS = AMP_STRIP_ST_TAPS < NH ? AMP_STRIP_ST_TAPS : NH;   // half-taps over which the stores of a step are spread
+    constexpr int LD_TAPS = AMP_STRIP_LD_TAPS < NH ? AMP_STRIP_LD_TAPS : NH;   // ... the residual loads of the next step
+    constexpr int GST = (32 + ST_TAPS - 1) / ST_TAPS, GLD = (32 + LD_TAPS - 1) / LD_TAPS;
+    constexpr int SLO = KT >= 7 ? 3 : KT - 1;        // a slot's chunk (of the next round) is split and written to LDS over the slot's taps SLO .. KT - 1
     constexpr int LDR = NR >= 4 ? NR - 2 : NR - 1;   // the round that requests the next step's residual
     constexpr bool CV_IN_ROUND = NR >= 4;            // ... which the LAST round turns into accumulators (else: at the boundary)
     static_assert(WM * WN == 4, "four waves");
@@ -153,36 +168,36 @@ __global__ __launch_bounds__(256, 1) void conv_strip_kernel(const ConvArgs a) {
             vox[it] = (exists && t >= 0 && t < Tv) ? t * 4 : kStripOOB;
         }
     };
-    float xs[CM][NST][4];
-    auto stage_load = [&](int rnd) __attribute__((always_inline)) {
-#pragma unroll
-        for (int cc = 0; cc < CM; ++cc)
-#pragma unroll
-            for (int it = 0; it < NST; ++it) {
-                const int qd = (wave * 64 + 256 * it) / S;   // wave-uniform
-                const int ch0 = (rnd * CM + cc) * KC16 + 4 * qd;
-                int t4 = Tin4;
-                asm volatile("" : "+s"(t4));                 // opaque: hipcc would hoist all NCH * 16 row offsets out of the step loop (SGPR spills)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) xs[cc][it][e] = ldf(rx, vox[it], (ch0 + e) * t4);
-            }
+    // One 16-channel chunk at a time (a SLOT of KT taps): its loads go out behind the slot's first tap and the split values enter LDS behind
+    // tap SPOS of the same slot, between MFMAs -- nothing of the staging is left for the end of a round but the barrier, and a round of CM
+    // chunks needs the registers of one.
+    float xs[NST][4];
+    auto stage_load_one = [&](int chunk, int it, int e) __attribute__((always_inline)) {
+        const int qd = (wave * 64 + 256 * it) / S;       // wave-uniform
+        int t4 = Tin4;
+        asm volatile("" : "+s"(t4));                     // opaque: hipcc would hoist all NCH * 16 row offsets out of the step loop (SGPR spills)
+        xs[it][e] = ldf(rx, vox[it], (chunk * KC16 + 4 * qd + e) * t4);
     };
-    auto stage_store = [&](int par) __attribute__((always_inline)) {
+    auto stage_store_one = [&](int par, int cc, int it) __attribute__((always_inline)) {
+        uint2* dst = reinterpret_cast<uint2*>(smem4 + (par * CM + cc) * BUF);
+        const int ibase = wave * 64 + 256 * it;
+        const int qd = ibase / S;
+        const int col = ibase - qd * S + lane;
+        struct { uint2 u; } fh, fl;
+        stage4_f16(xs[it][0], xs[it][1], xs[it][2], xs[it][3], kpos, kneg, range_max, fh.u, fl.u);
+        const int o2 = (((qd >> 1) * S + col) << 1) + (qd & 1);   // uint2 index inside a plane
+        dst[o2] = fh.u;
+        dst[4 * S + o2] = fl.u;
+    };
+    auto stage_load = [&](int chunk) __attribute__((always_inline)) {
 #pragma unroll
-        for (int cc = 0; cc < CM; ++cc) {
-            uint2* dst = reinterpret_cast<uint2*>(smem4 + (par * CM + cc) * BUF);
+        for (int it = 0; it < NST; ++it)
 #pragma unroll
-            for (int it = 0; it < NST; ++it) {
-                const int ibase = wave * 64 + 256 * it;
-                const int qd = ibase / S;
-                const int col = ibase - qd * S + lane;
-                struct { uint2 u; } fh, fl;
-                stage4_f16(xs[cc][it][0], xs[cc][it][1], xs[cc][it][2], xs[cc][it][3], kpos, kneg, range_max, fh.u, fl.u);
-                const int o2 = (((qd >> 1) * S + col) << 1) + (qd & 1);   // uint2 index inside a plane
-                dst[o2] = fh.u;
-                dst[4 * S + o2] = fl.u;
-            }
-        }
+            for (int e = 0; e < 4; ++e) stage_load_one(chunk, it, e);
+    };
+    auto stage_store = [&](int par, int cc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < NST; ++it) stage_store_one(par, cc, it);
     };
 
     // A fragments [mb][chunk][tap][plane][lane] x uint4 as a ring of RING taps per row block (conv_blk_f16x3.hip): the tap in slot
@@ -209,11 +224,28 @@ __global__ __launch_bounds__(256, 1) void conv_strip_kernel(const ConvArgs a) {
 
     // this lane's rows of register r of row block mi: 32 * (mb0 + mi) + (r & 3) + 8 * (r >> 2) [+ 4 * hi, part of the lane offset]
     auto row_of = [&](int mi, int r) __attribute__((always_inline)) { return 32 * (mb0 + mi) + (r & 3) + 8 * (r >> 2); };
+    // through an opaque index: read where it is used -- a plain read is hoisted out of the step loop (32 values per lane held across it,
+    // then spilled, and every reload sits behind an s_waitcnt vmcnt(0) in the middle of the MFMAs: the first build's last round took twice
+    // a plain one; a volatile read loses the LDS address space and becomes a flat load)
+    auto bias_at = [&](int mi, int r) __attribute__((always_inline)) {
+        int h4 = 4 * hi;                   // (only the lane part goes through the asm: its INPUT is loop-invariant and would be hoisted and spilled per row)
+        asm volatile("" : "+v"(h4));
+        return bias_s[row_of(mi, r) + h4];
+    };
     auto fin = [&](float v) __attribute__((always_inline)) {
         v *= isc;
         return __builtin_fmaxf(v, v * slope_out);    // leaky ReLU for slopes <= 1 (host), 1.0 = identity
     };
 
+#ifdef AMP_STRIP_STAMPS
+    // experiment build (tools/strip_stamps.py): shader-clock stamps of every wave -- entry, prologue, the rounds of step 1 (start, end of the
+    // MFMAs, barrier passed), every half-tap of its first two and last two rounds, the boundary, the flush
+    unsigned long long* const stp = a.stamps ? a.stamps + ((size_t)blockIdx.x * 4 + wave) * 256 : nullptr;
+#define AMP_STAMP(cond, i) do { if (stp && (cond) && lane == 0) stp[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AMP_STAMP(cond, i) do { } while (0)
+#endif
+    AMP_STAMP(true, 0);
     // ---------------- prologue: bias table, first staging round, first A taps, step 0's accumulators (the one exposed start) ----------------
     for (int i = tid; i < C; i += 256) bias_s[i] = a.bias ? a.bias[i] : 0.f;
     set_vox(tile0, true);
@@ -235,7 +267,7 @@ __global__ __launch_bounds__(256, 1) void conv_strip_kernel(const ConvArgs a) {
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float bv = bias_s[row_of(mi, r) + 4 * hi];
+                const float bv = bias_at(mi, r);
                 const int soff = row_of(mi, r) * Tout4;
 #pragma unroll
                 for (int t = 0; t < NI; ++t) {
@@ -262,9 +294,15 @@ __global__ __launch_bounds__(256, 1) void conv_strip_kernel(const ConvArgs a) {
 #pragma unroll
             for (int t = 0; t < NI; ++t) X[mi][t] *= asc;
     }
-    stage_store(0);
+    stage_store(0, 0);
+#pragma unroll
+    for (int cc = 1; cc < CM; ++cc) {   // (the first round of a strip: its other chunks one after the other, exposed)
+        stage_load(cc);
+        stage_store(0, cc);
+    }
     __syncthreads();
 
+    AMP_STAMP(true, 1);
     int vst[NI], vld[NI];
     // where the boundary's rotation left the results of tile (mi, t)
     auto yres = [&](int mi, int t) __attribute__((always_inline)) -> f32x16& {
@@ -280,6 +318,7 @@ __global__ __launch_bounds__(256, 1) void conv_strip_kernel(const ConvArgs a) {
         int wn = last ? wa0 : wr + RNDB;
         asm volatile("" : "+s"(wr), "+s"(wn));              // opaque: tap offsets are formed where they are used, not hoisted (SGPR spills)
         const uint4* base = smem4 + ((c & 1) * CM) * BUF + rd0;
+        AMP_STAMP(s == 1, 2 + 3 * c);
         if (last) set_vox(tile0 + s + 1, s + 1 < nst);     // every staging load of this step has been issued; a step that does not exist reads zeros
         FragC bh[2][NB], bl[2][NB];
 #pragma unroll
@@ -300,57 +339,98 @@ __global__ __launch_bounds__(256, 1) void conv_strip_kernel(const ConvArgs a) {
                 }
             }
             AMP_PIN_DSREAD();
+            // Everything that is not an MFMA rides BETWEEN the MFMAs of this half-tap, a unit behind each (a bunch of 20 buffer loads behind
+            // the last MFMA of a tap cost that tap 500 cycles, 120 staging VALU instructions in one tap 300-2 000: r6_c / r6_d stamps):
+            //   the loads of the slot's chunk (of the next round) behind the MFMAs of the slot's first tap,
+            //   its staging items (split + LDS write) one or two per tap over the slot's later taps,
+            //   the boundary's pieces (stores / residual loads / conversions) a row group at a time.
+            const int slot = v / KT, g = v % KT;
+            const int next_chunk = (last ? 0 : (c + 1) * CM) + slot;
+            constexpr int NM = MI * NB * 3;              // MFMAs of a half-tap
+            constexpr int NL = 4 * NST;                  // loads of a chunk
+            auto piece_st = [&](int g4) __attribute__((always_inline)) {        // the previous step's results leave
+                if (g4 >= 32) return;
+                const int mi = g4 / 16, r = g4 % 16;
+                int t4 = Tout4;
+                asm volatile("" : "+s"(t4));             // opaque, as in stage_load
+                const int soff = row_of(mi, r) * t4;
+#pragma unroll
+                for (int t = 0; t < NI; ++t) stf(fin(yres(mi, t)[r]), ry, vst[t], soff);
+            };
+            auto piece_ld = [&](int g4) __attribute__((always_inline)) {        // the next step's residual arrives
+                if (g4 >= 32) return;
+                const int mi = g4 / 16, r = g4 % 16;
+                int t4 = Tout4;
+                asm volatile("" : "+s"(t4));
+                const int soff = row_of(mi, r) * t4;
+#pragma unroll
+                for (int t = 0; t < NI; ++t) Y[mi][t][r] = ldf(rr, vld[t], soff);
+            };
+            auto piece_cv = [&](int g4) __attribute__((always_inline)) {        // ... and becomes its starting accumulators
+                if (g4 >= 32) return;
+                const int mi = g4 / 16, r = g4 % 16;
+                const float bv = bias_at(mi, r);
+#pragma unroll
+                for (int t = 0; t < NI; ++t) {
+                    float v = RES ? (bv + Y[mi][t][r]) * cvm : bv * cvm;
+                    // anchored HERE, in an accumulator register: a pure computation has no position of its own -- left alone all of
+                    // them (and their 32 bias values) sink to the boundary, where their only consumer (the exchange) is
+                    asm volatile("" : "+a"(v));
+                    Y[mi][t][r] = v;
+                }
+            };
+            auto side = [&](const int mf) __attribute__((always_inline)) {   // behind MFMA mf of this half-tap
+                if (th == 0 && g == 0) {
+#pragma unroll
+                    for (int q = (mf * NL) / NM; q < ((mf + 1) * NL) / NM; ++q) stage_load_one(next_chunk, q / 4, q % 4);
+                }
+                if ((kind & RK_ST) && h < ST_TAPS) {
+#pragma unroll
+                    for (int gi = 0; gi < GST; ++gi)
+                        if ((gi * NM) / GST == mf) piece_st(h * GST + gi);
+                }
+                if ((kind & RK_LD) && RES && h < LD_TAPS) {
+#pragma unroll
+                    for (int gi = 0; gi < GLD; ++gi)
+                        if ((gi * NM) / GLD == mf) piece_ld(h * GLD + gi);
+                }
+                if (kind & RK_CV) {
+#pragma unroll
+                    for (int gi = 0; gi < G; ++gi)
+                        if ((gi * NM) / G == mf) piece_cv(h * G + gi);
+                }
+                AMP_PIN_VMEM();
+            };
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-                for (int t = 0; t < NB; ++t)
+                for (int t = 0; t < NB; ++t) {
                     X[mi][th * NB + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[mi][v % RING].h, bh[cur][t].h, X[mi][th * NB + t], 0, 0, 0);
+                    side((mi * 3 + 0) * NB + t);
+                }
 #pragma unroll
-                for (int t = 0; t < NB; ++t)
+                for (int t = 0; t < NB; ++t) {
                     X[mi][th * NB + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[mi][v % RING].h, bl[cur][t].h, X[mi][th * NB + t], 0, 0, 0);
+                    side((mi * 3 + 1) * NB + t);
+                }
 #pragma unroll
-                for (int t = 0; t < NB; ++t)
+                for (int t = 0; t < NB; ++t) {
                     X[mi][th * NB + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l[mi][v % RING].h, bh[cur][t].h, X[mi][th * NB + t], 0, 0, 0);
+                    side((mi * 3 + 2) * NB + t);
+                }
                 if (th == BH - 1) reload(mi, v, wr, wn);
             }
-            if (h == 0) {       // the next round's x chunk(s): this step's round c + 1, or the next step's first
-                AMP_PIN_VMEM();
-                stage_load(last ? 0 : c + 1);
-            }
-            // ---- the step boundary, in pieces of G row quads ----
+            if (th == BH - 1) {   // this tap's share of the slot's staging items
 #pragma unroll
-            for (int gi = 0; gi < G; ++gi) {
-                const int g4 = h * G + gi;
-                if (g4 < 32) {
-                    const int mi = g4 / 16, r = g4 % 16;
-                    int t4 = Tout4;
-                    asm volatile("" : "+s"(t4));             // opaque, as in stage_load
-                    const int soff = row_of(mi, r) * t4;
-                    if (kind & RK_ST) {           // the previous step's results leave
-#pragma unroll
-                        for (int t = 0; t < NI; ++t) stf(fin(yres(mi, t)[r]), ry, vst[t], soff);
-                    }
-                    if ((kind & RK_LD) && RES) {  // the next step's residual arrives
-#pragma unroll
-                        for (int t = 0; t < NI; ++t) Y[mi][t][r] = ldf(rr, vld[t], soff);
-                    }
-                    if (kind & RK_CV) {           // ... and becomes its starting accumulators
-                        const float bv = bias_s[row_of(mi, r) + 4 * hi];
-#pragma unroll
-                        for (int t = 0; t < NI; ++t) {
-                            float v = RES ? (bv + Y[mi][t][r]) * cvm : bv * cvm;
-                            // anchored HERE, in an accumulator register: a pure computation has no position of its own -- left alone all 128 of
-                            // them (and their 32 bias values) sink to the boundary, where their only consumer (the exchange) is
-                            asm volatile("" : "+a"(v));
-                            Y[mi][t][r] = v;
-                        }
-                    }
-                }
+                for (int it = 0; it < NST; ++it)
+                    if (g == SLO + (it * (KT - SLO)) / NST) stage_store_one((c + 1) & 1, slot, it);
             }
             AMP_PIN_HALFTAP();
+            AMP_STAMP(s == 1 && (c <= 1 || c >= NR - 2), 64 + 32 * (c <= 1 ? c : c - (NR - 4)) + h);
         }
-        stage_store((c + 1) & 1);
+        AMP_STAMP(s == 1, 3 + 3 * c);
         __syncthreads();
+        AMP_STAMP(s == 1, 4 + 3 * c);
     };
 
     FragC zf;
@@ -371,7 +451,7 @@ __global__ __launch_bounds__(256, 1) void conv_strip_kernel(const ConvArgs a) {
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float bv = bias_s[row_of(mi, r) + 4 * hi];
+                    const float bv = bias_at(mi, r);
 #pragma unroll
                     for (int t = 0; t < NI; ++t) Y[mi][t][r] = RES ? (bv + Y[mi][t][r]) * cvm : bv * cvm;
                 }
@@ -391,6 +471,7 @@ __global__ __launch_bounds__(256, 1) void conv_strip_kernel(const ConvArgs a) {
         // start), Y_k <- the old X_(k + 1): 15 MFMAs and one spare tile.  Afterwards tile k's results sit in Y_((k + 7) % 8) -- yres() below.
         // The scheduling barriers keep the order: left alone the scheduler batches the independent copies and needs a spare tile for each
         // (128 registers: the A ring was spilled across the boundary).
+        AMP_STAMP(s == 1, 56);
         asm volatile("" : "+v"(zero));       // opaque: a zero the compiler cannot fold the MFMAs around
         zf.u = make_uint4(zero, zero, zero, zero);
         {
@@ -413,7 +494,9 @@ __global__ __launch_bounds__(256, 1) void conv_strip_kernel(const ConvArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        AMP_STAMP(s == 1, 57);
     }
+    AMP_STAMP(true, 58);
     {   // the last step's results
         int vo[NI];
         set_voy(tile0 + nst - 1, true, vo);
@@ -426,6 +509,10 @@ __global__ __launch_bounds__(256, 1) void conv_strip_kernel(const ConvArgs a) {
                 for (int t = 0; t < NI; ++t) stf(fin(yres(mi, t)[r]), ry, vo[t], soff);
             }
     }
+#ifdef AMP_STRIP_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    AMP_STAMP(true, 59);
     if (a.range_flag && __any(range_max > 65504.f) && lane == 0) atomicOr(a.range_flag, 1u);
 }
 
@@ -457,15 +544,15 @@ int AMP_CAT(conv_strip_nt_kt, AMP_KT)(int C, int halo_total) {
 // no tanh, C * T * 4 < 2^31, tiles of conv_strip_nt_kt*() columns, strip_steps / strips_per_item set
 hipError_t AMP_CAT(launch_conv_strip_kt, AMP_KT)(const ConvArgs& a, hipStream_t stream) {
     constexpr int KT = AMP_KT;
-    constexpr int CM = KT == 3 ? 2 : 1;
+    constexpr int CMX = KT == 3 ? 4 : 2;      // chunks per staging round / barrier: 200+ MFMAs per wave between barriers (C = 64 has four chunks: two)
     constexpr int RING = 4;
     const bool res = a.res != nullptr, sum = a.mode != 0;
     if (a.mode != 0 && a.mode != 1) return hipErrorInvalidValue;
     if (sum && !res) return hipErrorInvalidValue;
 #define AMP_STRIP_SHAPE(WM_, WN_)                                                                              \
-    return sum ? launch_strip_conv_one<KT, WM_, WN_, kStripNI, CM, RING, true, true>(a, stream)                 \
-               : res ? launch_strip_conv_one<KT, WM_, WN_, kStripNI, CM, RING, true, false>(a, stream)          \
-                     : launch_strip_conv_one<KT, WM_, WN_, kStripNI, CM, RING, false, false>(a, stream);
+    return sum ? launch_strip_conv_one<KT, WM_, WN_, kStripNI, (WM_ == 1 && CMX > 2 ? 2 : CMX), RING, true, true>(a, stream)                 \
+               : res ? launch_strip_conv_one<KT, WM_, WN_, kStripNI, (WM_ == 1 && CMX > 2 ? 2 : CMX), RING, true, false>(a, stream)          \
+                     : launch_strip_conv_one<KT, WM_, WN_, kStripNI, (WM_ == 1 && CMX > 2 ? 2 : CMX), RING, false, false>(a, stream);
     switch (a.Cout) {
         case 256: AMP_STRIP_SHAPE(4, 1)
         case 128: AMP_STRIP_SHAPE(2, 2)

@@ -496,8 +496,26 @@ static hipError_t launch_conv_strip(int kt, const ConvArgs& a, hipStream_t s) {
     }
     return hipErrorInvalidValue;
 }
+#ifdef AMP_STRIP_STAMPS
+static unsigned long long* g_strip_stamps = nullptr;   // experiment builds only: tools/strip_stamps.py
+extern "C" int amp_debug_strip_stamps(void* buf) { g_strip_stamps = static_cast<unsigned long long*>(buf); return 0; }
+#endif
 // the strip launch fills the chip (one workgroup per CU) from this many column tiles on
 constexpr long long kConvStripMinTiles = 512;
+// Column tiles per strip.  One workgroup per CU: the launch runs ceil(workgroups / 256) rounds of `steps` tiles (+ a third of a tile for a
+// workgroup's exposed start and flush) -- measured (r6_g): B = 32 x 22 tiles of the C = 256 stage take 244 us as 256 strips of 3, 280-300 as 704 / 352 /
+// 192 strips of 1 / 2 / 4; B = 64: 478 us as 256 strips of 6, 525-550 otherwise.  Ties go to the shorter strips (more workgroups: the dispatcher
+// evens out the CUs); strips beyond 12 tiles are not considered (CUs walking their own regions in lockstep: pair_strip_f16x3.hip's lesson).
+static int conv_strip_steps_for(int B, int tiles_per_item) {
+    int best = 1;
+    double best_cost = 1e30;
+    for (int st = 1; st <= 12 && st <= tiles_per_item; ++st) {
+        const long long wgs = (long long)B * ((tiles_per_item + st - 1) / st);
+        const double cost = (double)((wgs + 255) / 256) * (st + 0.33);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = st; }
+    }
+    return best;
+}
 // Convs with more than one row group (M > 32 * WM rows: the C = 256 stage, the transposed convs' polyphase rows) launch a
 // 1-D grid with the row group as the fastest index, so that the row groups of one x tile run back to back on one XCD and x
 // comes from HBM once (ConvArgs::row_groups).  amp_set_conv_rg_fast(0): the 2-D grid (row group =
@@ -740,23 +758,28 @@ static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope
             const int nt = blk_wn * (c->KT == 2 ? conv_blk_nt_kt2(cm, halo) : c->KT == 3 ? conv_blk_nt_kt3(cm, halo) : c->KT == 7 ? conv_blk_nt_kt7(cm, halo) : conv_blk_nt_kt11(cm, halo));
             if (nt > 0 && (long long)B * ((a.Tq + nt - 1) / nt) * (c->M / (256 / blk_wn)) >= kConvBlkMinWorkgroups) { blk_cm = cm; blk_nt = nt; }
         }
-        // persistent strips (conv_strip_f16x3.hip): square Conv1d, 'same' length, mode 0 / 1
+        // persistent strips (conv_strip_f16x3.hip): square Conv1d, 'same' length, mode 0 / 1.  Policy (mode 1; profiles/r6_strip_conv.txt): C = 128 and
+        // C = 256 at k >= 5 on launches of 512+ column tiles; k = 3 (a chunk is 54 MFMAs: level with the per-tile kernels) and C = 64 (1 x 4 waves:
+        // slower than the per-tile kernel at every k) stay where they were.
         int strip_nt = 0;
         if (conv_strip_mode() > 0 && !plan_small && !c->transposed && c->cin == c->cout && c->KT == c->ntaps && Tout == T && !c->pad_reflect &&
-            !c->tanh_out && mode != 2 && !(mode == 1 && !res) && slope_out <= 1.f && (long long)c->cout * T * 4 < (1ll << 31) &&
-            !(c->cout == 64 && mode == 1)) {   // (C = 64 with a running sum: that instantiation spills)
+            !c->tanh_out && mode != 2 && !(mode == 1 && !res) && slope_out <= 1.f && (long long)c->cout * T * 4 < (1ll << 31)) {
             strip_nt = conv_strip_nt(c->KT, c->cout, c->halo_left + c->halo_right);
-            if (strip_nt > 0 && conv_strip_mode() == 1 && (long long)B * ((a.Tq + strip_nt - 1) / strip_nt) < kConvStripMinTiles) strip_nt = 0;
+            if (strip_nt > 0 && conv_strip_mode() == 1 &&
+                (c->cout == 64 || c->KT < 5 || (long long)B * ((a.Tq + strip_nt - 1) / strip_nt) < kConvStripMinTiles))
+                strip_nt = 0;
         }
         if (strip_nt > 0) {
             a.tiles_per_item = (a.Tq + strip_nt - 1) / strip_nt;
             a.wd = strip_nt + c->halo_left + c->halo_right;
-            const long long tiles = (long long)B * a.tiles_per_item;
             int steps = cfg().conv_strip_steps;
-            if (steps <= 0) steps = tiles >= 8 * 1024 ? 4 : tiles >= 2 * 1024 ? 2 : 1;   // keep 1 000+ workgroups: the dispatcher balances the CUs
+            if (steps <= 0) steps = conv_strip_steps_for(B, a.tiles_per_item);
             if (steps > a.tiles_per_item) steps = a.tiles_per_item;
             a.strip_steps = steps;
             a.strips_per_item = (a.tiles_per_item + steps - 1) / steps;
+#ifdef AMP_STRIP_STAMPS
+            a.stamps = g_strip_stamps;
+#endif
             AMP_HIP(launch_conv_strip(c->KT, a, stream));
             return AMP_OK;
         }
