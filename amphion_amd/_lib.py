@@ -139,8 +139,6 @@ _SIGNATURES = {
     "amp_set_conv_rg_fast": (c_int, [c_int]),
     "amp_set_pingpong": (c_int, [c_int]),
     "amp_set_conv_blk_narrow": (c_int, [c_int]),
-    "amp_set_conv_strip": (c_int, [c_int]),
-    "amp_set_conv_strip_steps": (c_int, [c_int]),
     "amp_ampblock_forward": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                      c_void_p, c_int, c_int, c_void_p, c_int, c_float, c_void_p]),
     "amp_set_ampblock_fusion": (c_int, [c_int]),

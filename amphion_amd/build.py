@@ -31,7 +31,6 @@ SMALL_TAPS = (1, 3, 5, 7, 11)
 BLK_TAPS = (2, 3, 7, 11)
 RB_TAPS = (3, 5, 7, 11)
 AMPB_TAPS = (3, 5, 7, 11)
-STRIP_TAPS = (3, 5, 7, 11)
 
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC, "-Wall",
          "-Wno-unused-function"] + os.environ.get("AMP_BUILD_FLAGS", "").split()
@@ -53,8 +52,6 @@ def _units():
         units.append(("pair_strip_f16x3.hip", f"pair_strip_f16x3_kt{kt}.o", [f"-DAMP_KT={kt}"]))
     for kt in RB_TAPS:
         units.append(("rb_f16x3.hip", f"rb_f16x3_kt{kt}.o", [f"-DAMP_KT={kt}"]))
-    for kt in STRIP_TAPS:
-        units.append(("conv_strip_f16x3.hip", f"conv_strip_f16x3_kt{kt}.o", [f"-DAMP_KT={kt}"]))
     for kt in AMPB_TAPS:
         units.append(("ampb_f16x3.hip", f"ampb_f16x3_kt{kt}.o", [f"-DAMP_KT={kt}"]))
     return units

@@ -67,10 +67,6 @@ struct ConvArgs {
     float* wn_x;                // EPI_WNACC: x [B, H, T], updated in place: x = (x + rs[:H]) * mask
     float* wn_out;              //            output [B, H, T]: (+)= rs[H:] (last layer: (+)= rs)
     int wn_first, wn_last;      //            first layer starts `output` from zero; last layer has H rows only
-    // ---- conv_strip_f16x3.hip only (persistent strips of column tiles, one workgroup per CU) ----
-    int strip_steps;            // column tiles a workgroup walks (consecutive tiles of one item)
-    int strips_per_item;        // ceil(tiles_per_item / strip_steps)
-    unsigned long long* stamps; // experiment builds (-DAMP_STRIP_STAMPS): [workgroup][wave][128] clock stamps, else nullptr
 };
 
 // Arguments of the fused ResBlock-pair kernel (pair_f16x3.hip):

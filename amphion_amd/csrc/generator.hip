@@ -352,8 +352,6 @@ struct Config {
     int conv_rg_fast = 1;
     int pingpong = 1;
     int narrow_blk = 1;        // row-blocked conv kernel for 128- / 64-row convs (amp_set_conv_blk_narrow)
-    int conv_strip = 1;        // persistent strip conv kernel for the square C = 64 / 128 / 256 convs: 0 off, 1 policy, 2 wherever built (amp_set_conv_strip)
-    int conv_strip_steps = 0;  // column tiles per strip, 0 = the policy's (amp_set_conv_strip_steps)
     int rb_streams = -1;       // resblocks of a stage on concurrent streams: -1 small launches only, 0 never, 1 always (amp_set_resblock_streams)
     Config() {
         auto num = [](const char* name, int lo, int hi, int dflt) {
@@ -466,56 +464,6 @@ hipError_t launch_conv_blk_kt7(int, int, const ConvArgs&, hipStream_t);
 hipError_t launch_conv_blk_kt11(int, int, const ConvArgs&, hipStream_t);
 static int conv_blk_mode() { return cfg().conv_blk; }
 static int narrow_blk_mode() { return cfg().narrow_blk; }
-// Persistent strip conv kernel (conv_strip_f16x3.hip, round 6): Conv1d with Cin = Cout = 64 | 128 | 256 and k = 3 | 5 | 7 | 11 -- the unfused
-// AMPBlock convs of BigVGAN, the C = 256 stage of HiFi-GAN; same bits as conv_f16x3.hip.  amp_set_conv_strip: 0 off, 1 (default) the measured
-// policy, 2 wherever the kernel is built.
-int conv_strip_nt_kt3(int, int);
-int conv_strip_nt_kt5(int, int);
-int conv_strip_nt_kt7(int, int);
-int conv_strip_nt_kt11(int, int);
-hipError_t launch_conv_strip_kt3(const ConvArgs&, hipStream_t);
-hipError_t launch_conv_strip_kt5(const ConvArgs&, hipStream_t);
-hipError_t launch_conv_strip_kt7(const ConvArgs&, hipStream_t);
-hipError_t launch_conv_strip_kt11(const ConvArgs&, hipStream_t);
-static int conv_strip_mode() { return cfg().conv_strip; }
-static int conv_strip_nt(int kt, int C, int halo) {
-    switch (kt) {
-        case 3: return conv_strip_nt_kt3(C, halo);
-        case 5: return conv_strip_nt_kt5(C, halo);
-        case 7: return conv_strip_nt_kt7(C, halo);
-        case 11: return conv_strip_nt_kt11(C, halo);
-    }
-    return 0;
-}
-static hipError_t launch_conv_strip(int kt, const ConvArgs& a, hipStream_t s) {
-    switch (kt) {
-        case 3: return launch_conv_strip_kt3(a, s);
-        case 5: return launch_conv_strip_kt5(a, s);
-        case 7: return launch_conv_strip_kt7(a, s);
-        case 11: return launch_conv_strip_kt11(a, s);
-    }
-    return hipErrorInvalidValue;
-}
-#ifdef AMP_STRIP_STAMPS
-static unsigned long long* g_strip_stamps = nullptr;   // experiment builds only: tools/strip_stamps.py
-extern "C" int amp_debug_strip_stamps(void* buf) { g_strip_stamps = static_cast<unsigned long long*>(buf); return 0; }
-#endif
-// the strip launch fills the chip (one workgroup per CU) from this many column tiles on
-constexpr long long kConvStripMinTiles = 512;
-// Column tiles per strip.  One workgroup per CU: the launch runs ceil(workgroups / 256) rounds of `steps` tiles (+ a third of a tile for a
-// workgroup's exposed start and flush) -- measured (r6_g): B = 32 x 22 tiles of the C = 256 stage take 244 us as 256 strips of 3, 280-300 as 704 / 352 /
-// 192 strips of 1 / 2 / 4; B = 64: 478 us as 256 strips of 6, 525-550 otherwise.  Ties go to the shorter strips (more workgroups: the dispatcher
-// evens out the CUs); strips beyond 12 tiles are not considered (CUs walking their own regions in lockstep: pair_strip_f16x3.hip's lesson).
-static int conv_strip_steps_for(int B, int tiles_per_item) {
-    int best = 1;
-    double best_cost = 1e30;
-    for (int st = 1; st <= 12 && st <= tiles_per_item; ++st) {
-        const long long wgs = (long long)B * ((tiles_per_item + st - 1) / st);
-        const double cost = (double)((wgs + 255) / 256) * (st + 0.33);
-        if (cost < best_cost - 1e-9) { best_cost = cost; best = st; }
-    }
-    return best;
-}
 // Convs with more than one row group (M > 32 * WM rows: the C = 256 stage, the transposed convs' polyphase rows) launch a
 // 1-D grid with the row group as the fastest index, so that the row groups of one x tile run back to back on one XCD and x
 // comes from HBM once (ConvArgs::row_groups).  amp_set_conv_rg_fast(0): the 2-D grid (row group =
@@ -757,31 +705,6 @@ static int conv_run(const amp_conv* c, const float* x, int B, int T, float slope
             const int halo = c->halo_left + c->halo_right;
             const int nt = blk_wn * (c->KT == 2 ? conv_blk_nt_kt2(cm, halo) : c->KT == 3 ? conv_blk_nt_kt3(cm, halo) : c->KT == 7 ? conv_blk_nt_kt7(cm, halo) : conv_blk_nt_kt11(cm, halo));
             if (nt > 0 && (long long)B * ((a.Tq + nt - 1) / nt) * (c->M / (256 / blk_wn)) >= kConvBlkMinWorkgroups) { blk_cm = cm; blk_nt = nt; }
-        }
-        // persistent strips (conv_strip_f16x3.hip): square Conv1d, 'same' length, mode 0 / 1.  Policy (mode 1; profiles/r6_strip_conv.txt): C = 128 and
-        // C = 256 at k >= 5 on launches of 512+ column tiles; k = 3 (a chunk is 54 MFMAs: level with the per-tile kernels) and C = 64 (1 x 4 waves:
-        // slower than the per-tile kernel at every k) stay where they were.
-        int strip_nt = 0;
-        if (conv_strip_mode() > 0 && !plan_small && !c->transposed && c->cin == c->cout && c->KT == c->ntaps && Tout == T && !c->pad_reflect &&
-            !c->tanh_out && mode != 2 && !(mode == 1 && !res) && slope_out <= 1.f && (long long)c->cout * T * 4 < (1ll << 31)) {
-            strip_nt = conv_strip_nt(c->KT, c->cout, c->halo_left + c->halo_right);
-            if (strip_nt > 0 && conv_strip_mode() == 1 &&
-                (c->cout == 64 || c->KT < 5 || (long long)B * ((a.Tq + strip_nt - 1) / strip_nt) < kConvStripMinTiles))
-                strip_nt = 0;
-        }
-        if (strip_nt > 0) {
-            a.tiles_per_item = (a.Tq + strip_nt - 1) / strip_nt;
-            a.wd = strip_nt + c->halo_left + c->halo_right;
-            int steps = cfg().conv_strip_steps;
-            if (steps <= 0) steps = conv_strip_steps_for(B, a.tiles_per_item);
-            if (steps > a.tiles_per_item) steps = a.tiles_per_item;
-            a.strip_steps = steps;
-            a.strips_per_item = (a.tiles_per_item + steps - 1) / steps;
-#ifdef AMP_STRIP_STAMPS
-            a.stamps = g_strip_stamps;
-#endif
-            AMP_HIP(launch_conv_strip(c->KT, a, stream));
-            return AMP_OK;
         }
         if (plan_small && !(blk_cm == 0 && plan.NI == 2 && small_conv_covers(c) && (c->KT <= 5 || wgs_half <= 128))) return AMP_ERR_UNSUPPORTED;
         if (blk_cm > 0) {
@@ -1215,8 +1138,8 @@ extern "C" {
 // 141 (additive): the ragged / fused entry points of the VITS text side (amp_conv_forward_ragged, amp_layer_norm_c_ragged, amp_dwconv_layer_norm_c,
 // amp_rel_attention_strided, amp_set_rel_attention_tiled, amp_expand_path_strided); 142 (round 5, REMOVALS): amp_conv_act_forward, amp_set_fuse_act,
 // amp_set_wn_layer_fusion are gone with the kernels behind them (never chosen by the launch policy), amp_set_pair_strips(1) is refused; amp_mel_forward
-// accepts every n_fft in [64, 4096]; 143 (round 6, additive): amp_set_conv_strip / amp_set_conv_strip_steps
-int amp_version(void) { return 143; }
+// accepts every n_fft in [64, 4096]
+int amp_version(void) { return 142; }
 const char* amp_last_error(void) { return g_err; }
 
 int amp_set_precision(int precision) {
@@ -2040,18 +1963,6 @@ int amp_set_conv_rg_fast(int on) {
 int amp_set_conv_blk_narrow(int on) {
     if (on < -1 || on > 2) { set_error("amp_set_conv_blk_narrow: %d (0 off, 1 policy: 128-row convs with k >= 7, 2 every 128-row conv, -1 default)", on); return AMP_ERR_INVALID; }
     cfg().narrow_blk = on < 0 ? 1 : on;
-    return AMP_OK;
-}
-
-int amp_set_conv_strip(int mode) {
-    if (mode < -1 || mode > 2) { set_error("amp_set_conv_strip: mode %d (0 off, 1 policy, 2 wherever the kernel is built, -1 default)", mode); return AMP_ERR_INVALID; }
-    cfg().conv_strip = mode < 0 ? 1 : mode;
-    return AMP_OK;
-}
-
-int amp_set_conv_strip_steps(int steps) {
-    if (steps < 0 || steps > 4096) { set_error("amp_set_conv_strip_steps: %d (column tiles per strip, 0 = the policy's)", steps); return AMP_ERR_INVALID; }
-    cfg().conv_strip_steps = steps;
     return AMP_OK;
 }
 

@@ -92,8 +92,7 @@ typedef struct amp_gen amp_gen;
  * amp_conv_act_forward, amp_set_fuse_act and amp_set_wn_layer_fusion together with the kernels behind them (bit-identical forms the launch
  * policy never chose), refuses amp_set_pair_strips(1), and lets amp_mel_forward / amp_mel_backward / amp_istft_forward / amp_istft_same take
  * any n_fft in [64, 4096] (mixed-radix kernels: compile-time butterflies for the primes 2 .. 13, a run-time radix pass for larger prime factors;
- * powers of two keep their kernels); 143 (round 6, additive):
- * amp_set_conv_strip, amp_set_conv_strip_steps. */
+ * powers of two keep their kernels). */
 int amp_version(void);
 const char* amp_last_error(void);
 /* Number of HIP devices visible (0 when there is no GPU); never fails. */
@@ -394,20 +393,13 @@ int amp_set_small_conv(int on);
 /* Transposed convs and k = 3 / 7 / 11 convs whose GEMM rows are a multiple of 256 (ConvTranspose1d: Cout * stride) run, on grids
  * of 512+ workgroups, on the row-blocked kernel (csrc/conv_blk_f16x3.hip: 64 rows per wave, x staged once per 256 rows;
  * same bits as the pipelined kernel).  mode 0 keeps them on the pipelined kernel, 1 = one 16-channel chunk per staging
- * round, 2 = two where available, 3 = 2 + k = 7 / 11 on the A-fragment-ring form (default), -1 = back to
+ * round, 2 = two where available, 3 = 2 + k = 7 / 11 on the A-fragment-ring form (default), -1 = back to AMP_CONV_BLK /
  * the default -- an A/B and cross-check switch. */
 int amp_set_conv_blk(int mode);
 /* Conv1d with 128 output rows (BigVGAN's unpaired AMPBlock convs at C = 128) on the row-blocked kernel, two waves along the columns: 1
  * (default) the measured policy (k = 7 / 11), 2 every tap count the kernel is built for, 0 all on the pipelined kernel.  Same bits in every
  * mode (an A/B and cross-check switch); -1: default. */
 int amp_set_conv_blk_narrow(int on);
-/* Conv1d with Cin = Cout = 64 | 128 | 256 and k = 3 | 5 | 7 | 11 (BigVGAN's unpaired AMPBlock convs, bigvgan.py:137-146; HiFi-GAN's C = 256
- * stage, hifigan.py:93-100) on the persistent strip kernel (csrc/conv_strip_f16x3.hip: one workgroup per CU walks consecutive column tiles,
- * the stores of a tile and the residual loads of the next one ride between the MFMAs of the current one).  1 (default) the measured policy,
- * 2 wherever the kernel is built, 0 off; same bits in every mode (an A/B and cross-check switch); -1: default.
- * amp_set_conv_strip_steps: column tiles per strip, 0 (default) = the policy's choice. */
-int amp_set_conv_strip(int mode);
-int amp_set_conv_strip_steps(int steps);
 
 /* Convs with several row groups (more GEMM rows than one workgroup holds) launch with the row group as the fastest grid
  * index: the row groups of one x tile run back to back on one XCD and share its L2 copy of x (same bits; 1 = default).

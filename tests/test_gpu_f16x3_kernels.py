@@ -210,115 +210,3 @@ def test_blocked_conv_switch_rejects_bad_mode():
     assert _lib.lib().amp_set_conv_blk(-1) == 0
 
 
-
-
-# ---- square Conv1d at C = 64 / 128 / 256 (unfused AMPBlock convs, the C = 256 stage): the persistent strip kernel --------
-STRIP_CASES = [
-    # C, k, dilation, B, T
-    (128, 7, 1, 6, 2100),     # BigVGAN stage 1 (bigvgan.py:137-146): 2 x 2 waves, 192-column steps, ragged last tile
-    (128, 7, 3, 6, 2100),
-    (128, 11, 5, 4, 1900),    # 50-column receptive field
-    (128, 11, 1, 3, 191),     # ONE partial tile per item
-    (128, 3, 1, 6, 2100),     # two chunks per staging round
-    (128, 3, 5, 6, 1537),
-    (128, 5, 2, 4, 1000),
-    (64, 7, 1, 6, 4100),      # 1 x 4 waves, 384-column steps
-    (64, 11, 3, 4, 3000),
-    (64, 3, 3, 4, 3000),
-    (64, 11, 1, 2, 383),
-    (256, 3, 1, 6, 1000),     # 4 x 1 waves, 96-column steps (hifigan.py:93-100 at C = 256)
-    (256, 7, 5, 6, 1000),
-    (256, 11, 3, 4, 777),
-    (256, 11, 1, 1, 1),       # T = 1
-]
-
-
-@pytest.mark.parametrize("C,k,d,B,T", STRIP_CASES)
-def test_strip_conv_bitwise(C, k, d, B, T):
-    """Same accumulator start, chunk / tap / (hh, hl, lh) order and epilogue per output element -> the same bits as the per-tile
-    kernels, however many column tiles a strip walks (1: only the prologue / flush path, 2, 5: the software-pipelined boundary); within the
-    conv tolerance of torch's fp32 conv."""
-    from amphion_amd import _lib
-    from hip_helpers import conv_forward
-
-    w = _rand(C, C, k, seed=1, scale=(C * k) ** -0.5)
-    b = _rand(C, seed=2, scale=0.1)
-    x = _rand(B, C, T, seed=3)
-    res = _rand(B, C, T, seed=4)
-    pad = (k * d - d) // 2
-    kw = dict(dilation=d, padding=pad)
-    L = _lib.lib()
-
-    def run():
-        return [conv_forward(w, b, x, **kw), conv_forward(w, b, x, slope_in=0.1, res=res, slope_out=0.2, **kw),
-                conv_forward(w, None, x, res=res, **kw), conv_forward(w, None, x, slope_in=0.1, **kw)]
-    try:
-        _lib.check(L.amp_set_conv_strip(0))
-        base = run()
-        outs = {}
-        _lib.check(L.amp_set_conv_strip(2))
-        for steps in (1, 2, 5):
-            _lib.check(L.amp_set_conv_strip_steps(steps))
-            outs[steps] = run()
-    finally:
-        _lib.check(L.amp_set_conv_strip(-1))
-        _lib.check(L.amp_set_conv_strip_steps(0))
-    for steps, o in outs.items():
-        for i, (a, c) in enumerate(zip(o, base)):
-            assert torch.isfinite(a).all(), (steps, i)
-            assert torch.equal(a, c), f"strip kernel, {steps} steps per strip, variant {i}: differs from the per-tile kernels"
-    ref = F.conv1d(x, w, b, dilation=d, padding=pad)
-    assert (outs[2][0] - ref).abs().max().item() <= 2e-5
-
-
-def _strip_generator(arch):
-    from types import SimpleNamespace as NS
-    from oracle import synth
-    if arch == "bigvgan":
-        from amphion_amd.models.vocoders.gan.generator.bigvgan import BigVGAN
-        hp = vo.bigvgan_base_hp()
-        m = BigVGAN(NS(preprocess=NS(n_mel=100, hop_size=256), model=NS(bigvgan=NS(**hp))))
-        m.load_state_dict(synth.synth_state_dict(synth.bigvgan_param_shapes(100, hp), 1234, g_gain=0.75))
-        return m.cuda().eval(), 100
-    from amphion_amd.models.vocoders.gan.generator.hifigan import HiFiGAN
-    hp = vo.hifigan_v1_hp()
-    m = HiFiGAN(NS(preprocess=NS(n_mel=80, hop_size=256), model=NS(hifigan=NS(**hp))))
-    m.load_state_dict(synth.synth_state_dict(synth.hifigan_param_shapes(80, hp), 1234))
-    return m.cuda().eval(), 80
-
-
-@pytest.mark.parametrize("arch", ["bigvgan", "hifigan"])
-def test_generators_with_and_without_the_strip_kernel(arch):
-    """Whole generators, dense and ragged: every square conv the strip kernel covers on it (mode 2: also the MRF running-sum convs and the
-    ragged tails) == the per-tile kernels, bit for bit.  The whole-block fusions are switched off so that the convs run unfused."""
-    from amphion_amd import _lib
-
-    m, n_mel = _strip_generator(arch)
-    L = _lib.lib()
-    gen = torch.Generator().manual_seed(7)
-    mel = torch.randn(3, n_mel, 40, generator=gen)
-    lens = torch.tensor([150, 211, 97, 5, 160, 64], dtype=torch.int32)
-    melr = torch.randn(6, n_mel, 211, generator=gen)
-    for i, l in enumerate(lens):
-        melr[i, :, l:] = 0
-    outs = {}
-    try:
-        _lib.check(L.amp_set_ampblock_fusion(0))
-        _lib.check(L.amp_set_resblock_fusion(0))
-        _lib.check(L.amp_set_pair_strips(0))
-        for mode, steps in ((0, 0), (2, 0), (2, 3)):
-            _lib.check(L.amp_set_conv_strip(mode))
-            _lib.check(L.amp_set_conv_strip_steps(steps))
-            with torch.no_grad():
-                outs[(mode, steps)] = (m(mel.cuda()).cpu(), m.forward_ragged(melr.cuda(), lens.cuda()).cpu())
-    finally:
-        _lib.check(L.amp_set_conv_strip(-1))
-        _lib.check(L.amp_set_conv_strip_steps(0))
-        _lib.check(L.amp_set_ampblock_fusion(-1))
-        _lib.check(L.amp_set_resblock_fusion(-1))
-        _lib.check(L.amp_set_pair_strips(-1))
-    for key in ((2, 0), (2, 3)):
-        assert torch.isfinite(outs[key][0]).all()
-        assert torch.equal(outs[key][0], outs[(0, 0)][0]), key
-        for i, l in enumerate(lens):
-            assert torch.equal(outs[key][1][i, :, : l * 256], outs[(0, 0)][1][i, :, : l * 256]), (key, i)
