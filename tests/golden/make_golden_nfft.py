@@ -7,7 +7,7 @@ CPU in the build container (needs /root/reference):
 
     python tests/golden/make_golden_nfft.py        -> tests/golden/golden_nfft.npz
 
-The input is 9 600 samples of an in-tree speech clip (stored in the file) plus a rolled, attenuated copy as a second batch item."""
+The input is 4 800 samples of an in-tree speech clip (stored in the file) plus a rolled, attenuated copy as a second batch item."""
 import os
 import sys
 
@@ -35,13 +35,13 @@ def main():
     mel_mod = mg.load_by_path("ref_utils_mel", os.path.join(mg.REF, "utils/mel.py"))
     stft_mod = mg.load_by_path("ref_utils_stft", os.path.join(mg.REF, "utils/stft.py"))
     sr, pcm = mg.read_wav(os.path.join(mg.REF, "egs/tts/VALLE/prompt_examples/260_123440_000010_000004.wav"))
-    pcm = pcm[12000 : 12000 + 9600]
+    pcm = pcm[12000 : 12000 + 4800]
     out = {"wav_pcm16": pcm}
     y1 = torch.from_numpy(pcm.astype(np.float32) / 32768.0)
     g = torch.Generator().manual_seed(23)
     for tag, (srate, nfft, hop, win, n_mel, fmin, fmax) in CASES.items():
         pp = NS(sample_rate=srate, n_fft=nfft, hop_size=hop, win_size=win, n_mel=n_mel, fmin=fmin, fmax=fmax)
-        L = (9600 // hop) * hop                       # a whole number of hops: frames == L / hop (utils/mel.py:145-164)
+        L = (4800 // hop) * hop                       # a whole number of hops: frames == L / hop (utils/mel.py:145-164)
         y = torch.stack([y1[:L], torch.roll(y1[:L], 777) * 0.5])
         out[f"{tag}_cfg"] = np.array([srate, nfft, hop, win, n_mel, fmin, -1 if fmax is None else fmax, L])
         with torch.no_grad():

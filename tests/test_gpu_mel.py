@@ -360,3 +360,58 @@ def test_out_of_range_audio_is_reported_without_stalling(capsys):
     M.extract_mel_features(y * 0.1, pp)
     M.flush_range_warnings()
     assert capsys.readouterr().out == ""
+
+
+# ---- the transform lengths round 5 added, against outputs of the REAL reference (tests/golden/make_golden_nfft.py) -------------
+NFFT_TAGS = ["n1920", "n2048", "n1001", "n1021", "n400w320"]
+
+
+@pytest.fixture(scope="module")
+def gn():
+    import os
+
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_nfft.npz"))
+
+
+@pytest.mark.parametrize("tag", NFFT_TAGS)
+def test_mel_front_end_new_lengths_golden(gn, tag):
+    """extract_mel_features / extract_linear_features / amplitude_phase_spectrum (utils/mel.py:20-52,111-170) at n_fft 1920 / 2048 / 1001 / 1021 / 400:
+    the HIP front end against the reference's own outputs."""
+    from test_oracle_nfft import nfft_case
+
+    from amphion_amd.utils import mel as M
+
+    pp, y = nfft_case(gn, tag)
+    _check_logmel(M.extract_mel_features(y.cuda(), pp).cpu().numpy(), gn[f"{tag}_mel"], f"extract_mel_features {tag} vs reference")
+    lin = M.extract_linear_features(y[:1].cuda(), pp).cpu().numpy()
+    ref = gn[f"{tag}_linear"]
+    assert lin.shape == ref.shape
+    assert np.abs(lin - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    la, ph, re, im = (t.cpu().numpy() for t in M.amplitude_phase_spectrum(y.cuda(), pp))
+    scale = max(1.0, float(np.abs(gn[f"{tag}_re"]).max()))
+    assert np.abs(re - gn[f"{tag}_re"]).max() <= 2e-5 * scale
+    assert np.abs(im - gn[f"{tag}_im"]).max() <= 2e-5 * scale
+    big = np.exp(gn[f"{tag}_logamp"]) > 1e-3
+    assert np.abs(la - gn[f"{tag}_logamp"])[big].max() <= 5e-2
+
+
+@pytest.mark.parametrize("tag", NFFT_TAGS)
+def test_stft_new_lengths_golden(gn, tag):
+    """STFT.transform / STFT.inverse (utils/stft.py:152-222) at the same lengths against the reference's own outputs."""
+    from test_oracle_nfft import nfft_case
+
+    from amphion_amd.utils.stft import STFT
+
+    pp, y = nfft_case(gn, tag)
+    st = STFT(pp.n_fft, pp.hop_size, pp.win_size)
+    mag, phase = st.transform(y.cuda())
+    ref = gn[f"{tag}_stft_mag"]
+    assert tuple(mag.shape) == ref.shape
+    assert np.abs(mag.cpu().numpy() - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    big = ref > 1e-2 * ref.max()
+    d = np.angle(np.exp(1j * (phase.cpu().numpy() - gn[f"{tag}_stft_phase"])))
+    assert np.abs(d[big]).max() <= 1e-3
+    wav = st.inverse(torch.from_numpy(gn[f"{tag}_inv_mag"]).cuda(), torch.from_numpy(gn[f"{tag}_inv_phase"]).cuda()).cpu().numpy()
+    ref = gn[f"{tag}_inv_wav"]
+    assert wav.shape == ref.shape
+    assert np.abs(wav - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
