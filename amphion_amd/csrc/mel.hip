@@ -678,6 +678,354 @@ static hipError_t mel1024_device_init(hipStream_t stream, bool have_stream) {
     return hipSuccess;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wave-per-frame front end for n_fft = 128 P with P = 16 | 15: n_fft = 2048 and 1920 = 2^7 * 3 * 5 -- the n_fft of 24 of the reference's 38 JSON
+// configs (egs/vocoder/vocos/emilia_singnet.json:15; utils/mel.py:145-169) -- in mel1024_kernel's scheme (round 6; mel_mixed_kernel, one WORKGROUP
+// per frame with every pass through LDS, took 0.99 / 0.86 ms for 64 x 65 536 samples where 1024 takes 0.041):
+//   one WAVE per frame; the real frame as M = 64 P complex points z[n] = x[2n] + i x[2n + 1]; lane j loads z[j + 64 q], q < P, and runs pass 0 -- a
+//   radix-P butterfly (16 = 2 x 8; 15 = 3 x 5) -- in registers; two radix-8 passes (8 P butterflies: two per lane) through the wave's own LDS
+//   exchange buffer (Stockham autosort: the result arrives in natural order); the real-FFT split X[k] = E[k] - i W^k O[k] from Z[k] and Z[M - k];
+//   magnitudes into the wave's LDS row; the band-limited mel projection from packed filter rows in LDS; 32-frame workgroups write whole 128-B
+//   segments of every mel channel.  Twiddles: ONE table exp(-2 pi i n / n_fft) per workgroup in LDS, built from sincospi in double precision.
+// Same semantics as the other kernels (torch.stft, center = False after the reflection padding): golden vectors of the REAL reference at both
+// lengths (tests/golden/golden_nfft.npz) and the oracle.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+// 3-point DFT (forward), natural order
+__device__ __forceinline__ void dft3(float2& a0, float2& a1, float2& a2) {
+    const float s = 0.86602540378443864676f;
+    const float2 t = cadd(a1, a2), d = csub(a1, a2);
+    const float2 m = make_float2(a0.x - 0.5f * t.x, a0.y - 0.5f * t.y);
+    a0 = cadd(a0, t);
+    a1 = make_float2(m.x + s * d.y, m.y - s * d.x);      // m - i s d
+    a2 = make_float2(m.x - s * d.y, m.y + s * d.x);      // m + i s d
+}
+
+// 5-point DFT (forward), natural order
+__device__ __forceinline__ void dft5(float2& a0, float2& a1, float2& a2, float2& a3, float2& a4) {
+    const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;     // cos(2 pi / 5), cos(4 pi / 5)
+    const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;      // sin(2 pi / 5), sin(4 pi / 5)
+    const float2 t1 = cadd(a1, a4), t2 = cadd(a2, a3), t3 = csub(a1, a4), t4 = csub(a2, a3);
+    const float2 p1 = make_float2(a0.x + c1 * t1.x + c2 * t2.x, a0.y + c1 * t1.y + c2 * t2.y);
+    const float2 p2 = make_float2(a0.x + c2 * t1.x + c1 * t2.x, a0.y + c2 * t1.y + c1 * t2.y);
+    const float2 q1 = make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
+    const float2 q2 = make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
+    a0 = cadd(a0, cadd(t1, t2));
+    a1 = make_float2(p1.x + q1.y, p1.y - q1.x);          // p1 - i q1
+    a4 = make_float2(p1.x - q1.y, p1.y + q1.x);          // p1 + i q1
+    a2 = make_float2(p2.x + q2.y, p2.y - q2.x);
+    a3 = make_float2(p2.x - q2.y, p2.y + q2.x);
+}
+
+// in-place P-point DFT of v[0 .. P), natural order in and out: P = 16 as two 8-point DFTs + one radix-2 stage, P = 15 as 3 x 5 (Cooley-Tukey)
+template <int P>
+__device__ __forceinline__ void dftP(float2 (&v)[P]);
+
+template <>
+__device__ __forceinline__ void dftP<16>(float2 (&v)[16]) {
+    float2 e[8], o[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { e[q] = v[2 * q]; o[q] = v[2 * q + 1]; }
+    dft8(e);
+    dft8(o);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float2 t = cmul(o[k], make_float2(kC16[k], -kS16[k]));   // exp(-2 pi i k / 16)
+        v[k] = cadd(e[k], t);
+        v[k + 8] = csub(e[k], t);
+    }
+}
+
+template <>
+__device__ __forceinline__ void dftP<15>(float2 (&v)[15]) {
+    // n = 5 n1 + n2, k = k1 + 3 k2:  X[k1 + 3 k2] = sum_n2 w5^(n2 k2) [ w15^(n2 k1) sum_n1 w3^(n1 k1) x[5 n1 + n2] ]
+    float2 b[5][3];
+#pragma unroll
+    for (int n2 = 0; n2 < 5; ++n2) {
+        b[n2][0] = v[n2]; b[n2][1] = v[5 + n2]; b[n2][2] = v[10 + n2];
+        dft3(b[n2][0], b[n2][1], b[n2][2]);
+    }
+    // exp(-2 pi i m / 15), m = n2 * k1
+    constexpr float c15[9] = {1.f, 0.91354545764260089550f, 0.66913060635885821383f, 0.30901699437494742410f, -0.10452846326765347140f,
+                              -0.5f, -0.80901699437494742410f, -0.97814760073380563793f, -0.97814760073380563793f};
+    constexpr float s15[9] = {0.f, 0.40673664307580020775f, 0.74314482547739423501f, 0.95105651629515357212f, 0.99452189536827333692f,
+                              0.86602540378443864676f, 0.58778525229247312917f, 0.20791169081775933710f, -0.20791169081775933710f};
+#pragma unroll
+    for (int n2 = 1; n2 < 5; ++n2)
+#pragma unroll
+        for (int k1 = 1; k1 < 3; ++k1) {
+            const int m = n2 * k1;
+            b[n2][k1] = cmul(b[n2][k1], make_float2(c15[m], -s15[m]));
+        }
+#pragma unroll
+    for (int k1 = 0; k1 < 3; ++k1) {
+        dft5(b[0][k1], b[1][k1], b[2][k1], b[3][k1], b[4][k1]);
+#pragma unroll
+        for (int k2 = 0; k2 < 5; ++k2) v[k1 + 3 * k2] = b[k2][k1];
+    }
+}
+
+constexpr int MELW_WCAP = 4096;    // packed filter weights in LDS (every band padded to a multiple of 8)
+template <int P>
+struct MelW {
+    static constexpr int M = 64 * P, N = 2 * M, BINS = M + 1;
+    static constexpr int XW = M + M / 16 + 8;                 // exchange buffer of a wave, float2: P = 16 pads one slot in 16 (pass 0 writes at stride P)
+    static constexpr int MAGROW = ((BINS + 7) & ~7) + 8;      // magnitude row of a wave: the packed bands read up to 7 bins past a band's end, as zeros
+    static __host__ __device__ constexpr size_t lds_floats(int n_mel) {
+        return (size_t)2 * N + (size_t)(MELW_WCAP + 4) + (size_t)MEL_WAVES * MAGROW + (size_t)2 * MEL_WAVES * XW
+               + (size_t)n_mel * (MEL_FPB + 1) + (size_t)(1 + (2 * n_mel + 2) / 2);
+    }
+};
+
+template <int P>
+__global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_wave_kernel(const float* __restrict__ wav, const int* __restrict__ lens,
+                                                                   int L, int F, int hop, int pad, int n_mel, float mag_eps,
+                                                                   float log_clip, const float* __restrict__ window,
+                                                                   const float* __restrict__ melbasis,
+                                                                   const int* __restrict__ bands, float* __restrict__ mel,
+                                                                   float* __restrict__ mag, float* __restrict__ re_out,
+                                                                   float* __restrict__ im_out, const MelRange rng) {
+    constexpr int M = MelW<P>::M, N = MelW<P>::N, BINS = MelW<P>::BINS, XW = MelW<P>::XW, MAGROW = MelW<P>::MAGROW;
+    constexpr int I8 = 8 * P;                       // radix-8 butterflies per pass
+    constexpr int NU = (I8 + 63) / 64;              // ... per lane
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    mel_range_begin(rng);
+    float2* const twl = reinterpret_cast<float2*>(smem);                      // [N] exp(-2 pi i n / N)
+    float* const wl = smem + 2 * N;                                           // [MELW_WCAP + 4] packed filter weights
+    float* const magl = wl + MELW_WCAP + 4;                                   // [MEL_WAVES][MAGROW]
+    float2* const xch = reinterpret_cast<float2*>(magl + MEL_WAVES * MAGROW); // [MEL_WAVES][XW]
+    float* const melt = magl + MEL_WAVES * MAGROW + 2 * MEL_WAVES * XW;       // [n_mel][MEL_FPB + 1]
+    const int tid = threadIdx.x;
+    const int j = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fblocks = (F + MEL_FPB - 1) / MEL_FPB;
+    const int b = blockIdx.x / fblocks;
+    const int f0 = (blockIdx.x - b * fblocks) * MEL_FPB;
+    const float* wb = wav + (size_t)b * L;
+    int Li = L, Fi = F;        // ragged batch, see mel1024_kernel
+    if (lens) {
+        Li = lens[b] < L ? lens[b] : L;
+        Fi = Li <= pad ? 0 : (Li + 2 * pad - N) / hop + 1;
+        Fi = Fi < F ? Fi : F;
+    }
+    if (f0 >= Fi) return;   // workgroup-uniform
+
+    for (int n = tid; n < N; n += 64 * MEL_WAVES) {
+        double sn, cs;
+        sincospi(2.0 * (double)n / (double)N, &sn, &cs);
+        twl[n] = make_float2((float)cs, (float)-sn);
+    }
+    // packed filter rows, as in mel1024_kernel (same products in the same order as the loop over the global rows)
+    int* const total_p = reinterpret_cast<int*>(melt + n_mel * (MEL_FPB + 1));
+    unsigned short* const offs = reinterpret_cast<unsigned short*>(total_p + 1);
+    unsigned short* const los = offs + n_mel + 1;
+    bool packed = false;
+    if (mel && bands) {
+        if (w == 0) {
+            int wd[4], sum = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int m = 4 * j + t;
+                wd[t] = 0;
+                if (m < n_mel) {
+                    const int lo = bands[2 * m], hi = bands[2 * m + 1];
+                    wd[t] = hi > lo ? (hi - lo + 7) & ~7 : 0;
+                    los[m] = (unsigned short)lo;
+                }
+                sum += wd[t];
+            }
+            int incl = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(incl, d, 64);
+                if (j >= d) incl += o;
+            }
+            int base = incl - sum;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int m = 4 * j + t;
+                if (m <= n_mel) offs[m] = (unsigned short)base;
+                base += wd[t];
+            }
+            if (j == 63) { *total_p = incl; if (n_mel == MEL_MAXMEL) offs[n_mel] = (unsigned short)incl; }
+        }
+        for (int e = BINS + j; e < MAGROW; e += 64) magl[w * MAGROW + e] = 0.f;      // the row's pad: read under a zero weight
+        __syncthreads();
+        const int total = *total_p;
+        packed = total <= MELW_WCAP;
+        if (packed) {
+            for (int e = tid; e < total; e += 64 * MEL_WAVES) {
+                int ml = 0, mh = n_mel;
+                while (mh - ml > 1) {
+                    const int mid = (ml + mh) >> 1;
+                    if ((int)offs[mid] <= e) ml = mid; else mh = mid;
+                }
+                const int k = (int)los[ml] + (e - (int)offs[ml]);
+                wl[e] = k < bands[2 * ml + 1] ? melbasis[(size_t)ml * BINS + k] : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+
+    auto phys = [](int n) { return (P % 2 == 0) ? n + (n >> 4) : n; };
+    const float2* win = reinterpret_cast<const float2*>(window) + j;
+    float2* xw = xch + w * XW;
+    float* mg = magl + w * MAGROW;
+    float rlo = 0.f, rhi = 0.f;
+
+    for (int fi = 0; fi < MEL_FPW; ++fi) {
+        const int fl = w * MEL_FPW + fi;
+        const int f = f0 + fl;
+        if (f >= Fi) break;                         // wave-uniform
+        float2 v[P];
+        const int s0 = f * hop - pad + 2 * j;
+        {
+            float2 wq[P];
+#pragma unroll
+            for (int q = 0; q < P; ++q) wq[q] = win[64 * q];
+            if (s0 - 2 * j >= 0 && f * hop - pad + N <= Li) {          // interior frame (wave-uniform): no reflection
+#pragma unroll
+                for (int q = 0; q < P; ++q) v[q] = reinterpret_cast<const Float2U*>(wb + s0 + 128 * q)->v;
+                asm volatile("; interior frame: loads issued" ::: "memory");
+            } else {
+#pragma unroll
+                for (int q = 0; q < P; ++q) {
+                    const int sidx = s0 + 128 * q;
+                    v[q] = make_float2(wb[reflect_index(sidx, Li)], wb[reflect_index(sidx + 1, Li)]);
+                }
+                asm volatile("; edge frame: loads issued" ::: "memory");
+            }
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                rlo = fminf(rlo, fminf(v[q].x, v[q].y)); rhi = fmaxf(rhi, fmaxf(v[q].x, v[q].y));
+                v[q] = make_float2(__fmul_rn(v[q].x, wq[q].x), __fmul_rn(v[q].y, wq[q].y));
+            }
+        }
+        // pass 0 (radix P, Ns = 1): no twiddles; out[P j + q]
+        dftP<P>(v);
+#pragma unroll
+        for (int q = 0; q < P; ++q) xw[phys(P * j + q)] = v[q];
+        __builtin_amdgcn_wave_barrier();
+        // passes 1 and 2 (radix 8; Ns = P, then 8 P): butterfly i = j + 64 u reads in[i + 8 P q], twiddle exp(-2 pi i q k / (8 Ns)), k = i mod Ns,
+        // writes out[8 (i - k) + k + Ns q]; the second pass leaves Z in natural order
+#pragma unroll
+        for (int pass = 1; pass <= 2; ++pass) {
+            const int Ns = pass == 1 ? P : I8;
+            const int tstep = N / (8 * Ns);          // table index of exp(-2 pi i / (8 Ns)): 16, then 2
+            float2 a[NU][8];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int i = j + 64 * u;
+                if (i < I8) {
+                    const int k = i % Ns;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a[u][q] = xw[phys(i + I8 * q)];
+#pragma unroll
+                    for (int q = 1; q < 8; ++q) a[u][q] = cmul(a[u][q], twl[tstep * q * k]);
+                    dft8(a[u]);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int i = j + 64 * u;
+                if (i < I8) {
+                    const int k = i % Ns;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) xw[phys(8 * (i - k) + k + Ns * q)] = a[u][q];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // real-FFT split, bins k = j + 64 t: X[k] = E - i W^k O from Z[k] and Z[M - k]; bin M (Nyquist) from Z[0]
+        const size_t ob = ((size_t)b * BINS) * F + f;
+#pragma unroll
+        for (int t = 0; t < P; ++t) {
+            const int k = j + 64 * t;
+            const float2 z = xw[phys(k)];
+            const float2 zp = xw[phys(k == 0 ? 0 : M - k)];
+            const float2 e = make_float2(0.5f * (z.x + zp.x), 0.5f * (z.y - zp.y));       // (Z + conj Zp) / 2
+            const float2 o = make_float2(0.5f * (z.x - zp.x), 0.5f * (z.y + zp.y));       // (Z - conj Zp) / 2
+            const float2 tt = cmul(twl[k], o);
+            const float2 x = make_float2(e.x + tt.y, e.y - tt.x);
+            const float m = sqrtf(x.x * x.x + x.y * x.y + mag_eps);
+            mg[k] = m;
+            if (mag) mag[ob + (size_t)k * F] = m;
+            if (re_out) re_out[ob + (size_t)k * F] = x.x;
+            if (im_out) im_out[ob + (size_t)k * F] = x.y;
+            if (k == 0) {
+                const float xn = z.x - z.y;
+                const float mn = sqrtf(xn * xn + mag_eps);
+                mg[M] = mn;
+                if (mag) mag[ob + (size_t)M * F] = mn;
+                if (re_out) re_out[ob + (size_t)M * F] = xn;
+                if (im_out) im_out[ob + (size_t)M * F] = 0.f;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (mel && packed) {
+            for (int m0 = j; m0 < n_mel; m0 += 128) {
+                const int m1 = m0 + 64;
+                const int oa = offs[m0], na = (int)offs[m0 + 1] - oa;
+                int ob2 = 0, nb = 0, lb = 0;
+                if (m1 < n_mel) { ob2 = offs[m1]; nb = (int)offs[m1 + 1] - ob2; lb = los[m1]; }
+                const int nt = na + nb;
+                const float* pw = wl + oa;
+                const float* pg = mg + (int)los[m0];
+                float acc = 0.f, acca = 0.f;
+                for (int i = 0; i < nt; i += 8) {
+                    if (i == na) { acca = acc; acc = 0.f; pw = wl + ob2; pg = mg + lb; }
+                    const float4 w4 = *reinterpret_cast<const float4*>(pw), w8 = *reinterpret_cast<const float4*>(pw + 4);
+                    float x[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) x[u] = pg[u];
+                    acc = fmaf(w4.x, x[0], acc); acc = fmaf(w4.y, x[1], acc); acc = fmaf(w4.z, x[2], acc); acc = fmaf(w4.w, x[3], acc);
+                    acc = fmaf(w8.x, x[4], acc); acc = fmaf(w8.y, x[5], acc); acc = fmaf(w8.z, x[6], acc); acc = fmaf(w8.w, x[7], acc);
+                    pw += 8; pg += 8;
+                }
+                float accb = 0.f;
+                if (nb > 0) accb = acc; else acca = acc;
+                if (log_clip > 0.f) { acca = logf(fmaxf(acca, log_clip)); accb = logf(fmaxf(accb, log_clip)); }
+                melt[m0 * (MEL_FPB + 1) + fl] = acca;
+                if (m1 < n_mel) melt[m1 * (MEL_FPB + 1) + fl] = accb;
+            }
+        } else if (mel) {
+            for (int m = j; m < n_mel; m += 64) {
+                const int lo = bands ? bands[2 * m] : 0;
+                const int hi = bands ? bands[2 * m + 1] : BINS;
+                const float* row = melbasis + (size_t)m * BINS;
+                float acc = 0.f;
+                for (int k = lo; k < hi; ++k) acc = fmaf(row[k], mg[k], acc);
+                if (log_clip > 0.f) acc = logf(fmaxf(acc, log_clip));
+                melt[m * (MEL_FPB + 1) + fl] = acc;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    mel_range_end(rng, rlo, rhi);
+    if (!mel) return;
+    __syncthreads();
+    const int nfr = (Fi - f0) < MEL_FPB ? (Fi - f0) : MEL_FPB;
+    for (int idx = tid; idx < n_mel * MEL_FPB; idx += 64 * MEL_WAVES) {
+        const int m = idx >> 5, fl = idx & 31;
+        if (fl < nfr) mel[((size_t)b * n_mel + m) * F + f0 + fl] = melt[m * (MEL_FPB + 1) + fl];
+    }
+}
+
+template <int P>
+static hipError_t launch_mel_wave(const amp_mel_desc& d, const float* wav, const int* lens, int B, int L, int F, int pad, int n_mel,
+                                  const float* window, const float* melbasis, float* mel, float* mag, float* re, float* im, const MelRange& rng,
+                                  hipStream_t stream) {
+    const size_t lds = MelW<P>::lds_floats(n_mel) * sizeof(float);
+    if (hipError_t e = ensure_dynamic_lds<&mel_wave_kernel<P>>(160 * 1024); e != hipSuccess) return e;
+    const int fblocks = (F + MEL_FPB - 1) / MEL_FPB;
+    hipLaunchKernelGGL(mel_wave_kernel<P>, dim3((unsigned)((size_t)B * fblocks)), dim3(64 * MEL_WAVES), lds, stream, wav, lens, L, F,
+                       d.hop_size, pad, n_mel, d.mag_eps, d.log_clip, window, melbasis, static_cast<const int*>(d.mel_bands_dev), mel, mag, re, im, rng);
+    return hipGetLastError();
+}
+
 hipError_t launch_mel(const amp_mel_desc& d, const float* wav, const int* lens, int B, int L, int F, const float* window,
                       const float* melbasis, float* mel, float* mag, float* re, float* im, hipStream_t stream) {
     const int pad = d.pad_mode == 0 ? (d.n_fft - d.hop_size) / 2 : d.n_fft / 2;
@@ -695,6 +1043,15 @@ hipError_t launch_mel(const amp_mel_desc& d, const float* wav, const int* lens, 
                            d.hop_size, pad, n_mel, d.mag_eps, d.log_clip, window, melbasis,
                            static_cast<const int*>(d.mel_bands_dev), mel, mag, re, im, rng);
         hipError_t e = hipGetLastError();
+        if (e == hipSuccess && d.range_dev && d.range_host)
+            e = hipMemcpyAsync(d.range_host, d.range_dev, 3 * sizeof(int), hipMemcpyDeviceToHost, stream);
+        return e;
+    }
+    if ((d.n_fft == 2048 || d.n_fft == 1920) && (pad & 1) == 0 && (d.hop_size & 1) == 0 && pad >= 0 &&
+        (d.n_fft == 2048 ? MelW<16>::lds_floats(n_mel) : MelW<15>::lds_floats(n_mel)) * sizeof(float) <= 160 * 1024) {
+        // wave-per-frame radix-16 / radix-15 + 8 x 8 real FFT (round 6)
+        hipError_t e = d.n_fft == 2048 ? launch_mel_wave<16>(d, wav, lens, B, L, F, pad, n_mel, window, melbasis, mel, mag, re, im, rng, stream)
+                                       : launch_mel_wave<15>(d, wav, lens, B, L, F, pad, n_mel, window, melbasis, mel, mag, re, im, rng, stream);
         if (e == hipSuccess && d.range_dev && d.range_host)
             e = hipMemcpyAsync(d.range_host, d.range_dev, 3 * sizeof(int), hipMemcpyDeviceToHost, stream);
         return e;
