@@ -679,7 +679,7 @@ static hipError_t mel1024_device_init(hipStream_t stream, bool have_stream) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Wave-per-frame front end for n_fft = 128 P with P = 16 | 15: n_fft = 2048 and 1920 = 2^7 * 3 * 5 -- the n_fft of 24 of the reference's 38 JSON
+// Wave-per-frame front end for n_fft = 128 P with P = 16 | 15 | 4: n_fft = 2048, 512 and 1920 = 2^7 * 3 * 5 -- the n_fft of 24 of the reference's 38 JSON
 // configs (egs/vocoder/vocos/emilia_singnet.json:15; utils/mel.py:145-169) -- in mel1024_kernel's scheme (round 6; mel_mixed_kernel, one WORKGROUP
 // per frame with every pass through LDS, took 0.99 / 0.86 ms for 64 x 65 536 samples where 1024 takes 0.041):
 //   one WAVE per frame; the real frame as M = 64 P complex points z[n] = x[2n] + i x[2n + 1]; lane j loads z[j + 64 q], q < P, and runs pass 0 -- a
@@ -722,6 +722,18 @@ __device__ __forceinline__ void dft5(float2& a0, float2& a1, float2& a2, float2&
 // in-place P-point DFT of v[0 .. P), natural order in and out: P = 16 as two 8-point DFTs + one radix-2 stage, P = 15 as 3 x 5 (Cooley-Tukey)
 template <int P>
 __device__ __forceinline__ void dftP(float2 (&v)[P]);
+
+template <>
+__device__ __forceinline__ void dftP<4>(float2 (&v)[4]) {
+    const float2 a0 = cadd(v[0], v[2]), a1 = csub(v[0], v[2]), a2 = cadd(v[1], v[3]), a3 = csub(v[1], v[3]);
+    v[0] = cadd(a0, a2);
+    v[2] = csub(a0, a2);
+    v[1] = make_float2(a1.x + a3.y, a1.y - a3.x);       // a1 - i a3
+    v[3] = make_float2(a1.x - a3.y, a1.y + a3.x);       // a1 + i a3
+}
+
+template <>
+__device__ __forceinline__ void dftP<8>(float2 (&v)[8]) { dft8(v); }
 
 template <>
 __device__ __forceinline__ void dftP<16>(float2 (&v)[16]) {
@@ -771,7 +783,9 @@ constexpr int MELW_WCAP = 4096;    // packed filter weights in LDS (every band p
 template <int P>
 struct MelW {
     static constexpr int M = 64 * P, N = 2 * M, BINS = M + 1;
-    static constexpr int XW = M + M / 16 + 8;                 // exchange buffer of a wave, float2: P = 16 pads one slot in 16 (pass 0 writes at stride P)
+    static constexpr int PSH = P == 16 ? 4 : P == 8 ? 3 : P == 4 ? 2 : 31;   // a power-of-two P pads one slot in P: pass 0 writes at stride P (bank conflicts)
+    static constexpr int XW = M + (M >> PSH) + 8;             // exchange buffer of a wave, float2
+    static __host__ __device__ constexpr int phys(int n) { return n + (n >> PSH); }
     static constexpr int MAGROW = ((BINS + 7) & ~7) + 8;      // magnitude row of a wave: the packed bands read up to 7 bins past a band's end, as zeros
     static __host__ __device__ constexpr size_t lds_floats(int n_mel) {
         return (size_t)2 * N + (size_t)(MELW_WCAP + 4) + (size_t)MEL_WAVES * MAGROW + (size_t)2 * MEL_WAVES * XW
@@ -869,7 +883,7 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_wave_kernel(const float
     }
     __syncthreads();
 
-    auto phys = [](int n) { return (P % 2 == 0) ? n + (n >> 4) : n; };
+    auto phys = [](int n) { return MelW<P>::phys(n); };
     const float2* win = reinterpret_cast<const float2*>(window) + j;
     float2* xw = xch + w * XW;
     float* mg = magl + w * MAGROW;
@@ -1047,11 +1061,12 @@ hipError_t launch_mel(const amp_mel_desc& d, const float* wav, const int* lens, 
             e = hipMemcpyAsync(d.range_host, d.range_dev, 3 * sizeof(int), hipMemcpyDeviceToHost, stream);
         return e;
     }
-    if ((d.n_fft == 2048 || d.n_fft == 1920) && (pad & 1) == 0 && (d.hop_size & 1) == 0 && pad >= 0 &&
-        (d.n_fft == 2048 ? MelW<16>::lds_floats(n_mel) : MelW<15>::lds_floats(n_mel)) * sizeof(float) <= 160 * 1024) {
-        // wave-per-frame radix-16 / radix-15 + 8 x 8 real FFT (round 6)
+    if ((d.n_fft == 2048 || d.n_fft == 1920 || d.n_fft == 512) && (pad & 1) == 0 && (d.hop_size & 1) == 0 && pad >= 0 && n_mel <= MEL_MAXMEL &&
+        (d.n_fft == 2048 ? MelW<16>::lds_floats(n_mel) : d.n_fft == 1920 ? MelW<15>::lds_floats(n_mel) : MelW<4>::lds_floats(n_mel)) * sizeof(float) <= 160 * 1024) {
+        // wave-per-frame radix-16 / radix-15 / radix-4 + 8 x 8 real FFT (round 6)
         hipError_t e = d.n_fft == 2048 ? launch_mel_wave<16>(d, wav, lens, B, L, F, pad, n_mel, window, melbasis, mel, mag, re, im, rng, stream)
-                                       : launch_mel_wave<15>(d, wav, lens, B, L, F, pad, n_mel, window, melbasis, mel, mag, re, im, rng, stream);
+                       : d.n_fft == 1920 ? launch_mel_wave<15>(d, wav, lens, B, L, F, pad, n_mel, window, melbasis, mel, mag, re, im, rng, stream)
+                                         : launch_mel_wave<4>(d, wav, lens, B, L, F, pad, n_mel, window, melbasis, mel, mag, re, im, rng, stream);
         if (e == hipSuccess && d.range_dev && d.range_host)
             e = hipMemcpyAsync(d.range_host, d.range_dev, 3 * sizeof(int), hipMemcpyDeviceToHost, stream);
         return e;
@@ -1213,9 +1228,137 @@ __global__ __launch_bounds__(256) void istft_frames_mixed_kernel(const float* __
     for (int n = tid; n < n_fft; n += 256) fr[n] = in[n].x * sc * window[n];
 }
 
+// Wave-per-frame INVERSE real FFT for n_fft = 128 P (built for P = 15: n_fft = 1920; round 6: the frames of STFT.inverse, utils/stft.py:183-222, and of
+// the mel-loss gradient ran a full complex mixed-radix transform of n_fft points per WORKGROUP; P = 4 | 8 | 16 work and are level with the radix-2 kernel): the
+// Hermitian spectrum X[0 .. M] -> Z[k] = E[k] + i W^-k D[k] with E = (X[k] + conj X[M - k]) / 2, D = (X[k] - conj X[M - k]) / 2 -- the inverse of
+// mel_wave_kernel's split --, z = IDFT_M(Z) = conj(DFT_M(conj Z)) / M through the same three passes, x[2n] = Re z[n], x[2n + 1] = Im z[n],
+// times the window and inv_scale.  (irfft ignores Im X[0] and Im X[M]: zero rows of the pseudo-inverse basis.)
+template <int P>
+__global__ __launch_bounds__(64 * MEL_WAVES, 2) void istft_wave_kernel(const float* __restrict__ mag, const float* __restrict__ phase, int polar,
+                                                                     int F, long long nframes, float inv_scale,
+                                                                     const float* __restrict__ window, float* __restrict__ frames) {
+    constexpr int M = MelW<P>::M, N = MelW<P>::N, BINS = MelW<P>::BINS, XW = MelW<P>::XW;
+    constexpr int I8 = 8 * P, NU = (I8 + 63) / 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float2* const twl = reinterpret_cast<float2*>(smem);                      // [N] exp(-2 pi i n / N)
+    float2* const xch = twl + N;                                              // [MEL_WAVES][XW]
+    const int tid = threadIdx.x;
+    const int j = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int n = tid; n < N; n += 64 * MEL_WAVES) {
+        double sn, cs;
+        sincospi(2.0 * (double)n / (double)N, &sn, &cs);
+        twl[n] = make_float2((float)cs, (float)-sn);
+    }
+    __syncthreads();
+    auto phys = [](int n) { return MelW<P>::phys(n); };
+    float2* xw = xch + w * XW;
+    for (int fi = 0; fi < MEL_FPW; ++fi) {
+        const long long gf = (long long)blockIdx.x * MEL_FPB + w * MEL_FPW + fi;    // flat frame index b * F + f
+        if (gf >= nframes) break;                                                   // wave-uniform
+        const long long b = gf / F;
+        const int f = (int)(gf - b * F);
+        // X[k], k = j + 64 q (and k = M by lane 0), into the exchange buffer as complex numbers
+        auto load_bin = [&](int k) {
+            const size_t o = ((size_t)b * BINS + k) * F + f;
+            float re, im;
+            if (polar) {
+                const float m = mag[o];
+                float sn, cs;
+                sincosf(phase[o], &sn, &cs);
+                re = m * cs; im = m * sn;
+            } else {
+                re = mag[o]; im = phase[o];
+            }
+            if (k == 0 || k == M) im = 0.f;
+            return make_float2(re, im);
+        };
+#pragma unroll 4
+        for (int q = 0; q < P; ++q) xw[phys(j + 64 * q)] = load_bin(j + 64 * q);     // (four at a time: sixteen sincosf side by side spill)
+        if (j == 0) xw[phys(M)] = load_bin(M);     // (slot M: inside the buffer's 8 spare entries)
+        __builtin_amdgcn_wave_barrier();
+        float2 v[P];
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            const int k = j + 64 * q;
+            const float2 xq = xw[phys(k)];
+            const float2 xp = xw[phys(M - k)];                                         // X[M - k] (k = 0: X[M])
+            const float2 e = make_float2(0.5f * (xq.x + xp.x), 0.5f * (xq.y - xp.y));  // (X[k] + conj X[M - k]) / 2
+            const float2 dd = make_float2(0.5f * (xq.x - xp.x), 0.5f * (xq.y + xp.y)); // (X[k] - conj X[M - k]) / 2
+            const float2 tw = twl[k];                                                  // W^k; W^-k = conj
+            const float2 wd = make_float2(tw.x * dd.x + tw.y * dd.y, tw.x * dd.y - tw.y * dd.x);   // W^-k D
+            const float2 z = make_float2(e.x - wd.y, e.y + wd.x);                      // E + i W^-k D
+            v[q] = make_float2(z.x, -z.y);                                             // conj Z
+        }
+        __builtin_amdgcn_wave_barrier();
+        dftP<P>(v);
+#pragma unroll
+        for (int q = 0; q < P; ++q) xw[phys(P * j + q)] = v[q];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int pass = 1; pass <= 2; ++pass) {
+            const int Ns = pass == 1 ? P : I8;
+            const int tstep = N / (8 * Ns);
+            float2 a[NU][8];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int i = j + 64 * u;
+                if (i < I8) {
+                    const int k = i % Ns;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a[u][q] = xw[phys(i + I8 * q)];
+#pragma unroll
+                    for (int q = 1; q < 8; ++q) a[u][q] = cmul(a[u][q], twl[tstep * q * k]);
+                    dft8(a[u]);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int i = j + 64 * u;
+                if (i < I8) {
+                    const int k = i % Ns;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) xw[phys(8 * (i - k) + k + Ns * q)] = a[u][q];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // z[n] = conj(Y[n]) / M: x[2n] = Y.x / M, x[2n + 1] = -Y.y / M; times window and scale; one 8-byte store per lane: whole 512-B rows
+        const float sc = inv_scale / (float)M;
+        float2* fr = reinterpret_cast<float2*>(frames + (size_t)gf * N);
+        const float2* win = reinterpret_cast<const float2*>(window);
+#pragma unroll
+        for (int t = 0; t < P; ++t) {
+            const int n = j + 64 * t;
+            const float2 y = xw[phys(n)];
+            const float2 wn = win[n];
+            fr[n] = make_float2(y.x * sc * wn.x, -y.y * sc * wn.y);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int P>
+static hipError_t launch_istft_wave(const float* a, const float* b, int polar, int B, int F, float inv_scale, const float* window, float* frames,
+                                    hipStream_t stream) {
+    const size_t lds = ((size_t)MelW<P>::N + (size_t)MEL_WAVES * MelW<P>::XW) * sizeof(float2);
+    if (hipError_t e = ensure_dynamic_lds<&istft_wave_kernel<P>>(lds); e != hipSuccess) return e;
+    const long long nframes = (long long)B * F;
+    hipLaunchKernelGGL(istft_wave_kernel<P>, dim3((unsigned)((nframes + MEL_FPB - 1) / MEL_FPB)), dim3(64 * MEL_WAVES), lds, stream, a, b, polar, F,
+                       nframes, inv_scale, window, frames);
+    return hipGetLastError();
+}
+
 // irfft(spectrum) * window * inv_scale / n_fft per frame: the radix-2 kernel for powers of two, the mixed-radix one otherwise
 static hipError_t launch_istft_frames(int n_fft, const float* a, const float* b, int polar, int B, int F, float inv_scale, const float* window,
                                       float* frames, hipStream_t stream) {
+    // n_fft = 1920: the wave-per-frame kernel (needs 8-byte aligned frames and window: hipMalloc'ed tensors always are).  Measured, same box, alternating
+    // (profiles/r6_b_mel_wave_kernel.txt): STFT.inverse of 64 x 137 frames 0.272 -> 0.177 ms.  For powers of two it is level with the radix-2 kernel
+    // (512 / 1024 / 2048: 0.129 / 0.134 / 0.175 against 0.131 / 0.129 / 0.160 ms): the inverse is bound by its strided spectrum reads, the frame round trip
+    // through HBM and the overlap-add pass, not by the transform -- those lengths stay where they were.
+    if (n_fft == 1920 && (reinterpret_cast<uintptr_t>(window) & 7) == 0 && (reinterpret_cast<uintptr_t>(frames) & 7) == 0)
+        return launch_istft_wave<15>(a, b, polar, B, F, inv_scale, window, frames, stream);
     if ((n_fft & (n_fft - 1)) == 0) {
         int log2n = 0;
         while ((1 << log2n) < n_fft) ++log2n;

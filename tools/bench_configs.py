@@ -130,6 +130,17 @@ def mel(reps):
         b2 = 64 * w.shape[1] * 4 + 64 * n_mel * (w.shape[1] // hop) * 4
         out.append({"config": f"mel front end, n_fft {n_fft} / hop {hop} / {n_mel} mel, B=64 x {w.shape[1]} samples", "ms_per_step": ms2,
                     "samples_per_s": 64 * w.shape[1] / ms2 * 1e3, "algorithmic_GBps": b2 / ms2 / 1e6})
+    # the inverse direction (STFT.inverse, utils/stft.py:183-222: irfft frames + overlap-add) at the same lengths
+    from amphion_amd.utils.stft import STFT
+    for n_fft, hop in ((1024, 256), (2048, 512), (1920, 480), (512, 128)):
+        st = STFT(n_fft, hop, n_fft)
+        F = 65536 // hop + 1
+        g = torch.Generator().manual_seed(2)
+        magn = (torch.rand(64, n_fft // 2 + 1, F, generator=g) * 2).to(DEV)
+        ph = ((torch.rand(64, n_fft // 2 + 1, F, generator=g) * 2 - 1) * 3.14159).to(DEV)
+        ms3 = timed(lambda: st.inverse(magn, ph), max(2, reps // 2))
+        out.append({"config": f"inverse STFT, n_fft {n_fft} / hop {hop}, B=64 x {F} frames", "ms_per_step": ms3,
+                    "samples_per_s": 64 * (F - 1) * hop / ms3 * 1e3, "algorithmic_GBps": (2 * magn.numel() * 4 + 64 * (F - 1) * hop * 4) / ms3 / 1e6})
     return out
 
 
