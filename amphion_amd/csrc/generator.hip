@@ -91,6 +91,7 @@ void manifest_add(const char* name, unsigned long long workgroups, double gflop,
     if (!f) return;
     fprintf(f, "%s\t%llu\t%.6f\t%.6f\t%s\n", name, workgroups, gflop, mb, what);
     fflush(f);
+    tl_last_kernel[0] = '\0';   // a launcher that forgets note_kernel() shows up as an EMPTY name, not as the previous kernel's
 }
 static thread_local unsigned* tl_range_flag = nullptr;   // set while an amp_gen forward is launching: that handle's own word
 
@@ -363,6 +364,16 @@ struct Config {
         rb_fusion = num("AMP_RB_FUSION", 0, 3, 1);
         ampb_fusion = num("AMP_AMPB_FUSION", 0, 3, 1);
         rb_streams = num("AMP_RB_STREAMS", -1, 1, -1);
+        // a deployment that still sets one of the switches round 5 removed must hear about it -- once, here (AMP_GROUP_MB bounded the
+        // generator workspace: 168 MB instead of 2.7 GB at config 2; without a word the full-size workspace comes back after an upgrade)
+        static const char* const kRemoved[][2] = {
+            {"AMP_GROUP_MB", "amp_set_group_mb(megabytes)"}, {"AMP_PAIR_STRIP", "amp_set_pair_strips(mode)"}, {"AMP_CONV_BLK", "amp_set_conv_blk(mode)"},
+            {"AMP_FUSE_PAIRS", "nothing (the fused pairs are the only form)"}, {"AMP_RB_SUM_FRAMES", "nothing"},
+            {"AMP_RB_HORIZONTAL", "amp_set_resblock_streams(mode)"}, {"AMP_RB_HORIZONTAL_FRAMES", "amp_set_resblock_streams(mode)"}};
+        for (const auto& r : kRemoved) {
+            const char* e = getenv(r[0]);
+            if (e && *e) fprintf(stderr, "libamphion_hip: the environment variable %s=%s is no longer read (removed in ABI 142); use %s\n", r[0], e, r[1]);
+        }
     }
 };
 static Config& cfg() { static Config c; return c; }

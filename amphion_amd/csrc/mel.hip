@@ -291,9 +291,17 @@ static bool mel_radices(int n, MelRadices* out) {
         }
     return n == 1;
 }
+// THE gate of the four entry points (one check, one message).  Every length in the range runs: smooth ones on compile-time butterflies,
+// a prime factor p > 13 as a run-time radix pass of N p complex MACs per frame -- a PRIME n_fft is one pass of N^2 (n_fft = 4093: 16.7 M MACs per frame in one
+// 256-thread workgroup, three orders of magnitude slower per sample than 1024; documented in amphion_hip.h).
 bool mel_nfft_supported(int n_fft) {
     MelRadices r;
-    return n_fft >= 16 && n_fft <= 4096 && mel_radices(n_fft, &r);
+    return n_fft >= 64 && n_fft <= 4096 && mel_radices(n_fft, &r);
+}
+static bool mel_nfft_check(const char* who, int n_fft) {
+    if (mel_nfft_supported(n_fft)) return true;
+    set_error("%s: n_fft=%d must lie in [64, 4096] (torch.stft semantics for every length in that range)", who, n_fft);
+    return false;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1563,8 +1571,7 @@ int amp_mel_forward_ragged(const amp_mel_desc* d_in, const float* wav_dev, const
     if (!mel_desc_in(d_in, &dn, "amp_mel_forward_ragged")) return AMP_ERR_INVALID;
     const amp_mel_desc* d = &dn;
     if (!d || !wav_dev || !window_dev) { set_error("amp_mel_forward: null argument"); return AMP_ERR_INVALID; }
-    if (d->n_fft < 64 || d->n_fft > 4096 || !mel_nfft_supported(d->n_fft)) {
-        set_error("amp_mel_forward: n_fft=%d must lie in [64, 4096] (torch.stft semantics for every length in that range)", d->n_fft);
+    if (!mel_nfft_check("amp_mel_forward", d->n_fft)) {
         return AMP_ERR_UNSUPPORTED;
     }
     if (d->hop_size <= 0 || B <= 0 || L <= 0) { set_error("amp_mel_forward: hop=%d B=%d L=%d", d->hop_size, B, L); return AMP_ERR_INVALID; }
@@ -1585,8 +1592,7 @@ int amp_istft_forward(const amp_mel_desc* d_in, const float* mag_dev, const floa
     if (!mel_desc_in(d_in, &dn, "amp_istft_forward")) return AMP_ERR_INVALID;
     const amp_mel_desc* d = &dn;
     if (!d || !mag_dev || !phase_dev || !window_dev || !wss_dev || !frames_ws_dev || !wav_dev) { set_error("amp_istft_forward: null argument"); return AMP_ERR_INVALID; }
-    if (d->n_fft < 64 || d->n_fft > 4096 || !mel_nfft_supported(d->n_fft)) {
-        set_error("amp_istft_forward: n_fft=%d must lie in [64, 4096]", d->n_fft);
+    if (!mel_nfft_check("amp_istft_forward", d->n_fft)) {
         return AMP_ERR_UNSUPPORTED;
     }
     if (d->hop_size <= 0 || d->hop_size > d->n_fft || B <= 0 || F <= 1) { set_error("amp_istft_forward: hop=%d B=%d F=%d", d->hop_size, B, F); return AMP_ERR_INVALID; }
@@ -1601,8 +1607,8 @@ int amp_istft_same(const amp_mel_desc* d_in, const float* re_dev, const float* i
     if (!mel_desc_in(d_in, &dn, "amp_istft_same")) return AMP_ERR_INVALID;
     const amp_mel_desc* d = &dn;
     if (!d || !re_dev || !im_dev || !window_dev || !envelope_dev || !frames_ws_dev || !wav_dev) { set_error("amp_istft_same: null argument"); return AMP_ERR_INVALID; }
-    if (d->n_fft < 64 || d->n_fft > 4096 || !mel_nfft_supported(d->n_fft) || d->win_size != d->n_fft) {
-        set_error("amp_istft_same: n_fft=%d must lie in [64, 4096] and equal win_size=%d", d->n_fft, d->win_size);
+    if (!mel_nfft_check("amp_istft_same", d->n_fft) || d->win_size != d->n_fft) {
+        if (d->win_size != d->n_fft && mel_nfft_supported(d->n_fft)) set_error("amp_istft_same: n_fft=%d must equal win_size=%d", d->n_fft, d->win_size);
         return AMP_ERR_UNSUPPORTED;
     }
     if (d->hop_size <= 0 || d->hop_size > d->n_fft || ((d->win_size - d->hop_size) & 1) || B <= 0 || F <= 0) { set_error("amp_istft_same: hop=%d B=%d F=%d", d->hop_size, B, F); return AMP_ERR_INVALID; }
@@ -1620,8 +1626,7 @@ int amp_mel_backward(const amp_mel_desc* d_in, const int32_t* lens_dev, int B, i
     const amp_mel_desc* d = &dn;
     if (!d || !window_dev || !melbasis_dev || !mel_linear_dev || !mag_dev || !re_dev || !im_dev || !grad_logmel_dev || !spec_ws_dev ||
         !frames_ws_dev || !grad_wav_dev) { set_error("amp_mel_backward: null argument"); return AMP_ERR_INVALID; }
-    if (d->n_fft < 64 || d->n_fft > 4096 || !mel_nfft_supported(d->n_fft)) {
-        set_error("amp_mel_backward: n_fft=%d must lie in [64, 4096] and have no prime factor above 13", d->n_fft);
+    if (!mel_nfft_check("amp_mel_backward", d->n_fft)) {
         return AMP_ERR_UNSUPPORTED;
     }
     if (d->hop_size <= 0 || d->n_mel <= 0 || B <= 0 || L <= 0) { set_error("amp_mel_backward: hop=%d n_mel=%d B=%d L=%d", d->hop_size, d->n_mel, B, L); return AMP_ERR_INVALID; }

@@ -393,7 +393,7 @@ int amp_set_small_conv(int on);
 /* Transposed convs and k = 3 / 7 / 11 convs whose GEMM rows are a multiple of 256 (ConvTranspose1d: Cout * stride) run, on grids
  * of 512+ workgroups, on the row-blocked kernel (csrc/conv_blk_f16x3.hip: 64 rows per wave, x staged once per 256 rows;
  * same bits as the pipelined kernel).  mode 0 keeps them on the pipelined kernel, 1 = one 16-channel chunk per staging
- * round, 2 = two where available, 3 = 2 + k = 7 / 11 on the A-fragment-ring form (default), -1 = back to AMP_CONV_BLK /
+ * round, 2 = two where available, 3 = 2 + k = 7 / 11 on the A-fragment-ring form (default), -1 = back to
  * the default -- an A/B and cross-check switch. */
 int amp_set_conv_blk(int mode);
 /* Conv1d with 128 output rows (BigVGAN's unpaired AMPBlock convs at C = 128) on the row-blocked kernel, two waves along the columns: 1
@@ -507,7 +507,11 @@ int amp_mel_num_frames(const amp_mel_desc* d, int L);
  * (may be NULL when n_mel == 0).  Outputs (any may be NULL): mel_dev [B, n_mel, F] (log-mel),
  * mag_dev [B, n_fft/2+1, F] (magnitude), re_dev/im_dev [B, n_fft/2+1, F].
  * The first n_fft = 1024 call on a device sets the kernel up (a 4.5-KB twiddle table, uploaded with a blocking copy under a
- * lock): inside a stream capture that first call is refused with AMP_ERR_STATE -- call amp_mel_init() (or one forward) first. */
+ * lock): inside a stream capture that first call is refused with AMP_ERR_STATE -- call amp_mel_init() (or one forward) first.
+ * COST by transform length (64 utterances of 65 536 samples, one MI355X): n_fft 1024 / 2048 / 512 / 1920 run one WAVE per frame (register butterflies,
+ * 0.040 / 0.051 / 0.053 / 0.103 ms); other powers of two and lengths whose prime factors are <= 13 run one WORKGROUP per frame (about 0.4-1 ms); a
+ * prime factor p > 13 adds a run-time radix pass of n_fft * p complex multiply-adds per frame, so a PRIME n_fft is a direct O(n_fft^2) DFT (4093: 16.7 M
+ * per frame, three orders of magnitude slower per sample than 1024) -- accepted because torch.stft accepts it, not because it is a sensible choice. */
 int amp_mel_forward(const amp_mel_desc* d, const float* wav_dev, int B, int L, const float* window_dev,
                     const float* melbasis_dev, float* mel_dev, float* mag_dev, float* re_dev, float* im_dev,
                     void* stream);

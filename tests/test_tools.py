@@ -65,3 +65,32 @@ def test_isa_mix_counts_instruction_classes(tmp_path):
     assert r.returncode == 0, r.stderr
     assert "ONE AT A TIME: 0 of 1" in r.stdout                         # the one load is never waited for with vmcnt(0)
     assert "'pk_f32': 1" in r.stdout and "'mfma': 1" in r.stdout and "'trans': 1" in r.stdout and "'lds': 1" in r.stdout and "'vmem': 1" in r.stdout
+
+
+def test_bench_line_is_compact_and_carries_every_config_at_both_ends():
+    """bench.py prints the compact form of its record (the driver keeps the head and the last ~2 KB of the line): <= 6 KB, the
+    contract's keys, `roofline`, `cpu_baseline`, and the summary of every BASELINE config as the FIRST and the LAST key -- checked on round 5's
+    full record (profiles/r5_bench.json, 12 KB)."""
+    import importlib.util
+    import json
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod_compact", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    full = json.loads(open(os.path.join(root, "profiles", "r5_bench.json")).read().strip().split("\n")[-1])
+    line = bench.compact_line(full, os.path.join(root, "gpurun_out", "bench_detail.json"))
+    text = json.dumps(line)
+    assert len(text) <= 6 * 1024, len(text)
+    keys = list(line)
+    assert keys[0] == "summary_ms" and keys[-1] == "summary_ms_tail" and line["summary_ms"] == line["summary_ms_tail"]
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert line[k] == full[k], k
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in line["roofline"], k
+    assert abs(line["roofline"]["frac"] - full["roofline"]["frac"]) <= 1e-4 * full["roofline"]["frac"]
+    assert line["cpu_baseline"]["cores"] == full["cpu_baseline"]["cores"] and line["cpu_baseline"]["kind"] == "port"
+    tail = text[-2048:]
+    for k in ("c3_bigvgan_ms", "c2_strict_fp32_ms", "c5_vits_decode_ms", "c1_clips_ms", "cpu_b4_x_realtime"):
+        assert k in tail, k
