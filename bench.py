@@ -43,7 +43,7 @@ PEAK_HBM_GBS = 8000.0
 # (2192 TF on zeros, 1580-1630 TF on random data), so this -- not 2516.6 -- is what a perfect kernel gets.
 SUSTAINED_F16_TFLOPS = 1600.0
 # written by tools/summarize_prof.py from the FETCH_SIZE / WRITE_SIZE passes of tools/gpu_round.sh (newest round first)
-PROFILE_TRAFFIC_CSVS = [os.path.join(ROOT, "profiles", n) for n in ("r5_hbm_traffic.csv", "r4_hbm_traffic.csv", "r3_hbm_traffic.csv", "r2_hbm_traffic.csv")]
+PROFILE_TRAFFIC_CSVS = [os.path.join(ROOT, "profiles", n) for n in ("r6_hbm_traffic.csv", "r5_hbm_traffic.csv", "r4_hbm_traffic.csv", "r3_hbm_traffic.csv", "r2_hbm_traffic.csv")]
 # arithmetic of the conv contractions -> (dtype string, peak for ALGORITHMIC flops, note)
 PRECISIONS = {
     "f16x3": ("f32 (split-f16 MFMA: 3 x v_mfma_f32_32x32x16_f16 per term, f32 accumulate)", PEAK_F16_TFLOPS / 3.0,
