@@ -345,6 +345,14 @@ def compact_line(result, detail_path):
             rb = "seq" if "sequential" in cfg else "conc"
             short[f"{frames}f_{mode}_{rb}"] = float(f"{row.get('ms', 0.0):.4g}")
         line["other_configs"]["latency"] = short
+    oth = line.get("other_configs")
+    if isinstance(oth, dict) and isinstance(result.get("other_configs", {}).get("mel_front_end_other_nfft"), list):
+        short = {}                                              # seven rows -> {direction_nfft: ms}
+        for row in result["other_configs"]["mel_front_end_other_nfft"]:
+            cfg = row.get("config", "")
+            n = cfg.split("n_fft ")[1].split(" ")[0] if "n_fft " in cfg else "?"
+            short[("inverse_" if cfg.startswith("inverse") else "forward_") + n + "_ms"] = float(f"{row.get('ms_per_step', 0.0):.4g}")
+        oth["mel_front_end_other_nfft"] = short
     line["detail_file"] = os.path.relpath(detail_path, ROOT) if detail_path else None
     line["summary_ms_tail"] = result.get("summary_ms")
     return line
@@ -682,7 +690,7 @@ def main():
         # The full record (per-repeat arrays, notes, every sub-leg) goes to a side file; the printed line is the compact form: every required key,
         # `roofline`, `cpu_baseline`, one figure per leg, <= 6 KB, with the summary repeated as the LAST key -- a record that keeps only the head or
         # only the last ~2 KB of the line still carries every BASELINE config's number.
-        detail_path = os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+        detail_path = os.path.join(ROOT, "gpurun_out", "bench_detail.json" if "other_configs" in result else "bench_detail_headline_only.json")
         try:
             os.makedirs(os.path.dirname(detail_path), exist_ok=True)
             with open(detail_path, "w") as f:
