@@ -295,7 +295,7 @@ def _compact(o, strlen=90):
         return o if len(o) <= strlen else o[: strlen - 3] + "..."
     if isinstance(o, (list, tuple)):
         if o and all(isinstance(x, (int, float)) for x in o):
-            return [float(f"{x:.4g}") for x in o] if len(o) <= 4 else None
+            return [float(f"{x:.4g}") for x in o] if len(o) <= 8 else None      # (per-rank figures of an 8-GPU run stay)
         return [c for c in (_compact(x, strlen) for x in o) if c is not None]
     if isinstance(o, dict):
         out = {}
