@@ -415,3 +415,63 @@ def test_stft_new_lengths_golden(gn, tag):
     ref = gn[f"{tag}_inv_wav"]
     assert wav.shape == ref.shape
     assert np.abs(wav - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+# ---- round 6: the wave-per-frame kernels off n_fft = 1024 (mel_wave_kernel<16 | 15 | 4>) on the paths the goldens do not walk ----------------
+@pytest.mark.parametrize("sr,n_fft,hop,n_mel", [(44100, 2048, 512, 128), (24000, 1920, 480, 100), (16000, 512, 128, 80)])
+def test_mel_wave_kernel_ragged_batch_equals_per_utterance(sr, n_fft, hop, n_mel):
+    """A ragged batch through the wave-per-frame kernel (each utterance's reflection padding mirrors at ITS end, later frames of a row are left untouched)
+    == every utterance alone, bit for bit; and the oracle on each."""
+    from types import SimpleNamespace as NS
+
+    from amphion_amd.utils import mel as M
+
+    pp = NS(sample_rate=sr, n_fft=n_fft, win_size=n_fft, hop_size=hop, n_mel=n_mel, fmin=0, fmax=None)
+    g = torch.Generator().manual_seed(n_fft + 1)
+    lens = [hop * 43, hop * 9 + 77, n_fft + 5, hop * 21 - 3]
+    wavs = [(torch.rand(L, generator=g) * 2 - 1) * 0.8 for L in lens]
+    mels = M.extract_mel_features_batch(wavs, pp, device="cuda")
+    for w, m in zip(wavs, mels):
+        alone = M.extract_mel_features(w[None].cuda(), pp)        # (a batch of one comes back without its batch axis, as the reference's does)
+        assert m.shape == alone.shape and torch.equal(m, alone)
+        ref = vo.extract_mel_features(w[None], pp)
+        assert m.shape == ref.shape
+        _check_logmel(m.cpu().numpy(), ref.numpy(), f"n_fft {n_fft}: ragged item of {w.shape[0]} samples vs oracle")
+
+
+@pytest.mark.parametrize("n_fft,hop,n_mel", [(2048, 512, 256), (1920, 480, 200), (2048, 512, 160), (2048, 511, 80), (1920, 479, 64)])
+def test_mel_wave_kernel_limits_fall_back_without_changing_the_answer(n_fft, hop, n_mel):
+    """What the wave-per-frame kernel does not take -- more mel channels than its LDS holds beside eight exchange buffers, an odd hop (sample pairs must be 8-byte
+    pairs of ONE frame offset) -- runs on the one-workgroup-per-frame kernels: same semantics, checked against the oracle."""
+    from types import SimpleNamespace as NS
+
+    from amphion_amd.utils import mel as M
+
+    pp = NS(sample_rate=44100, n_fft=n_fft, win_size=n_fft, hop_size=hop, n_mel=n_mel, fmin=0, fmax=None)
+    g = torch.Generator().manual_seed(n_mel)
+    y = (torch.rand(2, hop * 14, generator=g) * 2 - 1) * 0.7
+    out = M.mel_spectrogram_torch(y.cuda(), pp).cpu()
+    ref = vo.mel_spectrogram_torch(y, pp)
+    _check_logmel(out.numpy(), ref.numpy(), f"n_fft {n_fft} hop {hop} n_mel {n_mel} vs oracle")
+
+
+def test_mel_wave_kernel_many_frames_and_shortest_signal():
+    """64 utterances x 128 frames (several workgroups per item, all eight waves busy) against the oracle on two probed items; and the shortest signal the
+    reflection padding admits (every frame an edge frame)."""
+    from types import SimpleNamespace as NS
+
+    from amphion_amd.utils import mel as M
+
+    pp = NS(sample_rate=24000, n_fft=1920, win_size=1920, hop_size=480, n_mel=128, fmin=0, fmax=12000)
+    g = torch.Generator().manual_seed(77)
+    y = (torch.rand(64, 480 * 128, generator=g) * 2 - 1) * 0.9
+    out = M.extract_mel_features(y.cuda(), pp).cpu()
+    for i in (0, 37, 63):
+        ref = vo.extract_mel_features(y[i: i + 1], pp)           # (a batch of one: no batch axis)
+        _check_logmel(out[i].numpy(), ref.numpy(), f"n_fft 1920, item {i} of 64")
+    pad = (1920 - 480) // 2
+    ys = (torch.rand(1, pad + 1 + 480, generator=g) * 2 - 1) * 0.5
+    ys = ys[:, : (ys.shape[1] // 480) * 480]
+    out = M.extract_mel_features(ys.cuda(), pp).cpu()
+    ref = vo.extract_mel_features(ys, pp)
+    _check_logmel(out.numpy(), ref.numpy(), "n_fft 1920, shortest signal")
