@@ -836,7 +836,7 @@ static int rb_fusion_mode() { return cfg().rb_fusion; }
 static int rb_form(int C, int k) {
     const int m = rb_fusion_mode();
     if (m == 0) return -1;
-    if (m == 3) return C == 32 ? 0 : 1;
+    if (m == 3) return (C == 32 || (C == 64 && k <= 5)) ? 0 : 1;
     if (m == 2) return 1;
     // policy: measured INSIDE the config-2 forward at thermal steady state, one box, modes alternating
     // (profiles/r3_e_inforward_resblock_modes_and_list_api_probe.txt; ms per resblock, fused pairs -> this kernel):
@@ -848,8 +848,12 @@ static int rb_form(int C, int k) {
     //           the package power limit what counts is energy per output, and 31 % recomputed MFMAs cancel the saved HBM round trips
     //   C = 128 k = 3 (eight waves, 256 columns, 16 guard columns: 147 KB) 1.91 -> 1.70; k = 5 2.70 -> 2.53 op-level
     // forward 29.15 -> 27.5 ms on that box.
+    // Round 6 (profiles/r6_h_rb_two_per_cu.txt, same method): C = 64 k = 3 as FOUR waves x 256 columns with 16 guard columns (74 KB: two workgroups per
+    // CU, 232 of 256 columns kept instead of 488 of 512) 1.02-1.04 -> 0.96 ms; the same form at k = 7 (split 2 + 1: 220 of 256 kept) 2.09 -> 2.12 and
+    // C = 128 k = 3 as four waves x 128 columns (104 of 128 kept) 1.74 -> 1.88 lose and were not kept.
     if (C == 32) return k >= 11 ? 1 : 0;
-    if (C == 64 || C == 128) return 1;           // C = 128: k <= 5 only (rb_tile)
+    if (C == 64) return k <= 5 ? 0 : 1;          // round 6: k <= 5 as four waves x 256 columns, two workgroups per CU (profiles/r6_h_rb_two_per_cu.txt)
+    if (C == 128) return 1;                      // k <= 5 only (rb_tile)
     return -1;
 }
 // the workgroups of a launch must at least fill the chip (256 CUs): a short single utterance keeps the pairs' 4x more numerous

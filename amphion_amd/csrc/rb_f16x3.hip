@@ -303,13 +303,13 @@ static hipError_t launch_rb_one(const RbArgs& a, hipStream_t stream) {
 #define AMP_CAT(a, b) AMP_CAT2(a, b)
 
 // Tile width W (columns evaluated per workgroup; outputs per tile = W - 2 * rh) for C channels in form `wide`
-// (1: eight waves, one workgroup per CU; 0: four waves, two per CU), or 0 when not covered.
+// (1: eight waves, one workgroup per CU; 0: four waves, two per CU -- C = 32, and C = 64 at k <= 5 since round 6), or 0 when not covered.
 int AMP_CAT(rb_tile_kt, AMP_KT)(int C, int max_dil, int wide) {
     constexpr int KT = AMP_KT;
     const int reach = (KT - 1) / 2 * max_dil;
     if (reach > 32) return 0;
     if (C == 32) return wide ? 1024 : 512;
-    if (C == 64) return wide ? 512 : 0;
+    if (C == 64) return wide ? 512 : ((KT <= 5 && reach <= 16) ? 256 : 0);   // four waves x 256 columns, 16 guard columns: 74 KB, two workgroups per CU
     if (C == 128) return (wide && KT <= 5 && reach <= 16) ? 256 : 0;
     return 0;
 }
@@ -320,8 +320,12 @@ hipError_t AMP_CAT(launch_rb_kt, AMP_KT)(const RbArgs& a, int wide, hipStream_t 
     if (a.C == 32) return wide ? launch_rb_one<KT, 1, 8, 4, RING>(a, stream) : launch_rb_one<KT, 1, 4, 4, RING>(a, stream);
     if (a.C == 64 && wide) return launch_rb_one<KT, 2, 4, 4, RING>(a, stream);
     if constexpr (KT <= 5) {
+        if (a.C == 64 && !wide) return launch_rb_one<KT, 2, 2, 4, 0, 16>(a, stream);
+    }
+    if constexpr (KT <= 5) {
         if (a.C == 128 && wide) return launch_rb_one<KT, 4, 2, 4, 0, 16>(a, stream);
     }
+
     return hipErrorInvalidValue;
 }
 

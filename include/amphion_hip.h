@@ -351,7 +351,7 @@ int amp_resblock_forward(const amp_conv* const* c1, const amp_conv* const* c2, i
                          float slope, float* y_dev, void* stream);
 /* 0: generators run every ResBlock1 as fused pairs; 1 (default): the measured policy (whole-resblock kernel for the narrow
  * late stages when the launch fills the chip); 2: wherever the kernel is built, any grid; 3: as 2 with the four-wave
- * 512-column tiles at C = 32.  Bit-identical results in every mode (tests/test_gpu_resblock.py); env AMP_RB_FUSION. */
+ * tiles (two workgroups per CU) at C = 32 (512 columns) and at C = 64, k <= 5 (256 columns).  Bit-identical results in every mode (tests/test_gpu_resblock.py); env AMP_RB_FUSION. */
 int amp_set_resblock_fusion(int mode);
 /* The n_kernels resblocks of a generator stage on CONCURRENT streams (they read the same stage tensor and only meet in the MRF mean,
  * hifigan.py:208-214 / bigvgan.py:320-327): -1 (default) while B * T <= 4096 mel frames -- small batches, whose launches do not
