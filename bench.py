@@ -364,7 +364,8 @@ def compact_line(result, detail_path):
             mode = "graph" if "hipGraph" in cfg else "api" if "public API" in cfg else "eager"
             frames = "860" if "860 frames" in cfg else "256"
             rb = "seq" if "sequential" in cfg else "conc"
-            short[f"{frames}f_{mode}_{rb}"] = float(f"{row.get('ms', 0.0):.4g}")
+            model = "bigvgan_" if "BigVGAN" in cfg else ""
+            short[f"{model}{frames}f_{mode}_{rb}"] = float(f"{row.get('ms', 0.0):.4g}")
         line["other_configs"]["latency"] = short
     oth = line.get("other_configs")
     if isinstance(oth, dict) and isinstance(result.get("other_configs", {}).get("mel_front_end_other_nfft"), list):
