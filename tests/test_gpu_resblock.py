@@ -73,6 +73,9 @@ CASES = [
     (64, 7, (1, 3, 5), 300, 1400),
     (128, 3, (1, 3, 5), 300, 800),
     (32, 5, (2, 6), 520, 1500),
+    # round 6: C = 64, k <= 5 as four waves x 256 columns (two workgroups per CU) -- mode 3 and the policy; thousands of tiles, a cut of T that leaves a 1-column last tile
+    (64, 3, (1, 3, 5), 200, 2089),
+    (64, 5, (1, 3, 5), 40, 3000),
 ]
 
 
