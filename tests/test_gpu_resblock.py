@@ -190,7 +190,7 @@ def test_low_yield_resblock_runs_as_two_launches_with_the_same_bits(fusion, tmp_
             "torch.cuda.synchronize()\n" % (root, hp))
     for B, want in ((64, {"4 convs", "2 convs +sum"}), (32, {"6 convs +sum"})):
         man = tmp_path / f"manifest_{B}.tsv"
-        r = subprocess.run([sys.executable, "-c", code, str(B)], capture_output=True, text=True, env=dict(os.environ, AMP_LAUNCH_MANIFEST=str(man), AMP_RB_FUSION="1"), timeout=600)   # the POLICY's split, whatever the caller's environment says
+        r = subprocess.run([sys.executable, "-c", code, str(B)], capture_output=True, text=True, env=dict(os.environ, AMP_LAUNCH_MANIFEST=str(man), AMP_RB_FUSION="1", AMP_PRECISION="f16x3"), timeout=600)   # the POLICY's split, whatever the caller's environment says
         assert r.returncode == 0, r.stderr[-2000:]
         work = {l.rstrip("\n").split("\t")[4].split(": ")[1] for l in open(man) if "whole ResBlock C=64 k=11" in l}
         assert work == want, (B, work)
