@@ -130,3 +130,24 @@ def test_config5_vits_full_size():
     err = (o[probe].cpu() - ro).abs().max().item()
     print(f"config 5 full size: |hip - oracle| on items {probe} = {err:.2e}")
     assert err <= TOL
+
+
+def test_config4_global_batch_on_one_gpu_equals_its_shards():
+    """BASELINE configs[3]'s GLOBAL batch (512 x 80 x 256) on ONE GPU: every stage tensor of the late stages is 4.3 GB (byte offsets beyond
+    2^32) -- the [512, 1, 65536] result equals the eight 64-item shards the ranks of an 8-GPU run would vocode, bit for bit (the
+    gathered tensor == N single-GPU runs), and the workspace stays far inside the 288 GB."""
+    from amphion_amd.models.vocoders.gan.generator.hifigan import HiFiGAN
+
+    hp = vo.hifigan_v1_hp()
+    m = HiFiGAN(NS(preprocess=NS(n_mel=80, hop_size=256), model=NS(hifigan=NS(**hp))))
+    m.load_state_dict(synth.synth_state_dict(synth.hifigan_param_shapes(80, hp), 1234))
+    m = m.cuda().eval()
+    mel = synth.synth_mel(512, 80, 256, seed=11).cuda()
+    torch.cuda.reset_peak_memory_stats()
+    with torch.no_grad():
+        big = m(mel)
+        assert big.shape == (512, 1, 65536) and torch.isfinite(big).all()
+        for r in range(8):
+            shard = m(mel[64 * r:64 * (r + 1)].contiguous())
+            assert torch.equal(shard, big[64 * r:64 * (r + 1)]), f"shard {r} differs from the rows of the 512-item forward"
+    assert torch.cuda.max_memory_allocated() < 64 * 2**30
